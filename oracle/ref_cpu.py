@@ -1,0 +1,357 @@
+"""CPU oracle for the TEC-MoLLM forward/backward hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain fp32 PyTorch-CPU *restatement* of the reference algorithm
+(`/root/reference/src/model/tec_mollm.py:59-125` and `src/model/modules.py`).
+It exists so that the HIP path can be checked against an independent statement of
+the same arithmetic.  Only `tests/`, `__graft_entry__.smoke()` and the
+`cpu_baseline` leg of `bench.py` may import it; the product package
+(`tec-mollm_amd/`) never does and fails loudly when its HIP library is missing.
+
+Pinning status (see DESIGN.md "Oracle"):
+  * embed / temporal encoder / prediction head / full wiring -- PINNED against the
+    reference's own classes, imported in the authoring container by
+    `oracle/make_golden.py`; vectors committed under `tests/golden/`.
+  * GPT-2 block math -- PINNED against the installed `transformers` 5.15.0
+    `GPT2Model` (the reference's call sites: modules.py:165,170,208), same script.
+  * GATv2Conv (torch_geometric) and LoRA (peft) -- third-party packages that are
+    not installed anywhere in this environment and whose versions the reference
+    does not pin: **parity unpinned**.  They are restated from the published
+    algorithm (Brody et al. 2021 / PyG `GATv2Conv`; Hu et al. 2021 / peft `Linear`)
+    and cross-checked by an independent dense-adjacency formulation in
+    `tests/test_oracle.py`.
+
+Everything is functional: parameters come in as a dict keyed by the reference's
+state-dict names, activations are ordinary tensors, gradients
+come from torch autograd on CPU.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+Params = Dict[str, torch.Tensor]
+
+# --------------------------------------------------------------------------- names
+P_EMB = "spatio_temporal_embedding."
+P_GAT = "spatial_encoder.gat_conv."
+P_CONV = "temporal_encoder.conv_embedder.embedder."
+P_PATCH = "temporal_encoder.patcher.projection."
+P_GPT = "llm_backbone.model.base_model.model."
+P_HEAD = "prediction_head.mlp."
+
+LORA_R = 32
+LORA_ALPHA = 64
+LORA_SCALE = LORA_ALPHA / LORA_R  # modules.py:177-183  (alpha / r = 2.0)
+GAT_NEG_SLOPE = 0.2
+GPT2_HEADS = 12
+LN_EPS = 1e-5
+
+
+# ------------------------------------------------------------------- stage a-1
+def embed(x: torch.Tensor, tf: torch.Tensor, p: Params) -> torch.Tensor:
+    """SpatioTemporalEmbedding.forward, modules.py:230-266.
+
+    x (B,L,N,C_in) f32, tf (B,L,N,4) f32 integer-valued -> (B,L,N,C_in+d_emb).
+    Sum order follows modules.py:260-261: ((tod+doy)+year)+season, then node + temporal.
+    """
+    B, L, N, _ = x.shape
+    node = p[P_EMB + "node_embedding.weight"][torch.arange(N)].view(1, 1, N, -1)
+    tod = p[P_EMB + "tod_embedding.weight"][tf[..., 0].long()]
+    doy = p[P_EMB + "doy_embedding.weight"][tf[..., 1].long()]
+    year = p[P_EMB + "year_embedding.weight"][tf[..., 2].long()]
+    season = p[P_EMB + "season_embedding.weight"][tf[..., 3].long()]
+    temporal = tod + doy + year + season
+    return torch.cat([x, node + temporal], dim=-1)
+
+
+# ------------------------------------------------------------------- stage a-2
+def gatv2_conv(x: torch.Tensor, edge_index: torch.Tensor, p: Params, heads: int,
+               alpha_keep: Optional[torch.Tensor] = None, drop_p: float = 0.0) -> torch.Tensor:
+    """torch_geometric.nn.GATv2Conv(in, out, heads, concat=True, add_self_loops=True,
+    share_weights=False, negative_slope=0.2) restated (call site modules.py:329-336,:356).
+
+    x (M, C); edge_index (2,E) int64 with [0]=source j, [1]=target i.  Self loops in
+    edge_index are removed, then one self loop per row is appended for ALL M rows
+    (PyG: `add_self_loops(edge_index, num_nodes=x.size(0))`).  Softmax per target with
+    max-subtraction and `+1e-16` in the denominator (PyG `utils.softmax`).
+    `alpha_keep` (E',heads) in {0,1}: optional dropout keep-mask applied to alpha as
+    alpha*keep/(1-drop_p); edge order = [non-self edges in given order, then self loops 0..M-1].
+    """
+    M, C = x.shape
+    Wl, bl = p[P_GAT + "lin_l.weight"], p[P_GAT + "lin_l.bias"]
+    Wr, br = p[P_GAT + "lin_r.weight"], p[P_GAT + "lin_r.bias"]
+    att, bias = p[P_GAT + "att"], p[P_GAT + "bias"]          # att (1,H,Ch)
+    H = heads
+    Ch = Wl.shape[0] // H
+    xl = (x @ Wl.t() + bl).view(M, H, Ch)                    # source side
+    xr = (x @ Wr.t() + br).view(M, H, Ch)                    # target side
+    src, dst = edge_index[0], edge_index[1]
+    keep = src != dst
+    loops = torch.arange(M, dtype=edge_index.dtype)
+    src = torch.cat([src[keep], loops])
+    dst = torch.cat([dst[keep], loops])
+    s = xl[src] + xr[dst]                                    # (E',H,Ch)
+    e = (F.leaky_relu(s, GAT_NEG_SLOPE) * att.view(1, H, Ch)).sum(-1)   # (E',H)
+    emax = torch.full((M, H), float("-inf")).scatter_reduce(
+        0, dst.view(-1, 1).expand(-1, H), e, reduce="amax", include_self=True)
+    pexp = (e - emax[dst]).exp()
+    denom = torch.zeros(M, H).index_add_(0, dst, pexp) + 1e-16
+    alpha = pexp / denom[dst]
+    if alpha_keep is not None:
+        alpha = alpha * alpha_keep / (1.0 - drop_p)
+    out = torch.zeros(M, H, Ch).index_add_(0, dst, alpha.unsqueeze(-1) * xl[src])
+    return out.reshape(M, H * Ch) + bias
+
+
+def batched_edge_index(edge_index: torch.Tensor, num_nodes: int, num_graphs: int) -> torch.Tensor:
+    """edge_index replicated with offsets g*N for g < num_graphs (what PyG batching would
+    have produced had the reference built a Batch; it does not -- SURVEY.md section 0)."""
+    offs = (torch.arange(num_graphs, dtype=edge_index.dtype) * num_nodes).view(1, -1, 1)
+    return (edge_index.unsqueeze(1) + offs).reshape(2, -1)
+
+
+def spatial(h: torch.Tensor, edge_index: torch.Tensor, p: Params, heads: int,
+            graphs_with_edges: Optional[int] = 1) -> torch.Tensor:
+    """tec_mollm.py:84-94 + modules.py:340-359: permute to (L*B, N, C), GATv2 on the
+    flattened (L*B*N, C) rows, residual add.  Returns x_spatial (L*B, N, C).
+
+    graphs_with_edges=1 is the reference's literal behaviour: edge ids < N only touch
+    graph 0 (t=0,b=0); every other row sees just its self loop.  None = every one of the
+    L*B graphs gets the edges (the per-timestep behaviour the reference's comments intend).
+    """
+    B, L, N, C = h.shape
+    xg = h.permute(1, 0, 2, 3).reshape(-1, N, C)
+    G = L * B if graphs_with_edges is None else graphs_with_edges
+    ei = batched_edge_index(edge_index, N, G)
+    gat = gatv2_conv(xg.reshape(-1, C), ei, p, heads).view(L * B, N, C)
+    return xg + gat
+
+
+# ------------------------------------------------------------------- stage a-4/a-5
+def conv_block(x: torch.Tensor, p: Params, idx: int, stride: int) -> torch.Tensor:
+    """Multi_Scale_Conv_Block.forward, modules.py:43-60: x (S, C_in, L)."""
+    outs = []
+    for j, k in enumerate((3, 5, 7)):
+        pre = f"{P_CONV}{idx}.convs.{j}."
+        y = F.conv1d(x, p[pre + "0.weight"], p[pre + "0.bias"], padding=(k - 1) // 2)
+        y = F.group_norm(y, 1, p[pre + "1.weight"], p[pre + "1.bias"], eps=1e-5)
+        outs.append(F.gelu(y))
+    cat = torch.cat(outs, dim=1)
+    pre = f"{P_CONV}{idx}.final_conv."
+    return F.conv1d(cat, p[pre + "weight"], p[pre + "bias"], stride=stride)
+
+
+def temporal_encoder(x: torch.Tensor, p: Params, strides, patch_len: int) -> torch.Tensor:
+    """TemporalEncoder.forward modules.py:134-154 + LatentPatchingProjection :100-119.
+    x (S, L, C) -> (S, P, d_llm).  Patch vector index = l*D + d (einops 'b (p l) d -> b p (l d)')."""
+    y = x.permute(0, 2, 1)
+    for i, s in enumerate(strides):
+        y = conv_block(y, p, i, s)
+    y = y.permute(0, 2, 1)                                   # (S, L', D)
+    S, Lc, D = y.shape
+    y = y.reshape(S, Lc // patch_len, patch_len * D)
+    return y @ p[P_PATCH + "weight"].t() + p[P_PATCH + "bias"]
+
+
+# ------------------------------------------------------------------- stage a-6
+def gelu_new(x: torch.Tensor) -> torch.Tensor:
+    """transformers NewGELUActivation (GPT-2 `activation_function='gelu_new'`)."""
+    return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * x.pow(3))))
+
+
+def gpt2_lora(h: torch.Tensor, p: Params, n_layers: int) -> torch.Tensor:
+    """LLMBackbone.forward modules.py:205-209 -> peft(GPT2Model)(inputs_embeds=h, all-ones mask).
+    Eval-mode (all dropouts off).  h (S, T, 768).  c_attn' = base Conv1D + 2.0 * B(A(u))."""
+    S, T, D = h.shape
+    hd = D // GPT2_HEADS
+    h = h + p[P_GPT + "wpe.weight"][:T]
+    causal = torch.tril(torch.ones(T, T, dtype=torch.bool))
+    for i in range(n_layers):
+        pre = f"{P_GPT}h.{i}."
+        u = F.layer_norm(h, (D,), p[pre + "ln_1.weight"], p[pre + "ln_1.bias"], LN_EPS)
+        qkv = u @ p[pre + "attn.c_attn.base_layer.weight"] + p[pre + "attn.c_attn.base_layer.bias"]
+        A = p[pre + "attn.c_attn.lora_A.default.weight"]     # (r, 768)
+        Bm = p[pre + "attn.c_attn.lora_B.default.weight"]    # (2304, r)
+        qkv = qkv + LORA_SCALE * ((u @ A.t()) @ Bm.t())
+        q, k, v = qkv.split(D, dim=-1)
+        q = q.view(S, T, GPT2_HEADS, hd).transpose(1, 2)
+        k = k.view(S, T, GPT2_HEADS, hd).transpose(1, 2)
+        v = v.view(S, T, GPT2_HEADS, hd).transpose(1, 2)
+        w = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
+        w = w.masked_fill(~causal, float("-inf")).softmax(-1)
+        ctx = (w @ v).transpose(1, 2).reshape(S, T, D)
+        h = h + ctx @ p[pre + "attn.c_proj.weight"] + p[pre + "attn.c_proj.bias"]
+        u = F.layer_norm(h, (D,), p[pre + "ln_2.weight"], p[pre + "ln_2.bias"], LN_EPS)
+        f = gelu_new(u @ p[pre + "mlp.c_fc.weight"] + p[pre + "mlp.c_fc.bias"])
+        h = h + f @ p[pre + "mlp.c_proj.weight"] + p[pre + "mlp.c_proj.bias"]
+    return F.layer_norm(h, (D,), p[P_GPT + "ln_f.weight"], p[P_GPT + "ln_f.bias"], LN_EPS)
+
+
+# ------------------------------------------------------------------- stage a-8
+def head(x: torch.Tensor, p: Params) -> torch.Tensor:
+    """PredictionHead.forward modules.py:295-313 (eval): (S,T,768) -> (S, L_out)."""
+    z = x.reshape(x.shape[0], -1)
+    z = F.gelu(z @ p[P_HEAD + "0.weight"].t() + p[P_HEAD + "0.bias"])
+    return z @ p[P_HEAD + "3.weight"].t() + p[P_HEAD + "3.bias"]
+
+
+# ------------------------------------------------------------------- full path
+def forward(x: torch.Tensor, tf: torch.Tensor, edge_index: torch.Tensor, p: Params, cfg: dict,
+            graphs_with_edges: Optional[int] = 1) -> torch.Tensor:
+    """TEC_MoLLM.forward tec_mollm.py:59-125, eval mode.  Returns (B, L_out, N, 1)."""
+    B, L, N, _ = x.shape
+    h = embed(x, tf, p)
+    xs = spatial(h, edge_index, p, cfg["spatial_heads"], graphs_with_edges)
+    C = xs.shape[-1]
+    xt = xs.view(L, B, N, C).permute(1, 2, 0, 3).reshape(B * N, L, C)
+    tok = temporal_encoder(xt, p, cfg["temporal_strides"], cfg["patch_len"])
+    hid = gpt2_lora(tok, p, cfg["llm_layers"])
+    pred = head(hid, p)
+    return pred.view(B, N, -1).permute(0, 2, 1).unsqueeze(-1)
+
+
+def huber(out: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """nn.HuberLoss(delta=1.0), mean reduction (train.py:372)."""
+    return F.huber_loss(out, y, delta=1.0)
+
+
+# ------------------------------------------------------------------- parameters
+def default_config(L_in: int = 48, L_out: int = 12, num_nodes: int = 2911, c_in: int = 6,
+                   d_emb: int = 16, llm_layers: int = 3) -> dict:
+    """model_config dict as built at train.py:249-269 (patch_len fallback 4 -> 2 -> 1)."""
+    conv_len = L_in // 4
+    patch_len = 4
+    if conv_len % patch_len != 0:
+        patch_len = 2 if conv_len % 2 == 0 else 1
+    return {
+        "num_nodes": num_nodes, "d_emb": d_emb, "spatial_in_channels_base": c_in,
+        "spatial_out_channels": (c_in + d_emb) // 2, "spatial_heads": 2,
+        "temporal_channel_list": [64, 128], "temporal_strides": [2, 2], "patch_len": patch_len,
+        "d_llm": 768, "llm_layers": llm_layers, "prediction_horizon": L_out,
+        "temporal_seq_len": L_in, "num_years": 13,
+    }
+
+
+def init_params(cfg: dict, seed: int = 0, include_wte: bool = False) -> Params:
+    """Deterministic config-style initialisation under the reference's state-dict names.
+    GPT-2 weights N(0, 0.02) (pretrained weights are unavailable offline); LoRA B is
+    NON-zero so the LoRA path is exercised; LayerNorm/GroupNorm affine perturbed off 1/0."""
+    g = torch.Generator().manual_seed(seed)
+
+    def rn(*shape, std=1.0):
+        return torch.randn(*shape, generator=g) * std
+
+    def lin(out_f, in_f):
+        b = 1.0 / math.sqrt(in_f)
+        return ((torch.rand(out_f, in_f, generator=g) * 2 - 1) * b,
+                (torch.rand(out_f, generator=g) * 2 - 1) * b)
+
+    p: Params = {}
+    d = cfg["d_emb"]
+    N = cfg["num_nodes"]
+    for name, rows in (("node", N), ("tod", 12), ("doy", 366), ("year", cfg.get("num_years", 13)),
+                       ("season", 4)):
+        p[f"{P_EMB}{name}_embedding.weight"] = rn(rows, d)
+    C = cfg["spatial_in_channels_base"] + d
+    H, Ch = cfg["spatial_heads"], cfg["spatial_out_channels"]
+    assert H * Ch == C, "residual needs base + d_emb == out_channels*heads (tec_mollm.py:94)"
+    p[P_GAT + "att"] = rn(1, H, Ch, std=0.4)
+    p[P_GAT + "bias"] = rn(C, std=0.1)
+    for s in ("l", "r"):
+        p[f"{P_GAT}lin_{s}.weight"] = rn(H * Ch, C, std=1.0 / math.sqrt(C))
+        p[f"{P_GAT}lin_{s}.bias"] = rn(H * Ch, std=0.1)
+    cin = C
+    for i, cout in enumerate(cfg["temporal_channel_list"]):
+        for j, k in enumerate((3, 5, 7)):
+            b = 1.0 / math.sqrt(cin * k)
+            p[f"{P_CONV}{i}.convs.{j}.0.weight"] = (torch.rand(cout, cin, k, generator=g) * 2 - 1) * b
+            p[f"{P_CONV}{i}.convs.{j}.0.bias"] = (torch.rand(cout, generator=g) * 2 - 1) * b
+            p[f"{P_CONV}{i}.convs.{j}.1.weight"] = 1.0 + rn(cout, std=0.1)
+            p[f"{P_CONV}{i}.convs.{j}.1.bias"] = rn(cout, std=0.1)
+        b = 1.0 / math.sqrt(3 * cout)
+        p[f"{P_CONV}{i}.final_conv.weight"] = (torch.rand(cout, 3 * cout, 1, generator=g) * 2 - 1) * b
+        p[f"{P_CONV}{i}.final_conv.bias"] = (torch.rand(cout, generator=g) * 2 - 1) * b
+        cin = cout
+    D = cfg["d_llm"]
+    p[P_PATCH + "weight"], p[P_PATCH + "bias"] = lin(D, cfg["patch_len"] * cin)
+    if include_wte:
+        p[P_GPT + "wte.weight"] = rn(50257, D, std=0.02)
+    p[P_GPT + "wpe.weight"] = rn(1024, D, std=0.02)
+    for i in range(cfg["llm_layers"]):
+        pre = f"{P_GPT}h.{i}."
+        for ln in ("ln_1", "ln_2"):
+            p[pre + ln + ".weight"] = 1.0 + rn(D, std=0.1)
+            p[pre + ln + ".bias"] = rn(D, std=0.1)
+        p[pre + "attn.c_attn.base_layer.weight"] = rn(D, 3 * D, std=0.02)
+        p[pre + "attn.c_attn.base_layer.bias"] = rn(3 * D, std=0.02)
+        p[pre + "attn.c_attn.lora_A.default.weight"] = rn(LORA_R, D, std=1.0 / math.sqrt(D))
+        p[pre + "attn.c_attn.lora_B.default.weight"] = rn(3 * D, LORA_R, std=0.02)
+        p[pre + "attn.c_proj.weight"] = rn(D, D, std=0.02)
+        p[pre + "attn.c_proj.bias"] = rn(D, std=0.02)
+        p[pre + "mlp.c_fc.weight"] = rn(D, 4 * D, std=0.02)
+        p[pre + "mlp.c_fc.bias"] = rn(4 * D, std=0.02)
+        p[pre + "mlp.c_proj.weight"] = rn(4 * D, D, std=0.02)
+        p[pre + "mlp.c_proj.bias"] = rn(D, std=0.02)
+    p[P_GPT + "ln_f.weight"] = 1.0 + rn(D, std=0.1)
+    p[P_GPT + "ln_f.bias"] = rn(D, std=0.1)
+    n_patches = (cfg["temporal_seq_len"] // (cfg["temporal_strides"][0] * cfg["temporal_strides"][1])) \
+        // cfg["patch_len"]
+    hin = D * n_patches
+    p[P_HEAD + "0.weight"], p[P_HEAD + "0.bias"] = lin(hin // 4, hin)
+    p[P_HEAD + "3.weight"], p[P_HEAD + "3.bias"] = lin(cfg["prediction_horizon"], hin // 4)
+    return p
+
+
+def is_trainable(name: str) -> bool:
+    """Freeze rule modules.py:195-203: inside the HF model only lora_/ln_/wpe train."""
+    if name.startswith("llm_backbone."):
+        return ("lora_" in name) or ("ln_" in name) or ("wpe" in name)
+    return True
+
+
+# ------------------------------------------------------------------- synthetic inputs
+def grid_graph(n_lat: int = 41, n_lon: int = 71, lat0: float = 15.0, lon0: float = 70.0,
+               step: float = 1.0, threshold_km: float = 150.0):
+    """Haversine <= threshold adjacency on a regular lat/lon grid, no self loops,
+    symmetric-normalised weights -- graph_constructor.py:46-56, :75-78, :112-125, :141-144.
+    Node id = lat_index * n_lon + lon_index (meshgrid + ravel order, :46-47)."""
+    import numpy as np
+    lat = np.radians(lat0 + step * np.arange(n_lat))
+    lon = np.radians(lon0 + step * np.arange(n_lon))
+    lon_g, lat_g = np.meshgrid(lon, lat)
+    la, lo = lat_g.ravel(), lon_g.ravel()
+    n = la.size
+    src, dst = [], []
+    reach = int(math.ceil(threshold_km / (111.0 * step * math.cos(math.radians(lat0 + step * n_lat))))) + 1
+    for i in range(n):
+        r, c = divmod(i, n_lon)
+        r0, r1 = max(0, r - reach), min(n_lat, r + reach + 1)
+        c0, c1 = max(0, c - reach), min(n_lon, c + reach + 1)
+        cand = (np.arange(r0, r1)[:, None] * n_lon + np.arange(c0, c1)[None, :]).ravel()
+        dlat = la[cand] - la[i]
+        dlon = lo[cand] - lo[i]
+        a = np.sin(dlat / 2) ** 2 + np.cos(la[i]) * np.cos(la[cand]) * np.sin(dlon / 2) ** 2
+        dist = 2 * np.arcsin(np.sqrt(a)) * 6371.0
+        nb = cand[(dist <= threshold_km) & (cand != i)]
+        src.extend([i] * len(nb))
+        dst.extend(nb.tolist())
+    src = np.asarray(src, dtype=np.int64)
+    dst = np.asarray(dst, dtype=np.int64)
+    deg = np.bincount(src, minlength=n).astype(np.float64)
+    inv = np.where(deg > 0, 1.0 / np.sqrt(np.maximum(deg, 1)), 0.0)
+    w = (inv[src] * inv[dst]).astype(np.float32)
+    return torch.from_numpy(np.stack([src, dst])), torch.from_numpy(w)
+
+
+def synthetic_batch(B: int, L_in: int, N: int, c_in: int, L_out: int, seed: int = 1234):
+    """Synthetic batch shaped like train.py:58-65 / dataset.py:86-99: x~N(0,1); integer time
+    features (tod<12, doy<366, year<13, season<4) as f32, stride-0 expanded over N; y~N(0,1)."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, L_in, N, c_in, generator=g)
+    tf = torch.stack([torch.randint(0, hi, (B, L_in), generator=g) for hi in (12, 366, 13, 4)], -1).float()
+    tf = tf.unsqueeze(-2).expand(B, L_in, N, 4)
+    y = torch.randn(B, L_out, N, 1, generator=g)
+    return x, tf, y

@@ -1,0 +1,197 @@
+/*
+ * tecmollm.h -- C ABI of libtecmollm_hip.so, the MI355X (gfx950) implementation of the
+ * TEC-MoLLM forward/backward hot path.
+ *
+ * The reference (PANXIONG-CN/TEC-MoLLM) is 100 % Python and has no FFI of its own: its
+ * hot path is `TEC_MoLLM.forward` (src/model/tec_mollm.py:59-125) calling torch /
+ * torch_geometric / transformers / peft ops.  Each entry point below therefore cites the
+ * reference *operation* it replaces; the Python-side mirror of the reference's module API
+ * (tec-mollm_amd/src/model/{tec_mollm,modules}.py) binds these through ctypes.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless said otherwise;
+ *   - the library never allocates or frees caller-visible memory (workspaces are passed in);
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), no internal sync;
+ *   - return value: 0 = launched, negative = TECM_E_* (nothing launched);
+ *   - activation tensors after the spatial stage are "time-major": rows m = (b*T + t)*N + n,
+ *     i.e. logical shape (B, T, N, C) with C contiguous -- see DESIGN.md "Data layout";
+ *   - dropout masks are a pure function keep(seed, idx) (tecm_keep in csrc/common.h), so the
+ *     backward pass recomputes them; idx = logical_row * ld + col of the tensor being dropped.
+ */
+#ifndef TECMOLLM_H
+#define TECMOLLM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TECM_OK 0
+#define TECM_E_ARG (-1)        /* bad shape / null pointer / unsupported size            */
+#define TECM_E_ALIGN (-2)      /* pointer or leading dimension not aligned as required   */
+#define TECM_E_LAUNCH (-3)     /* hipGetLastError() != hipSuccess after the launch       */
+#define TECM_E_LDS (-4)        /* problem does not fit the 160 KiB LDS budget            */
+
+#define TECM_ABI_VERSION 1
+int tecm_abi_version(void);
+/* Human-readable text for the last error on this thread (host pointer, never NULL). */
+const char* tecm_last_error(void);
+
+/* ------------------------------------------------------------------ temporal-window row view
+ * A row view maps a logical row m = (bq*Lout + t_out)*N + n and an inner index kk = tap*Cw + c
+ * onto a (B, Lin, N, ld) time-major tensor:
+ *      t_in = t_out*stride_t + tap - pad ;  valid iff 0 <= t_in < Lin  (else the element is 0)
+ *      addr = base + ((bq*Lin + t_in)*N + n)*ld + c
+ * enabled == 0 means the plain view addr = base + m*ld + kk.
+ * It expresses, without materialising anything: Conv1d im2col over time (modules.py:27),
+ * the stride-2 1x1 conv (modules.py:36-41), einops 'b (p l) d -> b p (l d)' (modules.py:114)
+ * and PredictionHead's view(batch, -1) (modules.py:307). */
+typedef struct TecmWin {
+  int32_t enabled;
+  int32_t N;
+  int32_t Lin, Lout;
+  int32_t stride_t;
+  int32_t taps;
+  int32_t Cw;
+  int32_t pad;
+} TecmWin;
+
+typedef struct TecmDrop {      /* keep-mask spec; p == 0 disables */
+  float p;
+  int32_t _pad;
+  uint64_t seed;
+  int64_t ld;                  /* idx = row*ld + col */
+} TecmDrop;
+
+enum { TECM_A_MK = 0, TECM_A_KM = 1 };   /* A stored [m][k] (k contiguous) or [k][m] (m contiguous) */
+enum { TECM_B_NK = 0, TECM_B_KN = 1 };   /* B stored [n][k] (k contiguous) or [k][n] (n contiguous) */
+enum { TECM_ACT_NONE = 0, TECM_ACT_GELU_ERF = 1, TECM_ACT_GELU_TANH = 2 };
+
+/* fp32 GEMM on exact-f32 MFMA (v_mfma_f32_32x32x2_f32):  C = epilogue(alpha * A_view . B_view).
+ * Replaces every dense contraction on the path: nn.Conv1d (modules.py:27,36), nn.Linear
+ * (modules.py:98,287,290), transformers Conv1D c_attn/c_proj/c_fc (pytorch_utils.py:95-121 via
+ * modules.py:208), peft LoRA A/B (modules.py:177-186), GATv2 is NOT here (tecm_spatial_*), and
+ * their autograd backward (dX and dW forms).
+ * Epilogue order: v = alpha*acc; v += bias[n]; v += rowbias[((m / rb_div) % rb_mod)*rb_ld + n];
+ *   if preact: preact[m*ldp+n] = v;  v = act(v);  if dact_src: v *= act'(dact_src[m*ldd+n]);
+ *   v = dropout(v, out_drop);  if residual: v += residual[m*ldr+n];  if accumulate: v += C[m,n];
+ *   store C (through c_win when enabled: column n is the inner index kk of the view). */
+typedef struct TecmGemm {
+  int64_t M, N, K;
+  const float* A; int64_t lda; int32_t a_layout; int32_t _p0; TecmWin a_win; TecmDrop a_drop;
+  const float* B; int64_t ldb; int32_t b_layout; int32_t _p1; TecmWin b_win; TecmDrop b_drop;
+  float* C; int64_t ldc; TecmWin c_win;
+  float alpha; int32_t act;
+  const float* bias;
+  const float* rowbias; int64_t rb_ld; int32_t rb_div; int32_t rb_mod;
+  float* preact; int64_t ldp;
+  const float* dact_src; int64_t ldd;
+  TecmDrop out_drop;
+  const float* residual; int64_t ldr;
+  int32_t accumulate;
+  int32_t split_k;             /* >1: partial sums go to workspace[split][M][N], then reduced */
+  float* workspace;            /* >= split_k*M*N floats when split_k > 1 */
+} TecmGemm;
+int tecm_gemm_f32(const TecmGemm* desc, void* stream);
+
+/* ------------------------------------------------------------------ stage a-1..a-3 (fused)
+ * SpatioTemporalEmbedding.forward (modules.py:230-266) + GATv2Conv (modules.py:329-336,:356)
+ * + residual (tec_mollm.py:94).  The two permute copies (tec_mollm.py:84, :100-106) disappear:
+ * input and output both stay (B, L, N, *) time-major. */
+typedef struct TecmSpatial {
+  int32_t B, L, N, Cin, Demb, H;          /* C = Cin + Demb = H*Ch */
+  int32_t graphs_with_edges;              /* R: graphs g = t*B + b < R aggregate neighbours;
+                                             1 = the reference's literal behaviour, B*L = every timestep */
+  int32_t num_tiles, tile_nodes, win_max; /* node tiling computed by the host from the CSR */
+  const float* x;                         /* (B, L, N, Cin) contiguous */
+  const float* tf; int64_t tf_sb, tf_sl, tf_sn, tf_sf;   /* (B,L,N,4) with element strides; sn may be 0 */
+  const float* node_tab; const float* tod_tab; const float* doy_tab; const float* year_tab;
+  const float* season_tab;                /* (rows, Demb) each */
+  int32_t year_rows, _pad;
+  const float* Wl; const float* bl; const float* Wr; const float* br;   /* (C,C),(C) */
+  const float* att;                       /* (H, Ch) */
+  const float* bias;                      /* (C) */
+  const int32_t* rowptr;                  /* (N+1) CSR by target, self loops removed */
+  const int32_t* colidx;                  /* (E) source node ids */
+  const int32_t* tile_lo; const int32_t* tile_hi;   /* (num_tiles) window [lo,hi) of sources u targets */
+  TecmDrop alpha_drop;                    /* GATv2 dropout on attention coefficients (modules.py:333) */
+  float* out;                             /* (B, L, N, C) */
+} TecmSpatial;
+int tecm_spatial_fwd(const TecmSpatial* d, void* stream);
+
+typedef struct TecmSpatialGrads {
+  const float* dout;                      /* (B, L, N, C) */
+  float* d_node_tab;                      /* (N, Demb)  accumulated with float atomics: zero before call */
+  float* d_tod_tab; float* d_doy_tab; float* d_year_tab; float* d_season_tab;   /* atomics: zero before call */
+  float* partials; int64_t partial_ld;    /* (num_blocks, partial_ld) per-block sums of
+                                             [dWl(C*C) dbl(C) dWr(C*C) dbr(C) datt(C) dbias(C)] */
+  int32_t t_chunk; int32_t num_blocks;    /* blocks = num_tiles * B * ceil(L / t_chunk) */
+} TecmSpatialGrads;
+int tecm_spatial_bwd(const TecmSpatial* d, const TecmSpatialGrads* g, void* stream);
+
+/* ------------------------------------------------------------------ stage a-4 normalisation
+ * nn.GroupNorm(1, C) + nn.GELU() (modules.py:28-29) for the three parallel branches at once.
+ * y/act: (B, L, N, CT) time-major with CT = 3*Cout (branch j owns channels [j*Cout,(j+1)*Cout)).
+ * stats: (B*N, 3, 2) = mean, rstd per sequence and branch. */
+int tecm_groupnorm_gelu_fwd(const float* y, const float* gamma, const float* beta, float* act,
+                            float* stats, int32_t B, int32_t L, int32_t N, int32_t Cout, float eps,
+                            void* stream);
+/* dact is (B, L/dstride, N, CT): the gradient exists only at t % dstride == 0 (stride-s 1x1 conv).
+ * dgb_partials: (num_blocks, 2*CT) per-block [dgamma | dbeta]; returns num_blocks via *num_blocks
+ * when dy == NULL (query mode, nothing launched). */
+int tecm_groupnorm_gelu_bwd(const float* dact, int32_t dstride, const float* y, const float* gamma,
+                            const float* beta, const float* stats, float* dy, float* dgb_partials,
+                            int32_t* num_blocks, int32_t B, int32_t L, int32_t N, int32_t Cout,
+                            void* stream);
+
+/* ------------------------------------------------------------------ stage a-6 pieces
+ * nn.LayerNorm(768, eps=1e-5) of GPT2Block / ln_f (modeling_gpt2.py:262-310, :620). */
+int tecm_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y,
+                       int64_t ldy, float* stats /* (M,2) mean,rstd */, int64_t M, int32_t D, float eps,
+                       void* stream);
+/* dx = dres (optional) + LN'(dy); then dropout(out_drop) on dx (the embd dropout of GPT2Model.drop
+ * sits in front of layer 0's residual stream).  dgb_partials (num_blocks, 2*D). */
+int tecm_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+                       const float* stats, const float* dres, float* dx, const TecmDrop* out_drop,
+                       float* dgb_partials, int32_t* num_blocks, int64_t M, int32_t D, void* stream);
+
+/* Causal multi-head self-attention over T tokens per sequence (GPT2Attention, modeling_gpt2.py:54-73,
+ * :144-226; all-ones attention_mask tec_mollm.py:111 => pure causal).  qkv: (B,T,N,3*D) time-major
+ * rows, ctx: (B,T,N,D).  head_dim = D/heads must be 64.  Dropout on the probabilities. */
+int tecm_attention_fwd(const float* qkv, float* ctx, int32_t B, int32_t T, int32_t N, int32_t heads,
+                       int32_t D, const TecmDrop* prob_drop, void* stream);
+int tecm_attention_bwd(const float* qkv, const float* dctx, float* dqkv, int32_t B, int32_t T, int32_t N,
+                       int32_t heads, int32_t D, const TecmDrop* prob_drop, void* stream);
+
+/* ------------------------------------------------------------------ reductions / small ops
+ * out[s][c] (+)= sum over rows r = o*outer_stride + j (o < outer, j < inner) + seg s offset
+ * of in[r*ld + c]; row(s,o,j) = (o*nseg + s)*inner + j when nseg > 1 (wpe / bias gradients). */
+int tecm_colsum(const float* in, int64_t ld, int64_t outer, int64_t inner, int32_t nseg, int32_t C,
+                float* out, int64_t ldo, int32_t accumulate, float scale, const TecmDrop* in_drop,
+                float* workspace /* >= 1024*nseg*C floats */, void* stream);
+
+/* nn.HuberLoss(delta) mean (train.py:372) fused with its gradient: pred/target/dpred are (n) floats
+ * addressed through pred_index: element e of pred = pred[e], target likewise (both contiguous in the
+ * SAME logical order).  loss_out[0] = mean huber; dpred = dloss/dpred * grad_scale. */
+int tecm_huber_fwd_bwd(const float* pred, const float* target, float* dpred, float* loss_out,
+                       int64_t n, float delta, float grad_scale, float* workspace /* >= 1024 */,
+                       void* stream);
+
+/* Conv1d weight (Cout, Cin, k) -> GEMM operands.  fwd_pack: [Cout][k*Cin] with kk = tap*Cin + ci;
+ * bwd_pack: [k*Cout][Cin] with row = tap'*Cout + co holding W[co][ci][k-1-tap'] (dX correlation). */
+int tecm_conv_weight_pack(const float* w, float* fwd_pack, float* bwd_pack, int32_t Cout, int32_t Cin,
+                          int32_t k, void* stream);
+/* inverse of fwd_pack for the weight gradient: dW[co][ci][tap] = dpack[co][tap*Cin+ci]. */
+int tecm_conv_weight_unpack(const float* dpack, float* dw, int32_t Cout, int32_t Cin, int32_t k,
+                            void* stream);
+
+/* dst[r*ldd + c] = scale * src[c*lds + r]  (r < rows, c < cols): builds the K-extended c_attn weight
+ * [W ; (alpha/r) * B^T] (modules.py:177-183) and other small transposes. */
+int tecm_transpose_scale(const float* src, int64_t lds, float* dst, int64_t ldd, int32_t rows,
+                         int32_t cols, float scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TECMOLLM_H */

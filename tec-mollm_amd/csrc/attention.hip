@@ -1,0 +1,245 @@
+// Causal multi-head attention over the T (<= 32) latent-patch tokens of one (b, n) sequence --
+// GPT2Attention with an all-ones mask (modeling_gpt2.py:54-73, :144-226; tec_mollm.py:111).
+//
+// T is tiny (3 for L_in=48, 6 for 96, 21 for 336) while there are B*N*12 independent (sequence, head)
+// problems, so this is a bandwidth kernel, not an MFMA one: 16 lanes own one (sequence, head), each
+// lane holds 4 of the 64 head dims (one float4 = a 256-byte coalesced segment per 16 lanes), dot
+// products are 16-lane shuffle reductions, softmax is per-lane scalar work replicated in the group.
+// Rows are time-major: token p of sequence (b, n) is row (b*T + p)*N + n of the (B,T,N,3D) qkv buffer.
+// Dropout on the probabilities uses idx = (((b*N + n)*H + h)*T + i)*T + j.
+#include "common.h"
+
+namespace {
+
+struct DropA {
+  uint64_t seed;
+  uint32_t thresh;
+  float inv;
+};
+
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) {
+  return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
+}
+__device__ __forceinline__ void fma4(float4& acc, float s, const float4& v) {
+  acc.x += s * v.x; acc.y += s * v.y; acc.z += s * v.z; acc.w += s * v.w;
+}
+
+// TT > 0: compile-time T with q/k/v held in registers; TT == 0: runtime T <= 32, k/v re-read (L1/L2).
+template <int TT>
+__global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ ctx,
+                                                            int B, int Trt, int N, int H, int D, DropA dr) {
+  const int T = TT > 0 ? TT : Trt;
+  const int sub = threadIdx.x & 15;
+  const int64_t item = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int64_t items = (int64_t)B * N * H;
+  if (item >= items) return;                      // whole 16-lane groups leave together
+  const int64_t seq = item / H;
+  const int h = (int)(item - seq * H);
+  const int b = (int)(seq / N), n = (int)(seq - (int64_t)b * N);
+  const int64_t ld = 3 * (int64_t)D;
+  const float scale = 0.125f;                     // 1/sqrt(64)
+  const int64_t row0 = ((int64_t)b * T) * N + n;  // row of token 0; token p at row0 + p*N
+  const int col = h * 64 + sub * 4;
+
+  if constexpr (TT > 0) {
+    float4 q[TT], k[TT], v[TT];
+#pragma unroll
+    for (int p = 0; p < TT; ++p) {
+      const float* r = qkv + (row0 + (int64_t)p * N) * ld + col;
+      q[p] = *reinterpret_cast<const float4*>(r);
+      k[p] = *reinterpret_cast<const float4*>(r + D);
+      v[p] = *reinterpret_cast<const float4*>(r + 2 * D);
+    }
+#pragma unroll
+    for (int i = 0; i < TT; ++i) {
+      float s[TT];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int j = 0; j <= i; ++j) {
+        s[j] = group16_sum(dot4(q[i], k[j])) * scale;
+        mx = fmaxf(mx, s[j]);
+      }
+      float den = 0.f;
+#pragma unroll
+      for (int j = 0; j <= i; ++j) {
+        s[j] = expf(s[j] - mx);
+        den += s[j];
+      }
+      const float inv = 1.0f / den;
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int j = 0; j <= i; ++j) {
+        float p = s[j] * inv;
+        if (dr.thresh) p *= tecm_drop_mult(dr.seed, (uint64_t)(((item * T + i) * T) + j), dr.thresh, dr.inv);
+        fma4(o, p, v[j]);
+      }
+      *reinterpret_cast<float4*>(ctx + (row0 + (int64_t)i * N) * D + col) = o;
+    }
+  } else {
+    for (int i = 0; i < T; ++i) {
+      const float4 qi = *reinterpret_cast<const float4*>(qkv + (row0 + (int64_t)i * N) * ld + col);
+      float s[32];
+      float mx = -INFINITY;
+      for (int j = 0; j <= i; ++j) {
+        const float4 kj = *reinterpret_cast<const float4*>(qkv + (row0 + (int64_t)j * N) * ld + D + col);
+        s[j] = group16_sum(dot4(qi, kj)) * scale;
+        mx = fmaxf(mx, s[j]);
+      }
+      float den = 0.f;
+      for (int j = 0; j <= i; ++j) {
+        s[j] = expf(s[j] - mx);
+        den += s[j];
+      }
+      const float inv = 1.0f / den;
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int j = 0; j <= i; ++j) {
+        const float4 vj = *reinterpret_cast<const float4*>(qkv + (row0 + (int64_t)j * N) * ld + 2 * D + col);
+        float p = s[j] * inv;
+        if (dr.thresh) p *= tecm_drop_mult(dr.seed, (uint64_t)(((item * T + i) * T) + j), dr.thresh, dr.inv);
+        fma4(o, p, vj);
+      }
+      *reinterpret_cast<float4*>(ctx + (row0 + (int64_t)i * N) * D + col) = o;
+    }
+  }
+}
+
+// Backward: recompute the probabilities, then
+//   dP~_ij = <dctx_i, v_j>;  dV_j += P~_ij dctx_i;  dP_ij = dP~_ij * keep/(1-p);
+//   dS_ij = P_ij (dP_ij - sum_k P_ik dP_ik);  dQ_i += dS_ij K_j / 8;  dK_j += dS_ij Q_i / 8.
+template <int TT>
+__global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restrict__ qkv,
+                                                            const float* __restrict__ dctx, float* __restrict__ dqkv,
+                                                            int B, int Trt, int N, int H, int D, DropA dr) {
+  const int T = TT > 0 ? TT : Trt;
+  const int sub = threadIdx.x & 15;
+  const int64_t item = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int64_t items = (int64_t)B * N * H;
+  if (item >= items) return;
+  const int64_t seq = item / H;
+  const int h = (int)(item - seq * H);
+  const int b = (int)(seq / N), n = (int)(seq - (int64_t)b * N);
+  const int64_t ld = 3 * (int64_t)D;
+  const float scale = 0.125f;
+  const int64_t row0 = ((int64_t)b * T) * N + n;
+  const int col = h * 64 + sub * 4;
+  constexpr int TM = TT > 0 ? TT : 32;
+
+  float4 q[TM], k[TM], v[TM], dq[TM], dk[TM], dv[TM];
+#pragma unroll
+  for (int p = 0; p < T; ++p) {
+    const float* r = qkv + (row0 + (int64_t)p * N) * ld + col;
+    q[p] = *reinterpret_cast<const float4*>(r);
+    k[p] = *reinterpret_cast<const float4*>(r + D);
+    v[p] = *reinterpret_cast<const float4*>(r + 2 * D);
+    dq[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    dk[p] = dq[p];
+    dv[p] = dq[p];
+  }
+#pragma unroll
+  for (int i = 0; i < T; ++i) {
+    const float4 go = *reinterpret_cast<const float4*>(dctx + (row0 + (int64_t)i * N) * D + col);
+    float pr[TM], dp[TM];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      pr[j] = group16_sum(dot4(q[i], k[j])) * scale;
+      mx = fmaxf(mx, pr[j]);
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      pr[j] = expf(pr[j] - mx);
+      den += pr[j];
+    }
+    const float inv = 1.0f / den;
+    float dotp = 0.f;
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      pr[j] *= inv;
+      float m = 1.0f;
+      if (dr.thresh) m = tecm_drop_mult(dr.seed, (uint64_t)(((item * T + i) * T) + j), dr.thresh, dr.inv);
+      const float dpt = group16_sum(dot4(go, v[j]));
+      fma4(dv[j], pr[j] * m, go);
+      dp[j] = dpt * m;
+      dotp += pr[j] * dp[j];
+    }
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      const float ds = pr[j] * (dp[j] - dotp) * scale;
+      fma4(dq[i], ds, k[j]);
+      fma4(dk[j], ds, q[i]);
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < T; ++p) {
+    float* r = dqkv + (row0 + (int64_t)p * N) * ld + col;
+    *reinterpret_cast<float4*>(r) = dq[p];
+    *reinterpret_cast<float4*>(r + D) = dk[p];
+    *reinterpret_cast<float4*>(r + 2 * D) = dv[p];
+  }
+}
+
+int check(const char* who, const void* a, const void* b, const void* c, int B, int T, int N, int heads, int D) {
+  TECM_REQUIRE(a && b && c, TECM_E_ARG, "%s: null pointer", who);
+  TECM_REQUIRE(B > 0 && N > 0 && T > 0 && T <= 32, TECM_E_ARG, "%s: need 1 <= T <= 32 (got %d)", who, T);
+  TECM_REQUIRE(heads > 0 && D == heads * 64, TECM_E_ARG, "%s: head_dim must be 64 (D=%d heads=%d)", who, D, heads);
+  TECM_REQUIRE(tecm_aligned(a, 16) && tecm_aligned(b, 16) && tecm_aligned(c, 16), TECM_E_ALIGN,
+               "%s: 16-byte alignment required", who);
+  return TECM_OK;
+}
+
+DropA make_dropa(const TecmDrop* d) {
+  DropA r;
+  r.seed = d ? d->seed : 0;
+  r.thresh = (d && d->p > 0.f) ? tecm_drop_thresh(d->p) : 0u;
+  r.inv = (d && d->p > 0.f) ? 1.0f / (1.0f - d->p) : 1.0f;
+  return r;
+}
+
+}  // namespace
+
+extern "C" int tecm_attention_fwd(const float* qkv, float* ctx, int32_t B, int32_t T, int32_t N, int32_t heads,
+                                  int32_t D, const TecmDrop* prob_drop, void* stream) {
+  const int rc = check("tecm_attention_fwd", qkv, ctx, ctx, B, T, N, heads, D);
+  if (rc) return rc;
+  const int64_t items = (int64_t)B * N * heads;
+  const dim3 grid((unsigned)((items + 15) / 16));
+  const DropA dr = make_dropa(prob_drop);
+  hipStream_t st = (hipStream_t)stream;
+#define ATT_FWD(TT) \
+  hipLaunchKernelGGL((attention_fwd_kernel<TT>), grid, dim3(256), 0, st, qkv, ctx, B, T, N, heads, D, dr)
+  switch (T) {
+    case 1: ATT_FWD(1); break;
+    case 2: ATT_FWD(2); break;
+    case 3: ATT_FWD(3); break;
+    case 4: ATT_FWD(4); break;
+    case 6: ATT_FWD(6); break;
+    default: ATT_FWD(0); break;
+  }
+#undef ATT_FWD
+  TECM_CHECK_LAUNCH("tecm_attention_fwd");
+  return TECM_OK;
+}
+
+extern "C" int tecm_attention_bwd(const float* qkv, const float* dctx, float* dqkv, int32_t B, int32_t T, int32_t N,
+                                  int32_t heads, int32_t D, const TecmDrop* prob_drop, void* stream) {
+  const int rc = check("tecm_attention_bwd", qkv, dctx, dqkv, B, T, N, heads, D);
+  if (rc) return rc;
+  const int64_t items = (int64_t)B * N * heads;
+  const dim3 grid((unsigned)((items + 15) / 16));
+  const DropA dr = make_dropa(prob_drop);
+  hipStream_t st = (hipStream_t)stream;
+#define ATT_BWD(TT) \
+  hipLaunchKernelGGL((attention_bwd_kernel<TT>), grid, dim3(256), 0, st, qkv, dctx, dqkv, B, T, N, heads, D, dr)
+  switch (T) {
+    case 1: ATT_BWD(1); break;
+    case 2: ATT_BWD(2); break;
+    case 3: ATT_BWD(3); break;
+    case 4: ATT_BWD(4); break;
+    case 6: ATT_BWD(6); break;
+    default: ATT_BWD(0); break;
+  }
+#undef ATT_BWD
+  TECM_CHECK_LAUNCH("tecm_attention_bwd");
+  return TECM_OK;
+}

@@ -1,0 +1,123 @@
+// Shared device/host helpers for libtecmollm_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <math.h>
+
+#include "../../include/tecmollm.h"
+
+#define TECM_WAVE 64
+
+// ------------------------------------------------------------------ host-side error plumbing
+void tecm_set_error(const char* fmt, ...);
+
+#define TECM_REQUIRE(cond, code, ...)            \
+  do {                                           \
+    if (!(cond)) {                               \
+      tecm_set_error(__VA_ARGS__);               \
+      return (code);                             \
+    }                                            \
+  } while (0)
+
+#define TECM_CHECK_LAUNCH(name)                                                     \
+  do {                                                                              \
+    hipError_t e_ = hipGetLastError();                                              \
+    if (e_ != hipSuccess) {                                                         \
+      tecm_set_error("%s: launch failed: %s", (name), hipGetErrorString(e_));       \
+      return TECM_E_LAUNCH;                                                         \
+    }                                                                               \
+  } while (0)
+
+static inline bool tecm_aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+// ------------------------------------------------------------------ counter-based dropout mask
+// keep(seed, idx): splitmix64 finaliser of (seed + idx*golden); top 24 bits compared with p*2^24.
+// Pure function => forward and backward agree without storing masks.  Mirrored bit-for-bit by
+// tecmollm/rng.py for the parity tests with dropout enabled.
+__host__ __device__ __forceinline__ uint32_t tecm_hash24(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (uint32_t)(z >> 40);
+}
+__host__ __device__ __forceinline__ uint32_t tecm_drop_thresh(float p) { return (uint32_t)(p * 16777216.0f); }
+// returns the multiplier to apply: 0 or 1/(1-p)
+__device__ __forceinline__ float tecm_drop_mult(uint64_t seed, uint64_t idx, uint32_t thresh, float inv_keep) {
+  return tecm_hash24(seed, idx) >= thresh ? inv_keep : 0.0f;
+}
+
+// ------------------------------------------------------------------ activations
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float dgelu_erf(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+__device__ __forceinline__ float gelu_tanh(float x) {
+  const float u = 0.79788456080286535588f * (x + 0.044715f * x * x * x);
+  return 0.5f * x * (1.0f + tanhf(u));
+}
+__device__ __forceinline__ float dgelu_tanh(float x) {
+  const float x2 = x * x;
+  const float u = 0.79788456080286535588f * (x + 0.044715f * x * x2);
+  const float t = tanhf(u);
+  const float du = 0.79788456080286535588f * (1.0f + 3.0f * 0.044715f * x2);
+  return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * du;
+}
+__device__ __forceinline__ float apply_act(int act, float v) {
+  return act == TECM_ACT_GELU_ERF ? gelu_erf(v) : (act == TECM_ACT_GELU_TANH ? gelu_tanh(v) : v);
+}
+__device__ __forceinline__ float apply_dact(int act, float v) {
+  return act == TECM_ACT_GELU_ERF ? dgelu_erf(v) : (act == TECM_ACT_GELU_TANH ? dgelu_tanh(v) : 1.0f);
+}
+
+// ------------------------------------------------------------------ wave / block reductions (wave = 64)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// sum over aligned groups of 16 lanes (result in every lane of the group)
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ------------------------------------------------------------------ temporal-window row view
+// Resolved once per (thread, row): everything the inner loop needs to address element kk.
+// Kept to 3 registers because the narrow-vector GEMM variants hold up to 16 of them per operand.
+#define TECM_ROW_INVALID INT32_MIN
+struct RowRef {
+  int64_t srow;     // source row index of tap 0 (may be negative when t0 < 0; only used when the tap is valid)
+  int32_t t0;       // t_out*stride_t - pad, or TECM_ROW_INVALID when the row is out of range
+};
+
+__device__ __forceinline__ RowRef make_rowref(const TecmWin& w, bool win, int64_t m, int64_t rows) {
+  RowRef r;
+  if (m >= rows) {
+    r.srow = 0;
+    r.t0 = TECM_ROW_INVALID;
+    return r;
+  }
+  if (!win) {
+    r.srow = m;
+    r.t0 = 0;
+    return r;
+  }
+  const int64_t q = m / w.N;
+  const int32_t n = (int32_t)(m - q * w.N);
+  const int64_t bq = q / w.Lout;
+  const int32_t t_out = (int32_t)(q - bq * w.Lout);
+  r.t0 = t_out * w.stride_t - w.pad;
+  r.srow = (bq * w.Lin + r.t0) * (int64_t)w.N + n;
+  return r;
+}

@@ -1,0 +1,122 @@
+// Small kernels around the GEMMs: fused Huber loss + gradient (train.py:372), Conv1d weight
+// (Cout,Cin,k) <-> GEMM operand packing, scaled transposes for the K-extended c_attn weight.
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void huber_stage1(const float* __restrict__ pred, const float* __restrict__ target,
+                                                    float* __restrict__ dpred, float* __restrict__ ws, int64_t n,
+                                                    float delta, float gscale) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float r = pred[i] - target[i];
+    const float a = fabsf(r);
+    acc += a <= delta ? 0.5f * r * r : delta * (a - 0.5f * delta);
+    if (dpred) dpred[i] = (a <= delta ? r : (r > 0.f ? delta : -delta)) * gscale;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) ws[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void huber_stage2(const float* __restrict__ ws, int nb, float* __restrict__ out,
+                                                    float inv_n) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) acc += ws[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = ((red[0] + red[1]) + (red[2] + red[3])) * inv_n;
+}
+
+__global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ fwd,
+                                                        float* __restrict__ bwd, int Cout, int Cin, int k) {
+  const int total = Cout * Cin * k;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int tap = i % k;
+    const int ci = (i / k) % Cin;
+    const int co = i / (k * Cin);
+    const float v = w[i];
+    if (fwd) fwd[(int64_t)co * (k * Cin) + tap * Cin + ci] = v;
+    if (bwd) bwd[((int64_t)(k - 1 - tap) * Cout + co) * Cin + ci] = v;
+  }
+}
+__global__ __launch_bounds__(256) void conv_unpack_kernel(const float* __restrict__ dpack, float* __restrict__ dw,
+                                                          int Cout, int Cin, int k) {
+  const int total = Cout * Cin * k;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int tap = i % k;
+    const int ci = (i / k) % Cin;
+    const int co = i / (k * Cin);
+    dw[i] = dpack[(int64_t)co * (k * Cin) + tap * Cin + ci];
+  }
+}
+
+// dst[r][c] = scale * src[c][r] through a 32x33 LDS tile (both sides coalesced)
+__global__ __launch_bounds__(256) void transpose_scale_kernel(const float* __restrict__ src, int64_t lds_,
+                                                              float* __restrict__ dst, int64_t ldd, int rows, int cols,
+                                                              float scale) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+  const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j, r = r0 + tx;
+    tile[j][tx] = (c < cols && r < rows) ? src[(int64_t)c * lds_ + r] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int r = r0 + j, c = c0 + tx;
+    if (r < rows && c < cols) dst[(int64_t)r * ldd + c] = scale * tile[tx][j];
+  }
+}
+
+}  // namespace
+
+extern "C" int tecm_huber_fwd_bwd(const float* pred, const float* target, float* dpred, float* loss_out, int64_t n,
+                                  float delta, float grad_scale, float* workspace, void* stream) {
+  TECM_REQUIRE(pred && target && loss_out && workspace, TECM_E_ARG, "tecm_huber_fwd_bwd: null pointer");
+  TECM_REQUIRE(n > 0 && delta > 0.f, TECM_E_ARG, "tecm_huber_fwd_bwd: bad n/delta");
+  const int64_t want = (n + 255) / 256;
+  const int nb = (int)(want < 1024 ? want : 1024);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(huber_stage1, dim3(nb), dim3(256), 0, st, pred, target, dpred, workspace, n, delta,
+                     grad_scale / (float)n);
+  TECM_CHECK_LAUNCH("tecm_huber_fwd_bwd/stage1");
+  hipLaunchKernelGGL(huber_stage2, dim3(1), dim3(256), 0, st, workspace, nb, loss_out, 1.0f / (float)n);
+  TECM_CHECK_LAUNCH("tecm_huber_fwd_bwd/stage2");
+  return TECM_OK;
+}
+
+extern "C" int tecm_conv_weight_pack(const float* w, float* fwd_pack, float* bwd_pack, int32_t Cout, int32_t Cin,
+                                     int32_t k, void* stream) {
+  TECM_REQUIRE(w && (fwd_pack || bwd_pack), TECM_E_ARG, "tecm_conv_weight_pack: null pointer");
+  TECM_REQUIRE(Cout > 0 && Cin > 0 && k > 0, TECM_E_ARG, "tecm_conv_weight_pack: bad shape");
+  const int total = Cout * Cin * k;
+  hipLaunchKernelGGL(conv_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, fwd_pack,
+                     bwd_pack, Cout, Cin, k);
+  TECM_CHECK_LAUNCH("tecm_conv_weight_pack");
+  return TECM_OK;
+}
+
+extern "C" int tecm_conv_weight_unpack(const float* dpack, float* dw, int32_t Cout, int32_t Cin, int32_t k,
+                                       void* stream) {
+  TECM_REQUIRE(dpack && dw, TECM_E_ARG, "tecm_conv_weight_unpack: null pointer");
+  TECM_REQUIRE(Cout > 0 && Cin > 0 && k > 0, TECM_E_ARG, "tecm_conv_weight_unpack: bad shape");
+  const int total = Cout * Cin * k;
+  hipLaunchKernelGGL(conv_unpack_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, dpack, dw, Cout,
+                     Cin, k);
+  TECM_CHECK_LAUNCH("tecm_conv_weight_unpack");
+  return TECM_OK;
+}
+
+extern "C" int tecm_transpose_scale(const float* src, int64_t lds, float* dst, int64_t ldd, int32_t rows, int32_t cols,
+                                    float scale, void* stream) {
+  TECM_REQUIRE(src && dst, TECM_E_ARG, "tecm_transpose_scale: null pointer");
+  TECM_REQUIRE(rows > 0 && cols > 0, TECM_E_ARG, "tecm_transpose_scale: bad shape");
+  hipLaunchKernelGGL(transpose_scale_kernel, dim3((rows + 31) / 32, (cols + 31) / 32), dim3(256), 0,
+                     (hipStream_t)stream, src, lds, dst, ldd, rows, cols, scale);
+  TECM_CHECK_LAUNCH("tecm_transpose_scale");
+  return TECM_OK;
+}

@@ -1,0 +1,480 @@
+// Bandwidth-bound normalisation kernels of the TEC-MoLLM path (gfx950, wave = 64):
+//   LayerNorm fwd/bwd     -- GPT2Block.ln_1 / ln_2 / ln_f   (modeling_gpt2.py:262-310, :620)
+//   GroupNorm(1)+GELU     -- Multi_Scale_Conv_Block branches (modules.py:28-29), 3 branches at once
+//   column sums           -- bias / gamma / beta / wpe gradients
+// One wave owns one row (LayerNorm) or one sequence (GroupNorm); statistics are wave reductions,
+// per-channel parameter gradients are kept in registers across the rows a wave visits and leave
+// the kernel as one partial row per block (summed by tecm_colsum) -- no atomics, deterministic.
+#include "common.h"
+
+namespace {
+
+constexpr int LN_MAXCH = 4;   // float4 chunks per lane: D <= 1024
+
+struct DropCtxN {
+  uint64_t seed;
+  int64_t ld;
+  uint32_t thresh;
+  float inv;
+};
+__host__ __device__ inline DropCtxN make_dropn(const TecmDrop* d) {
+  DropCtxN c;
+  c.seed = d ? d->seed : 0;
+  c.ld = d ? d->ld : 0;
+  c.thresh = (d && d->p > 0.f) ? tecm_drop_thresh(d->p) : 0u;
+  c.inv = (d && d->p > 0.f) ? 1.0f / (1.0f - d->p) : 1.0f;
+  return c;
+}
+
+// ------------------------------------------------------------------------------ LayerNorm
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, int64_t ldx,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ y,
+                                                            int64_t ldy, float* __restrict__ stats, int64_t M, int D,
+                                                            float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  if (row >= M) return;
+  const float* xr = x + row * ldx;
+  float4 v[NCH];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = 4 * (lane + 64 * i);
+    v[i] = c < D ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = 4 * (lane + 64 * i);
+    if (c < D) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+  float* yr = y + row * ldy;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = 4 * (lane + 64 * i);
+    if (c < D) {
+      const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+      const float4 b = *reinterpret_cast<const float4*>(beta + c);
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * g.x + b.x;
+      o.y = (v[i].y - mean) * rstd * g.y + b.y;
+      o.z = (v[i].z - mean) * rstd * g.z + b.z;
+      o.w = (v[i].w - mean) * rstd * g.w + b.w;
+      *reinterpret_cast<float4*>(yr + c) = o;
+    }
+  }
+  if (lane == 0) {
+    stats[2 * row] = mean;
+    stats[2 * row + 1] = rstd;
+  }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, int64_t lddy,
+                                                            const float* __restrict__ x, int64_t ldx,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ stats,
+                                                            const float* __restrict__ dres, float* __restrict__ dx,
+                                                            DropCtxN odc, float* __restrict__ partials, int64_t M,
+                                                            int D) {
+  __shared__ float red[4][2 * 4 * 64 * NCH];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float4 dg[NCH], db[NCH], gm[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int c = 4 * (lane + 64 * i);
+    gm[i] = c < D ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const float invD = 1.0f / (float)D;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    float4 xh[NCH], g[NCH];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = 4 * (lane + 64 * i);
+      if (c < D) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + row * ldx + c);
+        const float4 d = *reinterpret_cast<const float4*>(dy + row * lddy + c);
+        xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+        g[i] = make_float4(d.x * gm[i].x, d.y * gm[i].y, d.z * gm[i].z, d.w * gm[i].w);
+        dg[i].x += d.x * xh[i].x; dg[i].y += d.y * xh[i].y; dg[i].z += d.z * xh[i].z; dg[i].w += d.w * xh[i].w;
+        db[i].x += d.x; db[i].y += d.y; db[i].z += d.z; db[i].w += d.w;
+        s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+        s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+      } else {
+        xh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        g[i] = xh[i];
+      }
+    }
+    s1 = wave_sum(s1) * invD;
+    s2 = wave_sum(s2) * invD;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = 4 * (lane + 64 * i);
+      if (c < D) {
+        float o[4] = {rstd * (g[i].x - s1 - xh[i].x * s2), rstd * (g[i].y - s1 - xh[i].y * s2),
+                      rstd * (g[i].z - s1 - xh[i].z * s2), rstd * (g[i].w - s1 - xh[i].w * s2)};
+        if (dres) {
+          const float4 r = *reinterpret_cast<const float4*>(dres + row * (int64_t)D + c);
+          o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
+        }
+        if (odc.thresh) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            o[e] *= tecm_drop_mult(odc.seed, (uint64_t)(row * odc.ld + c + e), odc.thresh, odc.inv);
+        }
+        *reinterpret_cast<float4*>(dx + row * (int64_t)D + c) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
+  }
+  // block reduction of the per-lane parameter gradients -> one partial row per block
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = 4 * (lane + 64 * i);
+    float* r0 = &red[wave][c];
+    float* r1 = &red[wave][4 * 64 * NCH + c];
+    r0[0] = dg[i].x; r0[1] = dg[i].y; r0[2] = dg[i].z; r0[3] = dg[i].w;
+    r1[0] = db[i].x; r1[1] = db[i].y; r1[2] = db[i].z; r1[3] = db[i].w;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * D; c += 256) {
+    const int src = c < D ? c : (4 * 64 * NCH + (c - D));
+    partials[(int64_t)blockIdx.x * 2 * D + c] = (red[0][src] + red[1][src]) + (red[2][src] + red[3][src]);
+  }
+}
+
+// ------------------------------------------------------------------------------ GroupNorm(1) + GELU
+// CPB = Cout / 64 (channel chunks of 64 per branch); lane owns channels lane + 64*i.
+template <int CPB>
+__global__ __launch_bounds__(256) void gn_gelu_fwd_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ act,
+                                                          float* __restrict__ stats, int B, int L, int N, float eps) {
+  constexpr int CT = 3 * CPB * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t sidx = (int64_t)blockIdx.x * 4 + wave;
+  if (sidx >= (int64_t)B * N) return;
+  const int b = (int)(sidx / N), n = (int)(sidx - (int64_t)b * N);
+  const float inv_cnt = 1.0f / (float)(L * CPB * 64);
+  const int64_t tstride = (int64_t)N * CT;
+  const float* base = y + ((int64_t)b * L * N + n) * CT + lane;
+  float mean[3], rstd[3];
+  {
+    float s[3] = {0.f, 0.f, 0.f};
+    for (int t = 0; t < L; ++t) {
+      const float* p = base + t * tstride;
+#pragma unroll
+      for (int br = 0; br < 3; ++br)
+#pragma unroll
+        for (int k = 0; k < CPB; ++k) s[br] += p[64 * (br * CPB + k)];
+    }
+#pragma unroll
+    for (int br = 0; br < 3; ++br) mean[br] = wave_sum(s[br]) * inv_cnt;
+  }
+  {
+    float s[3] = {0.f, 0.f, 0.f};
+    for (int t = 0; t < L; ++t) {
+      const float* p = base + t * tstride;
+#pragma unroll
+      for (int br = 0; br < 3; ++br)
+#pragma unroll
+        for (int k = 0; k < CPB; ++k) {
+          const float d = p[64 * (br * CPB + k)] - mean[br];
+          s[br] += d * d;
+        }
+    }
+#pragma unroll
+    for (int br = 0; br < 3; ++br) rstd[br] = 1.0f / sqrtf(wave_sum(s[br]) * inv_cnt + eps);
+  }
+  float gm[3 * CPB], bt[3 * CPB];
+#pragma unroll
+  for (int i = 0; i < 3 * CPB; ++i) {
+    gm[i] = gamma[lane + 64 * i];
+    bt[i] = beta[lane + 64 * i];
+  }
+  float* obase = act + ((int64_t)b * L * N + n) * CT + lane;
+  for (int t = 0; t < L; ++t) {
+    const float* p = base + t * tstride;
+    float* o = obase + t * tstride;
+#pragma unroll
+    for (int br = 0; br < 3; ++br)
+#pragma unroll
+      for (int k = 0; k < CPB; ++k) {
+        const int i = br * CPB + k;
+        o[64 * i] = gelu_erf((p[64 * i] - mean[br]) * rstd[br] * gm[i] + bt[i]);
+      }
+  }
+  if (lane < 3) {
+    stats[(sidx * 3 + lane) * 2] = mean[lane];
+    stats[(sidx * 3 + lane) * 2 + 1] = rstd[lane];
+  }
+}
+
+template <int CPB>
+__global__ __launch_bounds__(256) void gn_gelu_bwd_kernel(const float* __restrict__ dact, int dstride, int L2,
+                                                          const float* __restrict__ y,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          const float* __restrict__ stats, float* __restrict__ dy,
+                                                          float* __restrict__ partials, int B, int L, int N) {
+  constexpr int NCHK = 3 * CPB;
+  constexpr int CT = NCHK * 64;
+  __shared__ float red[4][2 * CT];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float inv_cnt = 1.0f / (float)(L * CPB * 64);
+  const int64_t tstride = (int64_t)N * CT;
+  float gm[NCHK], bt[NCHK], dgm[NCHK], dbt[NCHK];
+#pragma unroll
+  for (int i = 0; i < NCHK; ++i) {
+    gm[i] = gamma[lane + 64 * i];
+    bt[i] = beta[lane + 64 * i];
+    dgm[i] = 0.f;
+    dbt[i] = 0.f;
+  }
+  for (int64_t sidx = (int64_t)blockIdx.x * 4 + wave; sidx < (int64_t)B * N; sidx += (int64_t)gridDim.x * 4) {
+    const int b = (int)(sidx / N), n = (int)(sidx - (int64_t)b * N);
+    float mean[3], rstd[3];
+#pragma unroll
+    for (int br = 0; br < 3; ++br) {
+      mean[br] = stats[(sidx * 3 + br) * 2];
+      rstd[br] = stats[(sidx * 3 + br) * 2 + 1];
+    }
+    const float* ybase = y + ((int64_t)b * L * N + n) * CT + lane;
+    const float* dbase = dact + ((int64_t)b * L2 * N + n) * CT + lane;
+    float* obase = dy + ((int64_t)b * L * N + n) * CT + lane;
+    float s1[3] = {0.f, 0.f, 0.f}, s2[3] = {0.f, 0.f, 0.f};
+    for (int t = 0; t < L; ++t) {
+      const bool has = (t % dstride) == 0;
+      const float* p = ybase + t * tstride;
+      const float* dp = dbase + (t / dstride) * tstride;
+#pragma unroll
+      for (int br = 0; br < 3; ++br)
+#pragma unroll
+        for (int k = 0; k < CPB; ++k) {
+          const int i = br * CPB + k;
+          if (has) {
+            const float yh = (p[64 * i] - mean[br]) * rstd[br];
+            const float g = dp[64 * i] * dgelu_erf(yh * gm[i] + bt[i]);
+            dgm[i] += g * yh;
+            dbt[i] += g;
+            const float dyh = g * gm[i];
+            s1[br] += dyh;
+            s2[br] += dyh * yh;
+          }
+        }
+    }
+#pragma unroll
+    for (int br = 0; br < 3; ++br) {
+      s1[br] = wave_sum(s1[br]) * inv_cnt;
+      s2[br] = wave_sum(s2[br]) * inv_cnt;
+    }
+    for (int t = 0; t < L; ++t) {
+      const bool has = (t % dstride) == 0;
+      const float* p = ybase + t * tstride;
+      const float* dp = dbase + (t / dstride) * tstride;
+      float* o = obase + t * tstride;
+#pragma unroll
+      for (int br = 0; br < 3; ++br)
+#pragma unroll
+        for (int k = 0; k < CPB; ++k) {
+          const int i = br * CPB + k;
+          const float yh = (p[64 * i] - mean[br]) * rstd[br];
+          float dyh = 0.f;
+          if (has) dyh = dp[64 * i] * dgelu_erf(yh * gm[i] + bt[i]) * gm[i];
+          o[64 * i] = rstd[br] * (dyh - s1[br] - yh * s2[br]);
+        }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NCHK; ++i) {
+    red[wave][lane + 64 * i] = dgm[i];
+    red[wave][CT + lane + 64 * i] = dbt[i];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * CT; c += 256)
+    partials[(int64_t)blockIdx.x * 2 * CT + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
+// ------------------------------------------------------------------------------ column sums
+// stage 1: grid (colblocks, RB, nseg).  Lane = column, the 4 waves stride the block's row chunk.
+__global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ in, int64_t ld, int64_t outer,
+                                                     int64_t inner, int nseg, int C, DropCtxN idc,
+                                                     float* __restrict__ ws, int64_t chunk) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int rb = blockIdx.y, s = blockIdx.z;
+  const int64_t total = outer * inner;
+  const int64_t beg = (int64_t)rb * chunk;
+  const int64_t end = beg + chunk < total ? beg + chunk : total;
+  float acc = 0.f;
+  if (c < C) {
+    for (int64_t ri = beg + wave; ri < end; ri += 4) {
+      const int64_t o = ri / inner, j = ri - o * inner;
+      const int64_t row = (o * nseg + s) * inner + j;
+      float v = in[row * ld + c];
+      if (idc.thresh) v *= tecm_drop_mult(idc.seed, (uint64_t)(row * idc.ld + c), idc.thresh, idc.inv);
+      acc += v;
+    }
+  }
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && c < C)
+    ws[((int64_t)s * gridDim.y + rb) * C + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+__global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ ws, int RB, int nseg, int C,
+                                                     float* __restrict__ out, int64_t ldo, int accumulate,
+                                                     float scale) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nseg * C) return;
+  const int s = i / C, c = i - s * C;
+  float acc = 0.f;
+  for (int rb = 0; rb < RB; ++rb) acc += ws[((int64_t)s * RB + rb) * C + c];
+  acc *= scale;
+  float* o = out + (int64_t)s * ldo + c;
+  *o = accumulate ? *o + acc : acc;
+}
+
+int ln_blocks(int64_t M) {
+  const int64_t want = (M + 3) / 4;
+  return (int)(want < 1024 ? want : 1024);
+}
+int gn_blocks(int64_t S) {
+  const int64_t want = (S + 3) / 4;
+  return (int)(want < 1024 ? want : 1024);
+}
+
+}  // namespace
+
+extern "C" int tecm_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y,
+                                  int64_t ldy, float* stats, int64_t M, int32_t D, float eps, void* stream) {
+  TECM_REQUIRE(x && gamma && beta && y && stats, TECM_E_ARG, "tecm_layernorm_fwd: null pointer");
+  TECM_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAXCH, TECM_E_ARG,
+               "tecm_layernorm_fwd: need D %% 4 == 0 and D <= %d (got %d)", 256 * LN_MAXCH, D);
+  TECM_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && tecm_aligned(x, 16) && tecm_aligned(y, 16) &&
+                   tecm_aligned(gamma, 16) && tecm_aligned(beta, 16),
+               TECM_E_ALIGN, "tecm_layernorm_fwd: 16-byte alignment required");
+  const dim3 grid((unsigned)((M + 3) / 4));
+  const int nch = (D + 255) / 256;
+  hipStream_t st = (hipStream_t)stream;
+#define LN_FWD(NCH) \
+  hipLaunchKernelGGL((layernorm_fwd_kernel<NCH>), grid, dim3(256), 0, st, x, ldx, gamma, beta, y, ldy, stats, M, D, eps)
+  switch (nch) {
+    case 1: LN_FWD(1); break;
+    case 2: LN_FWD(2); break;
+    case 3: LN_FWD(3); break;
+    default: LN_FWD(4); break;
+  }
+#undef LN_FWD
+  TECM_CHECK_LAUNCH("tecm_layernorm_fwd");
+  return TECM_OK;
+}
+
+extern "C" int tecm_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+                                  const float* stats, const float* dres, float* dx, const TecmDrop* out_drop,
+                                  float* dgb_partials, int32_t* num_blocks, int64_t M, int32_t D, void* stream) {
+  TECM_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAXCH, TECM_E_ARG, "tecm_layernorm_bwd: bad M/D");
+  const int nb = ln_blocks(M);
+  if (num_blocks) *num_blocks = nb;
+  if (dx == nullptr) return TECM_OK;   // query mode
+  TECM_REQUIRE(dy && x && gamma && stats && dgb_partials, TECM_E_ARG, "tecm_layernorm_bwd: null pointer");
+  TECM_REQUIRE(lddy % 4 == 0 && ldx % 4 == 0 && tecm_aligned(dy, 16) && tecm_aligned(x, 16) &&
+                   tecm_aligned(dx, 16) && (!dres || tecm_aligned(dres, 16)),
+               TECM_E_ALIGN, "tecm_layernorm_bwd: 16-byte alignment required");
+  const DropCtxN odc = make_dropn(out_drop);
+  const int nch = (D + 255) / 256;
+  hipStream_t st = (hipStream_t)stream;
+#define LN_BWD(NCH)                                                                                              \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<NCH>), dim3(nb), dim3(256), 0, st, dy, lddy, x, ldx, gamma, stats, dres, \
+                     dx, odc, dgb_partials, M, D)
+  switch (nch) {
+    case 1: LN_BWD(1); break;
+    case 2: LN_BWD(2); break;
+    case 3: LN_BWD(3); break;
+    default: LN_BWD(4); break;
+  }
+#undef LN_BWD
+  TECM_CHECK_LAUNCH("tecm_layernorm_bwd");
+  return TECM_OK;
+}
+
+extern "C" int tecm_groupnorm_gelu_fwd(const float* y, const float* gamma, const float* beta, float* act,
+                                       float* stats, int32_t B, int32_t L, int32_t N, int32_t Cout, float eps,
+                                       void* stream) {
+  TECM_REQUIRE(y && gamma && beta && act && stats, TECM_E_ARG, "tecm_groupnorm_gelu_fwd: null pointer");
+  TECM_REQUIRE(B > 0 && L > 0 && N > 0, TECM_E_ARG, "tecm_groupnorm_gelu_fwd: bad shape");
+  TECM_REQUIRE(Cout == 64 || Cout == 128 || Cout == 256, TECM_E_ARG,
+               "tecm_groupnorm_gelu_fwd: Cout must be 64, 128 or 256 (got %d)", Cout);
+  const int64_t S = (int64_t)B * N;
+  const dim3 grid((unsigned)((S + 3) / 4));
+  hipStream_t st = (hipStream_t)stream;
+  if (Cout == 64)
+    hipLaunchKernelGGL((gn_gelu_fwd_kernel<1>), grid, dim3(256), 0, st, y, gamma, beta, act, stats, B, L, N, eps);
+  else if (Cout == 128)
+    hipLaunchKernelGGL((gn_gelu_fwd_kernel<2>), grid, dim3(256), 0, st, y, gamma, beta, act, stats, B, L, N, eps);
+  else
+    hipLaunchKernelGGL((gn_gelu_fwd_kernel<4>), grid, dim3(256), 0, st, y, gamma, beta, act, stats, B, L, N, eps);
+  TECM_CHECK_LAUNCH("tecm_groupnorm_gelu_fwd");
+  return TECM_OK;
+}
+
+extern "C" int tecm_groupnorm_gelu_bwd(const float* dact, int32_t dstride, const float* y, const float* gamma,
+                                       const float* beta, const float* stats, float* dy, float* dgb_partials,
+                                       int32_t* num_blocks, int32_t B, int32_t L, int32_t N, int32_t Cout,
+                                       void* stream) {
+  TECM_REQUIRE(B > 0 && L > 0 && N > 0 && dstride > 0, TECM_E_ARG, "tecm_groupnorm_gelu_bwd: bad shape");
+  TECM_REQUIRE(Cout == 64 || Cout == 128 || Cout == 256, TECM_E_ARG,
+               "tecm_groupnorm_gelu_bwd: Cout must be 64, 128 or 256 (got %d)", Cout);
+  const int nb = gn_blocks((int64_t)B * N);
+  if (num_blocks) *num_blocks = nb;
+  if (dy == nullptr) return TECM_OK;   // query mode
+  TECM_REQUIRE(dact && y && gamma && beta && stats && dgb_partials, TECM_E_ARG, "tecm_groupnorm_gelu_bwd: null pointer");
+  const int L2 = (L + dstride - 1) / dstride;
+  hipStream_t st = (hipStream_t)stream;
+  if (Cout == 64)
+    hipLaunchKernelGGL((gn_gelu_bwd_kernel<1>), dim3(nb), dim3(256), 0, st, dact, dstride, L2, y, gamma, beta, stats,
+                       dy, dgb_partials, B, L, N);
+  else if (Cout == 128)
+    hipLaunchKernelGGL((gn_gelu_bwd_kernel<2>), dim3(nb), dim3(256), 0, st, dact, dstride, L2, y, gamma, beta, stats,
+                       dy, dgb_partials, B, L, N);
+  else
+    hipLaunchKernelGGL((gn_gelu_bwd_kernel<4>), dim3(nb), dim3(256), 0, st, dact, dstride, L2, y, gamma, beta, stats,
+                       dy, dgb_partials, B, L, N);
+  TECM_CHECK_LAUNCH("tecm_groupnorm_gelu_bwd");
+  return TECM_OK;
+}
+
+extern "C" int tecm_colsum(const float* in, int64_t ld, int64_t outer, int64_t inner, int32_t nseg, int32_t C,
+                           float* out, int64_t ldo, int32_t accumulate, float scale, const TecmDrop* in_drop,
+                           float* workspace, void* stream) {
+  TECM_REQUIRE(in && out && workspace, TECM_E_ARG, "tecm_colsum: null pointer");
+  TECM_REQUIRE(outer > 0 && inner > 0 && nseg > 0 && C > 0, TECM_E_ARG, "tecm_colsum: bad shape");
+  const int colblocks = (C + 63) / 64;
+  const int64_t total = outer * inner;
+  int64_t rb = 1024 / ((int64_t)colblocks * nseg);
+  if (rb > 256) rb = 256;
+  if (rb > (total + 15) / 16) rb = (total + 15) / 16;
+  if (rb < 1) rb = 1;
+  const int64_t chunk = (total + rb - 1) / rb;
+  rb = (total + chunk - 1) / chunk;
+  hipStream_t st = (hipStream_t)stream;
+  const DropCtxN idc = make_dropn(in_drop);
+  hipLaunchKernelGGL(colsum_stage1, dim3(colblocks, (unsigned)rb, nseg), dim3(256), 0, st, in, ld, outer, inner, nseg,
+                     C, idc, workspace, chunk);
+  TECM_CHECK_LAUNCH("tecm_colsum/stage1");
+  hipLaunchKernelGGL(colsum_stage2, dim3((nseg * C + 255) / 256), dim3(256), 0, st, workspace, (int)rb, nseg, C, out,
+                     ldo, accumulate, scale);
+  TECM_CHECK_LAUNCH("tecm_colsum/stage2");
+  return TECM_OK;
+}

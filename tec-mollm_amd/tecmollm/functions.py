@@ -1,0 +1,432 @@
+"""torch.autograd.Function wrappers: one per stage of TEC_MoLLM.forward (tec_mollm.py:59-125).
+
+PyTorch owns tensors, the autograd graph and the optimiser; every forward and backward here is a
+sequence of launches of hand-written HIP kernels through the C ABI (ops.py).  Nothing in this file
+computes on tensors with torch ops except allocation, tiny weight reshapes (zero-padding the 22->24
+channel conv weights) and slicing of gradient buffers.
+
+All activations after the spatial stage are time-major (B, T, N, C): row m = (b*T + t)*N + n.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+
+from . import ops
+from ._lib import TecmSpatial, TecmSpatialGrads, check, lib, stream_ptr
+from .graph import GraphMeta
+from .ops import (A_KM, A_MK, ACT_GELU_ERF, ACT_GELU_TANH, B_KN, B_NK, colsum, drop, gemm, pick_split_k, win)
+
+import ctypes as C
+
+CP = 24            # C = 22 feature channels padded to a multiple of 4 floats (16-byte rows)
+C_FEAT = 22
+LORA_R = 32
+LORA_SCALE = 2.0   # lora_alpha / r = 64 / 32 (modules.py:177-183)
+GPT_HEADS = 12
+
+# dropout sites (each gets an independent seed derived from the per-forward base seed)
+SITE_GAT, SITE_EMBD, SITE_POST, SITE_HEAD = 0, 1, 100, 101
+
+
+def site_lora(i):
+    return 10 + 4 * i
+
+
+def site_attn(i):
+    return 11 + 4 * i
+
+
+def site_res1(i):
+    return 12 + 4 * i
+
+
+def site_res2(i):
+    return 13 + 4 * i
+
+
+@dataclass
+class DropPlan:
+    """Dropout configuration of one forward pass.  Masks are keep(seed_site, idx) recomputed in backward."""
+    training: bool
+    p: float
+    base_seed: int
+
+    def spec(self, site: int, ld: int):
+        if not self.training or self.p <= 0.0:
+            return None
+        return drop(self.p, ops.splitmix64(self.base_seed * 1000003 + site), ld)
+
+
+def _empty(*shape, like: torch.Tensor) -> torch.Tensor:
+    return torch.empty(*shape, device=like.device, dtype=torch.float32)
+
+
+# ============================================================================ stage a-1..a-3
+class SpatialFn(torch.autograd.Function):
+    """SpatioTemporalEmbedding + GATv2Conv + residual (modules.py:230-266, :340-359; tec_mollm.py:84-94)."""
+
+    @staticmethod
+    def forward(ctx, x, tf, node_tab, tod_tab, doy_tab, year_tab, season_tab, Wl, bl, Wr, br, att, bias,
+                meta: GraphMeta, heads: int, graphs_with_edges: int, plan: DropPlan):
+        B, L, N, Cin = x.shape
+        Demb = node_tab.shape[1]
+        x = x.contiguous()
+        out = _empty(B, L, N, CP, like=x)
+        d = SpatialFn._desc(x, tf, node_tab, tod_tab, doy_tab, year_tab, season_tab, Wl, bl, Wr, br, att, bias, meta,
+                            heads, graphs_with_edges, plan, B, L, N, Cin, Demb)
+        d.out = out.data_ptr()
+        check(lib().tecm_spatial_fwd(C.byref(d), stream_ptr()), "tecm_spatial_fwd")
+        ctx.save_for_backward(x, tf, node_tab, tod_tab, doy_tab, year_tab, season_tab, Wl, bl, Wr, br, att, bias)
+        ctx.meta, ctx.heads, ctx.R, ctx.plan = meta, heads, graphs_with_edges, plan
+        return out
+
+    @staticmethod
+    def _desc(x, tf, node_tab, tod_tab, doy_tab, year_tab, season_tab, Wl, bl, Wr, br, att, bias, meta, heads, R,
+              plan, B, L, N, Cin, Demb) -> TecmSpatial:
+        d = TecmSpatial()
+        d.B, d.L, d.N, d.Cin, d.Demb, d.H = B, L, N, Cin, Demb, heads
+        d.graphs_with_edges = min(int(R), B * L)
+        d.num_tiles, d.tile_nodes, d.win_max = meta.num_tiles, meta.tile_nodes, meta.win_max
+        d.x = x.data_ptr()
+        d.tf = tf.data_ptr()
+        d.tf_sb, d.tf_sl, d.tf_sn, d.tf_sf = tf.stride()
+        for name, t in (("node_tab", node_tab), ("tod_tab", tod_tab), ("doy_tab", doy_tab), ("year_tab", year_tab),
+                        ("season_tab", season_tab), ("Wl", Wl), ("bl", bl), ("Wr", Wr), ("br", br), ("att", att),
+                        ("bias", bias)):
+            setattr(d, name, t.data_ptr())
+        d.year_rows = year_tab.shape[0]
+        d.rowptr, d.colidx = meta.rowptr.data_ptr(), meta.colidx.data_ptr()
+        d.tile_lo, d.tile_hi = meta.tile_lo.data_ptr(), meta.tile_hi.data_ptr()
+        sp = plan.spec(SITE_GAT, meta.max_deg + 1)
+        if sp is not None:
+            d.alpha_drop = sp
+        return d
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x, tf, node_tab, tod_tab, doy_tab, year_tab, season_tab, Wl, bl, Wr, br, att, bias) = ctx.saved_tensors
+        meta = ctx.meta
+        B, L, N, Cin = x.shape
+        Demb = node_tab.shape[1]
+        dout = dout.contiguous()
+        d = SpatialFn._desc(x, tf, node_tab, tod_tab, doy_tab, year_tab, season_tab, Wl, bl, Wr, br, att, bias, meta,
+                            ctx.heads, ctx.R, ctx.plan, B, L, N, Cin, Demb)
+        t_chunk = 8
+        nchunks = (L + t_chunk - 1) // t_chunk
+        nblocks = meta.num_tiles * B * nchunks
+        Cc = C_FEAT
+        pld = 2 * Cc * Cc + 4 * Cc
+        partials = _empty(nblocks, pld, like=x)
+        d_node, d_tod, d_doy = torch.zeros_like(node_tab), torch.zeros_like(tod_tab), torch.zeros_like(doy_tab)
+        d_year, d_season = torch.zeros_like(year_tab), torch.zeros_like(season_tab)
+        g = TecmSpatialGrads()
+        g.dout = dout.data_ptr()
+        g.d_node_tab, g.d_tod_tab, g.d_doy_tab = d_node.data_ptr(), d_tod.data_ptr(), d_doy.data_ptr()
+        g.d_year_tab, g.d_season_tab = d_year.data_ptr(), d_season.data_ptr()
+        g.partials, g.partial_ld = partials.data_ptr(), pld
+        g.t_chunk, g.num_blocks = t_chunk, nblocks
+        check(lib().tecm_spatial_bwd(C.byref(d), C.byref(g), stream_ptr()), "tecm_spatial_bwd")
+        s = colsum(partials, pld, nblocks, 1, 1, pld)[0]
+        o = 0
+        dWl = s[o:o + Cc * Cc].view(Cc, Cc); o += Cc * Cc
+        dbl = s[o:o + Cc]; o += Cc
+        dWr = s[o:o + Cc * Cc].view(Cc, Cc); o += Cc * Cc
+        dbr = s[o:o + Cc]; o += Cc
+        datt = s[o:o + Cc].view_as(att); o += Cc
+        dbias = s[o:o + Cc]
+        return (None, None, d_node, d_tod, d_doy, d_year, d_season, dWl, dbl, dWr, dbr, datt, dbias,
+                None, None, None, None)
+
+
+# ============================================================================ stage a-4
+class ConvBlockFn(torch.autograd.Function):
+    """Multi_Scale_Conv_Block.forward (modules.py:43-60): three Conv1d(k=3,5,7)+GroupNorm(1)+GELU branches,
+    channel concat, Conv1d(k=1, stride).  inp is (B, Lc, N, ld_in) time-major with `cin` real channels
+    (ld_in - cin zero pad channels); returns (B, Lc//stride, N, Cout)."""
+
+    @staticmethod
+    def forward(ctx, inp, cin: int, stride: int, need_dinp: bool,
+                w3, b3, g3, be3, w5, b5, g5, be5, w7, b7, g7, be7, wf, bf):
+        B, Lc, N, ld_in = inp.shape
+        Cout = w3.shape[0]
+        CT = 3 * Cout
+        M = B * Lc * N
+        ws = (w3, w5, w7)
+        bs = (b3, b5, b7)
+        y = _empty(B, Lc, N, CT, like=inp)
+        packs = []
+        for j, (w, b) in enumerate(zip(ws, bs)):
+            k = w.shape[2]
+            wp = w if ld_in == cin else torch.nn.functional.pad(w, (0, 0, 0, ld_in - cin))
+            fp, bp = ops.conv_weight_pack(wp.contiguous(), want_bwd=True)
+            packs.append(bp)
+            gemm(M, Cout, k * ld_in, inp, ld_in, fp, k * ld_in, y, CT, c_off=j * Cout,
+                 a_win=win(N, Lc, Lc, 1, k, ld_in, (k - 1) // 2), bias=b)
+        gamma = torch.cat([g3, g5, g7])
+        beta = torch.cat([be3, be5, be7])
+        act = _empty(B, Lc, N, CT, like=inp)
+        stats = _empty(B * N, 3, 2, like=inp)
+        ops.groupnorm_gelu_fwd(y, gamma, beta, act, stats, B, Lc, N, Cout)
+        Lo = (Lc - 1) // stride + 1
+        out = _empty(B, Lo, N, Cout, like=inp)
+        wf2 = wf.view(Cout, CT)
+        gemm(B * Lo * N, Cout, CT, act, CT, wf2, CT, out, Cout, a_win=win(N, Lc, Lo, stride, 1, CT, 0), bias=bf)
+        ctx.save_for_backward(inp, y, act, stats, gamma, beta, wf, *packs)
+        ctx.dims = (B, Lc, N, ld_in, cin, Cout, stride, Lo, need_dinp)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        inp, y, act, stats, gamma, beta, wf, bp3, bp5, bp7 = ctx.saved_tensors
+        B, Lc, N, ld_in, cin, Cout, stride, Lo, need_dinp = ctx.dims
+        CT = 3 * Cout
+        M = B * Lc * N
+        Mo = B * Lo * N
+        dout = dout.contiguous()
+        wf2 = wf.view(Cout, CT)
+        # final 1x1 strided conv
+        dbf = colsum(dout, Cout, Mo, 1, 1, Cout)[0]
+        dwf = _empty(Cout, CT, like=inp)
+        gemm(Cout, CT, Mo, dout, Cout, act, CT, dwf, CT, a_layout=A_KM, b_layout=B_KN,
+             b_win=win(N, Lc, Lo, stride, 1, CT, 0), split_k=pick_split_k(Cout, CT, Mo))
+        dact = _empty(B, Lo, N, CT, like=inp)
+        gemm(Mo, CT, Cout, dout, Cout, wf2, CT, dact, CT, b_layout=B_KN)
+        # GroupNorm + GELU
+        dy = _empty(B, Lc, N, CT, like=inp)
+        dgamma, dbeta = ops.groupnorm_gelu_bwd(dact, stride, y, gamma, beta, stats, dy, B, Lc, N, Cout)
+        dinp = _empty(B, Lc, N, ld_in, like=inp) if need_dinp else None
+        grads = []
+        for j, (k, bp) in enumerate(((3, bp3), (5, bp5), (7, bp7))):
+            K = k * ld_in
+            db = colsum(dy, CT, M, 1, 1, Cout, in_off=j * Cout)[0]
+            dpack = _empty(Cout, K, like=inp)
+            gemm(Cout, K, M, dy, CT, inp, ld_in, dpack, K, a_layout=A_KM, b_layout=B_KN, a_off=j * Cout,
+                 b_win=win(N, Lc, Lc, 1, k, ld_in, (k - 1) // 2), split_k=pick_split_k(Cout, K, M))
+            dw = ops.conv_weight_unpack(dpack, Cout, ld_in, k)
+            if ld_in != cin:
+                dw = dw[:, :cin, :].contiguous()
+            if need_dinp:
+                gemm(M, ld_in, k * Cout, dy, CT, bp, ld_in, dinp, ld_in, b_layout=B_KN, a_off=j * Cout,
+                     a_win=win(N, Lc, Lc, 1, k, Cout, (k - 1) // 2), accumulate=(j > 0))
+            grads += [dw, db, dgamma[j * Cout:(j + 1) * Cout], dbeta[j * Cout:(j + 1) * Cout]]
+        return (dinp, None, None, None, *grads, dwf.view_as(wf), dbf)
+
+
+# ============================================================================ stage a-5 (+ wpe / embd dropout of a-6)
+class PatchEmbedFn(torch.autograd.Function):
+    """LatentPatchingProjection (modules.py:100-119) fused with GPT2Model's `+ wpe` and `drop`
+    (modeling_gpt2.py:576-604).  conv (B, Lc, N, D) -> tokens (B, P, N, d_llm), P = Lc // patch_len."""
+
+    @staticmethod
+    def forward(ctx, conv, Wp, bp, wpe, patch_len: int, plan: DropPlan):
+        B, Lc, N, D = conv.shape
+        P = Lc // patch_len
+        d_llm = Wp.shape[0]
+        M = B * P * N
+        K = patch_len * D
+        h0 = _empty(B, P, N, d_llm, like=conv)
+        w = win(N, Lc, P, patch_len, patch_len, D, 0)
+        dspec = plan.spec(SITE_EMBD, d_llm) if wpe is not None else None
+        gemm(M, d_llm, K, conv, D, Wp, K, h0, d_llm, a_win=w, bias=bp,
+             rowbias=(wpe, wpe.shape[1], N, P) if wpe is not None else None, out_drop=dspec)
+        ctx.save_for_backward(conv, Wp, wpe if wpe is not None else Wp)
+        ctx.meta = (B, Lc, N, D, P, d_llm, patch_len, wpe is not None, dspec)
+        return h0
+
+    @staticmethod
+    def backward(ctx, dh0):
+        conv, Wp, wpe = ctx.saved_tensors
+        B, Lc, N, D, P, d_llm, patch_len, has_wpe, dspec = ctx.meta
+        M = B * P * N
+        K = patch_len * D
+        dh0 = dh0.contiguous()
+        w = win(N, Lc, P, patch_len, patch_len, D, 0)
+        dbp = colsum(dh0, d_llm, M, 1, 1, d_llm, in_drop=dspec)[0]
+        dwpe = None
+        if has_wpe:
+            dwpe = torch.zeros_like(wpe)
+            colsum(dh0, d_llm, B, N, P, d_llm, in_drop=dspec, out=dwpe)      # rows 0..P-1 of wpe
+        dWp = _empty(d_llm, K, like=conv)
+        gemm(d_llm, K, M, dh0, d_llm, conv, D, dWp, K, a_layout=A_KM, b_layout=B_KN, b_win=w, a_drop=dspec,
+             split_k=pick_split_k(d_llm, K, M))
+        dconv = _empty(B, Lc, N, D, like=conv)
+        if P * patch_len != Lc:
+            dconv.zero_()
+        gemm(M, K, d_llm, dh0, d_llm, Wp, K, dconv, D, b_layout=B_KN, c_win=w, a_drop=dspec)
+        return dconv, dWp, dbp, dwpe, None, None
+
+
+# ============================================================================ stage a-6
+class GPT2StackFn(torch.autograd.Function):
+    """GPT2Block x n_layers + ln_f with LoRA(r=32) on c_attn (modeling_gpt2.py:262-310, :620;
+    peft Linear: modules.py:177-186).  h0 (B, T, N, 768) already holds inputs_embeds + wpe (+ embd dropout).
+    params per layer: ln1_w, ln1_b, Wqkv(768,2304), bqkv, loraA(32,768), loraB(2304,32), Wo, bo,
+                      ln2_w, ln2_b, Wfc, bfc, Wproj, bproj      then lnf_w, lnf_b."""
+    PER_LAYER = 14
+
+    @staticmethod
+    def forward(ctx, h0, n_layers: int, plan: DropPlan, *params):
+        B, T, N, D = h0.shape
+        M = B * T * N
+        KE = D + LORA_R
+        h = h0.contiguous()
+        saved: List[torch.Tensor] = []
+        for i in range(n_layers):
+            (ln1w, ln1b, Wqkv, bqkv, lA, lB, Wo, bo, ln2w, ln2b, Wfc, bfc, Wpr,
+             bpr) = params[i * GPT2StackFn.PER_LAYER:(i + 1) * GPT2StackFn.PER_LAYER]
+            F3, F4 = Wqkv.shape[1], Wfc.shape[1]
+            u = _empty(M, KE, like=h)                       # [ LN1(h) | z = drop(LN1(h)) A^T ]
+            st1 = _empty(M, 2, like=h)
+            ops.layernorm_fwd(h, D, ln1w, ln1b, u, KE, st1, M, D)
+            lspec = plan.spec(site_lora(i), KE)
+            gemm(M, LORA_R, D, u, KE, lA, D, u, KE, c_off=D, a_drop=lspec)
+            wcat = _empty(KE, F3, like=h)                   # [ W ; (alpha/r) B^T ]  K-extended c_attn
+            wcat[:D].copy_(Wqkv)
+            ops.transpose_scale(lB, LORA_R, wcat, F3, LORA_R, F3, LORA_SCALE, dst_off=D * F3)
+            qkv = _empty(M, F3, like=h)
+            gemm(M, F3, KE, u, KE, wcat, F3, qkv, F3, b_layout=B_KN, bias=bqkv)
+            cx = _empty(M, D, like=h)
+            aspec = plan.spec(site_attn(i), 1)
+            ops.attention_fwd(qkv, cx, B, T, N, GPT_HEADS, D, aspec)
+            h2 = _empty(M, D, like=h)
+            gemm(M, D, D, cx, D, Wo, D, h2, D, b_layout=B_KN, bias=bo, out_drop=plan.spec(site_res1(i), D),
+                 residual=(h, D))
+            u2 = _empty(M, D, like=h)
+            st2 = _empty(M, 2, like=h)
+            ops.layernorm_fwd(h2, D, ln2w, ln2b, u2, D, st2, M, D)
+            a = _empty(M, F4, like=h)
+            f = _empty(M, F4, like=h)
+            gemm(M, F4, D, u2, D, Wfc, F4, f, F4, b_layout=B_KN, bias=bfc, preact=(a, F4), act=ACT_GELU_TANH)
+            h3 = _empty(M, D, like=h)
+            gemm(M, D, F4, f, F4, Wpr, D, h3, D, b_layout=B_KN, bias=bpr, out_drop=plan.spec(site_res2(i), D),
+                 residual=(h2, D))
+            saved += [h, u, st1, wcat, qkv, cx, h2, st2, u2, a]
+            h = h3
+        lnfw, lnfb = params[n_layers * GPT2StackFn.PER_LAYER:]
+        out = _empty(B, T, N, D, like=h)
+        stf = _empty(M, 2, like=h)
+        ops.layernorm_fwd(h, D, lnfw, lnfb, out, D, stf, M, D)
+        ctx.save_for_backward(h, stf, *saved, *params)
+        ctx.meta = (B, T, N, D, n_layers, plan, len(saved))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, T, N, D, n_layers, plan, nsaved = ctx.meta
+        tens = ctx.saved_tensors
+        h_last, stf = tens[0], tens[1]
+        saved = tens[2:2 + nsaved]
+        params = tens[2 + nsaved:]
+        M = B * T * N
+        KE = D + LORA_R
+        dout = dout.contiguous()
+        lnfw = params[n_layers * GPT2StackFn.PER_LAYER]
+        dh = _empty(M, D, like=dout)
+        dlnfw, dlnfb = ops.layernorm_bwd(dout, D, h_last, D, lnfw, stf, None, dh, M, D)
+        pgrads: List[Optional[torch.Tensor]] = [None] * (n_layers * GPT2StackFn.PER_LAYER)
+        for i in reversed(range(n_layers)):
+            (ln1w, ln1b, Wqkv, bqkv, lA, lB, Wo, bo, ln2w, ln2b, Wfc, bfc, Wpr,
+             bpr) = params[i * GPT2StackFn.PER_LAYER:(i + 1) * GPT2StackFn.PER_LAYER]
+            h, u, st1, wcat, qkv, cx, h2, st2, u2, a = saved[i * 10:(i + 1) * 10]
+            F3, F4 = Wqkv.shape[1], Wfc.shape[1]
+            # MLP:  h3 = h2 + drop(gelu(u2 Wfc + b) Wpr + b)
+            da = _empty(M, F4, like=dh)
+            gemm(M, F4, D, dh, D, Wpr, D, da, F4, a_drop=plan.spec(site_res2(i), D), act=ACT_GELU_TANH,
+                 dact_src=(a, F4))
+            du2 = _empty(M, D, like=dh)
+            gemm(M, D, F4, da, F4, Wfc, F4, du2, D)
+            del da
+            dh2 = _empty(M, D, like=dh)
+            dg2, db2 = ops.layernorm_bwd(du2, D, h2, D, ln2w, st2, dh, dh2, M, D)
+            # attention: h2 = h + drop(ctx Wo + b)
+            dcx = du2                                         # reuse buffer
+            gemm(M, D, D, dh2, D, Wo, D, dcx, D, a_drop=plan.spec(site_res1(i), D))
+            dqkv = _empty(M, F3, like=dh)
+            ops.attention_bwd(qkv, dcx, dqkv, B, T, N, GPT_HEADS, D, plan.spec(site_attn(i), 1))
+            du = _empty(M, KE, like=dh)                       # [ d LN1-out (base path) | dz ]
+            gemm(M, KE, F3, dqkv, F3, wcat, F3, du, KE)
+            lspec = plan.spec(site_lora(i), KE)
+            dlB = _empty(F3, LORA_R, like=dh)
+            gemm(F3, LORA_R, M, dqkv, F3, u, KE, dlB, LORA_R, a_layout=A_KM, b_layout=B_KN, b_off=D,
+                 alpha=LORA_SCALE, split_k=pick_split_k(F3, LORA_R, M))
+            dlA = _empty(LORA_R, D, like=dh)
+            gemm(LORA_R, D, M, du, KE, u, KE, dlA, D, a_layout=A_KM, b_layout=B_KN, a_off=D, b_drop=lspec,
+                 split_k=pick_split_k(LORA_R, D, M))
+            # LoRA path back to LN1's output: du[:, :D] += mask * (dz A)
+            gemm(M, D, LORA_R, du, KE, lA, D, du, KE, b_layout=B_KN, a_off=D, out_drop=lspec, accumulate=True)
+            dhn = _empty(M, D, like=dh)
+            dg1, db1 = ops.layernorm_bwd(du, KE, h, D, ln1w, st1, dh2, dhn, M, D)
+            dh = dhn
+            base = i * GPT2StackFn.PER_LAYER
+            pgrads[base + 0], pgrads[base + 1] = dg1, db1
+            pgrads[base + 4], pgrads[base + 5] = dlA, dlB
+            pgrads[base + 8], pgrads[base + 9] = dg2, db2
+        pg = [g if ctx.needs_input_grad[3 + j] else None for j, g in enumerate(pgrads)]
+        return (dh.view(B, T, N, D), None, None, *pg, dlnfw, dlnfb)
+
+
+# ============================================================================ stage a-7/a-8
+class HeadFn(torch.autograd.Function):
+    """F.dropout (tec_mollm.py:115) + PredictionHead (modules.py:295-313):
+    hid (B, T, N, 768) -> (B, N, L_out); flattened feature index = t*768 + d."""
+
+    @staticmethod
+    def forward(ctx, hid, W1, b1, W2, b2, plan: DropPlan):
+        B, T, N, D = hid.shape
+        S = B * N
+        Hd, K1 = W1.shape
+        Lo = W2.shape[0]
+        w = win(N, T, 1, T, T, D, 0)
+        pspec = plan.spec(SITE_POST, D)
+        hspec = plan.spec(SITE_HEAD, Hd)
+        pre = _empty(S, Hd, like=hid)
+        h1 = _empty(S, Hd, like=hid)
+        gemm(S, Hd, K1, hid, D, W1, K1, h1, Hd, a_win=w, a_drop=pspec, bias=b1, preact=(pre, Hd), act=ACT_GELU_ERF,
+             out_drop=hspec)
+        pred = _empty(B, N, Lo, like=hid)
+        gemm(S, Lo, Hd, h1, Hd, W2, Hd, pred, Lo, bias=b2)
+        ctx.save_for_backward(hid, W1, W2, pre, h1)
+        ctx.meta = (B, T, N, D, Hd, K1, Lo, w, pspec, hspec)
+        return pred
+
+    @staticmethod
+    def backward(ctx, dpred):
+        hid, W1, W2, pre, h1 = ctx.saved_tensors
+        B, T, N, D, Hd, K1, Lo, w, pspec, hspec = ctx.meta
+        S = B * N
+        dpred = dpred.contiguous()
+        db2 = colsum(dpred, Lo, S, 1, 1, Lo)[0]
+        dW2 = _empty(Lo, Hd, like=hid)
+        gemm(Lo, Hd, S, dpred, Lo, h1, Hd, dW2, Hd, a_layout=A_KM, b_layout=B_KN, split_k=pick_split_k(Lo, Hd, S))
+        dpre = _empty(S, Hd, like=hid)
+        gemm(S, Hd, Lo, dpred, Lo, W2, Hd, dpre, Hd, b_layout=B_KN, act=ACT_GELU_ERF, dact_src=(pre, Hd),
+             out_drop=hspec)
+        db1 = colsum(dpre, Hd, S, 1, 1, Hd)[0]
+        dW1 = _empty(Hd, K1, like=hid)
+        gemm(Hd, K1, S, dpre, Hd, hid, D, dW1, K1, a_layout=A_KM, b_layout=B_KN, b_win=w, b_drop=pspec,
+             split_k=pick_split_k(Hd, K1, S))
+        dhid = _empty(B, T, N, D, like=hid)
+        gemm(S, K1, Hd, dpre, Hd, W1, K1, dhid, D, b_layout=B_KN, c_win=w, out_drop=pspec)
+        return dhid, dW1, db1, dW2, db2, None
+
+
+# ============================================================================ loss
+class HuberFn(torch.autograd.Function):
+    """nn.HuberLoss(delta=1.0), mean reduction (train.py:372), loss and gradient in one pass."""
+
+    @staticmethod
+    def forward(ctx, pred, target, delta: float):
+        p = pred.contiguous()
+        t = target.contiguous()
+        loss, dpred = ops.huber_fwd_bwd(p, t, delta, 1.0, want_grad=True)
+        ctx.save_for_backward(dpred)
+        ctx.shape = pred.shape
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, gloss):
+        (dpred,) = ctx.saved_tensors
+        return dpred.view(ctx.shape) * gloss, None, None

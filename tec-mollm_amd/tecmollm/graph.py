@@ -1,0 +1,102 @@
+"""Host-side graph preparation for the fused spatial kernel.
+
+`edge_index` is the reference's (2,E) int64 COO with [0] = source j, [1] = target i
+(graph_constructor.py:141; PyG flow source_to_target).  GATv2Conv strips self loops and re-adds one
+per node (modules.py:335), so self loops are dropped here and handled implicitly by the kernel.
+The result is a CSR by target plus, per tile of `tile_nodes` consecutive targets, the node-id
+window [lo,hi) that covers the tile and all of its sources -- what the kernel stages in LDS.
+Built once per distinct edge_index tensor and cached (the graph is static during training).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+
+LDS_BYTES = 160 * 1024
+C_FEAT = 22
+
+
+@dataclass
+class GraphMeta:
+    num_nodes: int
+    num_edges: int
+    max_deg: int
+    tile_nodes: int
+    num_tiles: int
+    win_max: int
+    rowptr: torch.Tensor   # int32 (N+1) device
+    colidx: torch.Tensor   # int32 (E') device
+    tile_lo: torch.Tensor  # int32 (num_tiles) device
+    tile_hi: torch.Tensor  # int32 (num_tiles) device
+
+
+def csr_by_target(edge_index: np.ndarray, num_nodes: int) -> Tuple[np.ndarray, np.ndarray]:
+    src, dst = edge_index[0].astype(np.int64), edge_index[1].astype(np.int64)
+    if src.size and (src.min() < 0 or dst.min() < 0 or src.max() >= num_nodes or dst.max() >= num_nodes):
+        raise ValueError(f"edge_index has node ids outside [0, {num_nodes})")
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    order = np.argsort(dst, kind="stable")          # keeps the given edge order inside each target
+    src, dst = src[order], dst[order]
+    rowptr = np.zeros(num_nodes + 1, dtype=np.int64)
+    np.add.at(rowptr, dst + 1, 1)
+    rowptr = np.cumsum(rowptr)
+    return rowptr.astype(np.int32), src.astype(np.int32)
+
+
+def tile_windows(rowptr: np.ndarray, colidx: np.ndarray, num_nodes: int, tile_nodes: int):
+    num_tiles = (num_nodes + tile_nodes - 1) // tile_nodes
+    lo = np.empty(num_tiles, dtype=np.int32)
+    hi = np.empty(num_tiles, dtype=np.int32)
+    for k in range(num_tiles):
+        n0, n1 = k * tile_nodes, min(num_nodes, (k + 1) * tile_nodes)
+        cols = colidx[rowptr[n0]:rowptr[n1]]
+        lo[k] = min(n0, int(cols.min())) if cols.size else n0
+        hi[k] = max(n1, int(cols.max()) + 1) if cols.size else n1
+    return lo, hi
+
+
+def lds_bytes_bwd(win: int, tile_nodes: int, demb: int = 16) -> int:
+    wm4 = (win + 3) & ~3
+    return 4 * (3 * wm4 * C_FEAT + tile_nodes * C_FEAT + wm4 * demb + 64 + 2 * C_FEAT)
+
+
+def build(edge_index: torch.Tensor, num_nodes: int, device: torch.device, demb: int = 16) -> GraphMeta:
+    ei = edge_index.detach().cpu().numpy()
+    rowptr, colidx = csr_by_target(ei, num_nodes)
+    deg = np.diff(rowptr)
+    chosen = None
+    for tn in (128, 64, 32, 16, 8, 4, 2, 1):          # largest tile whose backward window fits the LDS
+        tn = min(tn, 256)
+        lo, hi = tile_windows(rowptr, colidx, num_nodes, tn)
+        wmax = int((hi - lo).max())
+        if lds_bytes_bwd(wmax, tn, demb) <= LDS_BYTES - 4096:
+            chosen = (tn, lo, hi, wmax)
+            break
+    if chosen is None:
+        raise ValueError(
+            "graph bandwidth too large for the 160 KiB LDS neighbour window even with 1-node tiles; "
+            "renumber the nodes (e.g. reverse Cuthill-McKee) so that neighbours have nearby ids")
+    tn, lo, hi, wmax = chosen
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)   # noqa: E731
+    return GraphMeta(num_nodes=num_nodes, num_edges=int(colidx.size), max_deg=int(deg.max()) if deg.size else 0,
+                     tile_nodes=tn, num_tiles=int(lo.size), win_max=wmax, rowptr=to(rowptr),
+                     colidx=to(colidx if colidx.size else np.zeros(1, np.int32)), tile_lo=to(lo), tile_hi=to(hi))
+
+
+_cache: Dict[Tuple[int, int, int, str], Tuple[torch.Tensor, GraphMeta]] = {}
+
+
+def get(edge_index: torch.Tensor, num_nodes: int, device: torch.device, demb: int = 16) -> GraphMeta:
+    key = (edge_index.data_ptr(), int(edge_index.shape[1]), num_nodes, str(device))
+    hit = _cache.get(key)
+    if hit is not None and hit[0] is edge_index:
+        return hit[1]
+    meta = build(edge_index, num_nodes, device, demb)
+    _cache[key] = (edge_index, meta)
+    if len(_cache) > 16:
+        _cache.pop(next(iter(_cache)))
+    return meta

@@ -1,0 +1,205 @@
+"""Thin, typed wrappers over the C ABI (include/tecmollm.h).  Every function launches HIP kernels
+asynchronously on torch's current stream; tensors are only used as device-memory handles."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import TecmDrop, TecmGemm, TecmWin, check, lib, ptr, stream_ptr
+
+A_MK, A_KM = 0, 1
+B_NK, B_KN = 0, 1
+ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH = 0, 1, 2
+
+_MASK64 = (1 << 64) - 1
+
+
+def splitmix64(x: int) -> int:
+    x = (x + 0x9E3779B97F4A7C15) & _MASK64
+    z = x
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _MASK64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _MASK64
+    return z ^ (z >> 31)
+
+
+def win(N: int, Lin: int, Lout: int, stride_t: int, taps: int, Cw: int, pad: int) -> TecmWin:
+    return TecmWin(1, N, Lin, Lout, stride_t, taps, Cw, pad)
+
+
+NO_WIN = TecmWin(0, 0, 0, 0, 0, 0, 0, 0)
+
+
+def drop(p: float, seed: int, ld: int) -> TecmDrop:
+    return TecmDrop(float(p), 0, seed & _MASK64, int(ld))
+
+
+NO_DROP = TecmDrop(0.0, 0, 0, 0)
+
+
+def _off(t: torch.Tensor, col_off: int = 0) -> int:
+    return t.data_ptr() + 4 * col_off
+
+
+def gemm(M: int, N: int, K: int, A: torch.Tensor, lda: int, B: torch.Tensor, ldb: int, Cout: torch.Tensor, ldc: int,
+         *, a_layout: int = A_MK, b_layout: int = B_NK, a_off: int = 0, b_off: int = 0, c_off: int = 0,
+         a_win: Optional[TecmWin] = None, b_win: Optional[TecmWin] = None, c_win: Optional[TecmWin] = None,
+         a_drop: Optional[TecmDrop] = None, b_drop: Optional[TecmDrop] = None, out_drop: Optional[TecmDrop] = None,
+         alpha: float = 1.0, act: int = ACT_NONE, bias: Optional[torch.Tensor] = None,
+         rowbias: Optional[Tuple[torch.Tensor, int, int, int]] = None,
+         preact: Optional[Tuple[torch.Tensor, int]] = None, dact_src: Optional[Tuple[torch.Tensor, int]] = None,
+         residual: Optional[Tuple[torch.Tensor, int]] = None, accumulate: bool = False, split_k: int = 1) -> None:
+    """C[M,N] = epilogue(alpha * A_view[M,K] . B_view[K,N]); see TecmGemm in include/tecmollm.h.
+    *_off are element offsets added to the base pointers (column slices of wider buffers)."""
+    g = TecmGemm()
+    g.M, g.N, g.K = M, N, K
+    g.A, g.lda, g.a_layout = _off(A, a_off), lda, a_layout
+    g.B, g.ldb, g.b_layout = _off(B, b_off), ldb, b_layout
+    g.C, g.ldc = _off(Cout, c_off), ldc
+    g.a_win = a_win or NO_WIN
+    g.b_win = b_win or NO_WIN
+    g.c_win = c_win or NO_WIN
+    g.a_drop = a_drop or NO_DROP
+    g.b_drop = b_drop or NO_DROP
+    g.out_drop = out_drop or NO_DROP
+    g.alpha, g.act = alpha, act
+    g.bias = ptr(bias)
+    if rowbias is not None:
+        rb, rb_ld, rb_div, rb_mod = rowbias
+        g.rowbias, g.rb_ld, g.rb_div, g.rb_mod = rb.data_ptr(), rb_ld, rb_div, rb_mod
+    if preact is not None:
+        g.preact, g.ldp = preact[0].data_ptr(), preact[1]
+    if dact_src is not None:
+        g.dact_src, g.ldd = dact_src[0].data_ptr(), dact_src[1]
+    if residual is not None:
+        g.residual, g.ldr = residual[0].data_ptr(), residual[1]
+    g.accumulate = 1 if accumulate else 0
+    ws = None
+    if split_k > 1:
+        ws = torch.empty(split_k * M * N, device=Cout.device, dtype=torch.float32)
+        g.split_k, g.workspace = split_k, ws.data_ptr()
+    else:
+        g.split_k = 1
+    check(lib().tecm_gemm_f32(C.byref(g), stream_ptr()), "tecm_gemm_f32")
+
+
+def pick_split_k(Mo: int, No: int, K: int, target_blocks: int = 768, min_chunk: int = 512) -> int:
+    """Split the (huge) reduction dim of a weight-gradient GEMM so the grid fills 256 CUs."""
+    tiles = ((Mo + 127) // 128) * ((No + 127) // 128 if No > 32 else 1)
+    s = max(1, target_blocks // max(tiles, 1))
+    s = min(s, max(1, K // min_chunk))
+    return int(s)
+
+
+def layernorm_fwd(x: torch.Tensor, ldx: int, gamma: torch.Tensor, beta: torch.Tensor, y: torch.Tensor, ldy: int,
+                  stats: torch.Tensor, M: int, D: int, eps: float = 1e-5, y_off: int = 0) -> None:
+    check(lib().tecm_layernorm_fwd(x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), _off(y, y_off), ldy,
+                                   stats.data_ptr(), M, D, eps, stream_ptr()), "tecm_layernorm_fwd")
+
+
+def layernorm_bwd_blocks(M: int, D: int) -> int:
+    nb = C.c_int32(0)
+    check(lib().tecm_layernorm_bwd(None, 0, None, 0, None, None, None, None, None, None, C.byref(nb), M, D, None),
+          "tecm_layernorm_bwd(query)")
+    return nb.value
+
+
+def layernorm_bwd(dy: torch.Tensor, lddy: int, x: torch.Tensor, ldx: int, gamma: torch.Tensor, stats: torch.Tensor,
+                  dres: Optional[torch.Tensor], dx: torch.Tensor, M: int, D: int,
+                  out_drop: Optional[TecmDrop] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Returns (dgamma, dbeta)."""
+    nb = layernorm_bwd_blocks(M, D)
+    partials = torch.empty(nb, 2 * D, device=dx.device, dtype=torch.float32)
+    nbc = C.c_int32(0)
+    od = out_drop if out_drop is not None else NO_DROP
+    check(lib().tecm_layernorm_bwd(dy.data_ptr(), lddy, x.data_ptr(), ldx, gamma.data_ptr(), stats.data_ptr(),
+                                   ptr(dres), dx.data_ptr(), C.byref(od), partials.data_ptr(), C.byref(nbc), M, D,
+                                   stream_ptr()), "tecm_layernorm_bwd")
+    dgb = colsum(partials, 2 * D, nb, 1, 1, 2 * D)
+    return dgb[0, :D], dgb[0, D:]
+
+
+def groupnorm_gelu_fwd(y: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, act: torch.Tensor,
+                       stats: torch.Tensor, B: int, L: int, N: int, Cout: int, eps: float = 1e-5) -> None:
+    check(lib().tecm_groupnorm_gelu_fwd(y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), act.data_ptr(),
+                                        stats.data_ptr(), B, L, N, Cout, eps, stream_ptr()),
+          "tecm_groupnorm_gelu_fwd")
+
+
+def groupnorm_gelu_bwd(dact: torch.Tensor, dstride: int, y: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
+                       stats: torch.Tensor, dy: torch.Tensor, B: int, L: int, N: int,
+                       Cout: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Returns (dgamma, dbeta), each (3*Cout,)."""
+    nb = C.c_int32(0)
+    check(lib().tecm_groupnorm_gelu_bwd(None, dstride, None, None, None, None, None, None, C.byref(nb), B, L, N, Cout,
+                                        None), "tecm_groupnorm_gelu_bwd(query)")
+    CT = 3 * Cout
+    partials = torch.empty(nb.value, 2 * CT, device=dy.device, dtype=torch.float32)
+    check(lib().tecm_groupnorm_gelu_bwd(dact.data_ptr(), dstride, y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                        stats.data_ptr(), dy.data_ptr(), partials.data_ptr(), C.byref(nb), B, L, N,
+                                        Cout, stream_ptr()), "tecm_groupnorm_gelu_bwd")
+    dgb = colsum(partials, 2 * CT, nb.value, 1, 1, 2 * CT)
+    return dgb[0, :CT], dgb[0, CT:]
+
+
+def attention_fwd(qkv: torch.Tensor, ctx: torch.Tensor, B: int, T: int, N: int, heads: int, D: int,
+                  prob_drop: Optional[TecmDrop] = None) -> None:
+    pd = prob_drop if prob_drop is not None else NO_DROP
+    check(lib().tecm_attention_fwd(qkv.data_ptr(), ctx.data_ptr(), B, T, N, heads, D, C.byref(pd), stream_ptr()),
+          "tecm_attention_fwd")
+
+
+def attention_bwd(qkv: torch.Tensor, dctx: torch.Tensor, dqkv: torch.Tensor, B: int, T: int, N: int, heads: int,
+                  D: int, prob_drop: Optional[TecmDrop] = None) -> None:
+    pd = prob_drop if prob_drop is not None else NO_DROP
+    check(lib().tecm_attention_bwd(qkv.data_ptr(), dctx.data_ptr(), dqkv.data_ptr(), B, T, N, heads, D, C.byref(pd),
+                                   stream_ptr()), "tecm_attention_bwd")
+
+
+def colsum(inp: torch.Tensor, ld: int, outer: int, inner: int, nseg: int, Cn: int, *, in_off: int = 0,
+           scale: float = 1.0, in_drop: Optional[TecmDrop] = None, out: Optional[torch.Tensor] = None,
+           accumulate: bool = False) -> torch.Tensor:
+    """out[s][c] = scale * sum_{o<outer, j<inner} in[((o*nseg + s)*inner + j)*ld + c]  -> (nseg, Cn)."""
+    if out is None:
+        out = torch.empty(nseg, Cn, device=inp.device, dtype=torch.float32)
+    ws = torch.empty(256 * nseg * Cn, device=inp.device, dtype=torch.float32)
+    idr = in_drop if in_drop is not None else NO_DROP
+    check(lib().tecm_colsum(_off(inp, in_off), ld, outer, inner, nseg, Cn, out.data_ptr(), Cn, 1 if accumulate else 0,
+                            scale, C.byref(idr), ws.data_ptr(), stream_ptr()), "tecm_colsum")
+    return out
+
+
+def huber_fwd_bwd(pred: torch.Tensor, target: torch.Tensor, delta: float = 1.0, grad_scale: float = 1.0,
+                  want_grad: bool = True) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    n = pred.numel()
+    loss = torch.empty(1, device=pred.device, dtype=torch.float32)
+    dpred = torch.empty_like(pred) if want_grad else None
+    ws = torch.empty(1024, device=pred.device, dtype=torch.float32)
+    check(lib().tecm_huber_fwd_bwd(pred.data_ptr(), target.data_ptr(), ptr(dpred), loss.data_ptr(), n, delta,
+                                   grad_scale, ws.data_ptr(), stream_ptr()), "tecm_huber_fwd_bwd")
+    return loss, dpred
+
+
+def conv_weight_pack(w: torch.Tensor, want_bwd: bool = True) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    Cout, Cin, k = w.shape
+    fwd = torch.empty(Cout, k * Cin, device=w.device, dtype=torch.float32)
+    bwd = torch.empty(k * Cout, Cin, device=w.device, dtype=torch.float32) if want_bwd else None
+    check(lib().tecm_conv_weight_pack(w.data_ptr(), fwd.data_ptr(), ptr(bwd), Cout, Cin, k, stream_ptr()),
+          "tecm_conv_weight_pack")
+    return fwd, bwd
+
+
+def conv_weight_unpack(dpack: torch.Tensor, Cout: int, Cin: int, k: int) -> torch.Tensor:
+    dw = torch.empty(Cout, Cin, k, device=dpack.device, dtype=torch.float32)
+    check(lib().tecm_conv_weight_unpack(dpack.data_ptr(), dw.data_ptr(), Cout, Cin, k, stream_ptr()),
+          "tecm_conv_weight_unpack")
+    return dw
+
+
+def transpose_scale(src: torch.Tensor, lds: int, dst: torch.Tensor, ldd: int, rows: int, cols: int, scale: float,
+                    dst_off: int = 0) -> None:
+    """dst[r*ldd + c] = scale * src[c*lds + r]."""
+    check(lib().tecm_transpose_scale(src.data_ptr(), lds, _off(dst, dst_off), ldd, rows, cols, scale, stream_ptr()),
+          "tecm_transpose_scale")

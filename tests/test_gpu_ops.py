@@ -1,0 +1,322 @@
+"""GPU parity tests of the individual HIP kernels through the C ABI (via tecmollm.ops).
+References here are plain torch fp64 ops on the same inputs (floating-point kernels), the dropout
+masks come from the NumPy mirror of the device hash.  Tolerance: 1e-4 relative to the reference's
+max magnitude (fp32 accumulate vs fp64), tighter than the 1e-3 the north star asks end to end."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-4
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda")
+
+
+def _rand(*shape, dev, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dev)
+
+
+# ----------------------------------------------------------------------------- GEMM, plain views
+@pytest.mark.parametrize("M,N,K", [(300, 200, 96), (129, 130, 64), (77, 33, 50), (64, 31, 51), (1000, 12, 576),
+                                   (257, 32, 768), (513, 768, 32)])
+def test_gemm_mk_nk(dev, M, N, K):
+    from tecmollm import ops
+    A, B = _rand(M, K, dev=dev, seed=1), _rand(N, K, dev=dev, seed=2)
+    bias = _rand(N, dev=dev, seed=3)
+    C = torch.full((M, N), float("nan"), device=dev)
+    ops.gemm(M, N, K, A, K, B, K, C, N, bias=bias)
+    ref = A.double() @ B.double().t() + bias.double()
+    assert _rel(C, ref) < TOL
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 200, 96), (130, 2304, 800), (77, 22, 192), (65, 50, 33)])
+def test_gemm_mk_kn(dev, M, N, K):
+    from tecmollm import ops
+    A, B = _rand(M, K, dev=dev, seed=1), _rand(K, N, dev=dev, seed=2)
+    C = torch.full((M, N), float("nan"), device=dev)
+    ops.gemm(M, N, K, A, K, B, N, C, N, b_layout=ops.B_KN, alpha=0.5)
+    assert _rel(C, 0.5 * (A.double() @ B.double())) < TOL
+
+
+@pytest.mark.parametrize("Mo,No,K,split", [(64, 154, 3000, 1), (64, 168, 5000, 7), (12, 576, 999, 3),
+                                           (2304, 32, 2000, 4), (32, 768, 1501, 1), (100, 75, 333, 2)])
+def test_gemm_km_kn_splitk(dev, Mo, No, K, split):
+    from tecmollm import ops
+    A, B = _rand(K, Mo, dev=dev, seed=1), _rand(K, No, dev=dev, seed=2)
+    C = torch.full((Mo, No), float("nan"), device=dev)
+    ops.gemm(Mo, No, K, A, Mo, B, No, C, No, a_layout=ops.A_KM, b_layout=ops.B_KN, split_k=split)
+    assert _rel(C, A.double().t() @ B.double()) < TOL
+
+
+def test_gemm_strided_slices_and_accumulate(dev):
+    """column slices of wider buffers (lda/ldc + offsets), residual, accumulate."""
+    from tecmollm import ops
+    M, K, N = 200, 64, 96
+    Abuf, B = _rand(M, 100, dev=dev, seed=1), _rand(N, K, dev=dev, seed=2)
+    Cbuf = _rand(M, 300, dev=dev, seed=3)
+    C0 = Cbuf.clone()
+    R = _rand(M, N, dev=dev, seed=4)
+    ops.gemm(M, N, K, Abuf, 100, B, K, Cbuf, 300, a_off=36, c_off=100, residual=(R, N), accumulate=True)
+    ref = C0.double().clone()
+    ref[:, 100:100 + N] += Abuf[:, 36:36 + K].double() @ B.double().t() + R.double()
+    assert _rel(Cbuf, ref) < TOL
+    assert torch.equal(Cbuf[:, :100], C0[:, :100]) and torch.equal(Cbuf[:, 196:], C0[:, 196:])
+
+
+def test_gemm_activations_preact_dact(dev):
+    from tecmollm import ops
+    M, K, N = 150, 64, 80
+    A, B = _rand(M, K, dev=dev, seed=1, scale=0.3), _rand(N, K, dev=dev, seed=2, scale=0.3)
+    for act, fn in ((ops.ACT_GELU_ERF, lambda t: torch.nn.functional.gelu(t)),
+                    (ops.ACT_GELU_TANH, lambda t: torch.nn.functional.gelu(t, approximate="tanh"))):
+        C = torch.empty(M, N, device=dev)
+        pre = torch.empty(M, N, device=dev)
+        ops.gemm(M, N, K, A, K, B, K, C, N, act=act, preact=(pre, N))
+        z = A.double() @ B.double().t()
+        assert _rel(pre, z) < TOL and _rel(C, fn(z)) < TOL
+        # backward through the activation: out = (A.B^T) * act'(src)
+        src = _rand(M, N, dev=dev, seed=5)
+        D = torch.empty(M, N, device=dev)
+        ops.gemm(M, N, K, A, K, B, K, D, N, act=act, dact_src=(src, N))
+        s = src.double().requires_grad_(True)
+        (gsum,) = torch.autograd.grad(fn(s).sum(), s)
+        assert _rel(D, z * gsum) < TOL
+
+
+def test_gemm_dropout_prologue_epilogue_match_numpy_mirror(dev):
+    from tecmollm import ops, rng
+    M, K, N = 140, 96, 70
+    A, B = _rand(M, K, dev=dev, seed=1), _rand(N, K, dev=dev, seed=2)
+    p, seedA, seedO = 0.1, 0x1234567890ABCDEF, 987654321
+    C = torch.empty(M, N, device=dev)
+    ops.gemm(M, N, K, A, K, B, K, C, N, a_drop=ops.drop(p, seedA, 800), out_drop=ops.drop(p, seedO, N))
+    ia = (np.arange(M)[:, None] * 800 + np.arange(K)[None, :]).astype(np.uint64)
+    io = (np.arange(M)[:, None] * N + np.arange(N)[None, :]).astype(np.uint64)
+    ma = torch.from_numpy(rng.keep_mult(seedA, ia, p)).double()
+    mo = torch.from_numpy(rng.keep_mult(seedO, io, p)).double()
+    ref = ((A.double().cpu() * ma) @ B.double().cpu().t()) * mo
+    assert _rel(C, ref) < TOL
+    frac = float((ma == 0).double().mean())
+    assert 0.07 < frac < 0.13
+
+
+# ----------------------------------------------------------------------------- GEMM, window views
+def _tm(x_scl):
+    """(S, C, L) reference conv layout -> time-major (B=S, L, N=1, C)."""
+    S, Cc, L = x_scl.shape
+    return x_scl.permute(0, 2, 1).contiguous().view(S, L, 1, Cc)
+
+
+@pytest.mark.parametrize("Bn,L,N,Cin,Cout,k", [(2, 48, 5, 24, 64, 3), (2, 24, 3, 64, 128, 7), (1, 16, 7, 22, 64, 5),
+                                               (3, 12, 4, 8, 32, 7)])
+def test_gemm_window_conv_forward(dev, Bn, L, N, Cin, Cout, k):
+    """A-window == Conv1d over time with zero padding (modules.py:27) on a (B, L, N, C) tensor."""
+    from tecmollm import ops
+    x = _rand(Bn, L, N, Cin, dev=dev, seed=1)
+    w = _rand(Cout, Cin, k, dev=dev, seed=2, scale=0.2)
+    b = _rand(Cout, dev=dev, seed=3)
+    fp, bp = ops.conv_weight_pack(w)
+    y = torch.empty(Bn, L, N, Cout, device=dev)
+    ops.gemm(Bn * L * N, Cout, k * Cin, x, Cin, fp, k * Cin, y, Cout,
+             a_win=ops.win(N, L, L, 1, k, Cin, (k - 1) // 2), bias=b)
+    xs = x.permute(0, 2, 3, 1).reshape(Bn * N, Cin, L).double()
+    ref = torch.nn.functional.conv1d(xs, w.double(), b.double(), padding=(k - 1) // 2)
+    ref = ref.view(Bn, N, Cout, L).permute(0, 3, 1, 2)
+    assert _rel(y, ref) < TOL
+    # dX through the flipped pack, dW through the B-window
+    dy = _rand(Bn, L, N, Cout, dev=dev, seed=4)
+    dx = torch.empty(Bn, L, N, Cin, device=dev)
+    ops.gemm(Bn * L * N, Cin, k * Cout, dy, Cout, bp, Cin, dx, Cin, b_layout=ops.B_KN,
+             a_win=ops.win(N, L, L, 1, k, Cout, (k - 1) // 2))
+    dpack = torch.empty(Cout, k * Cin, device=dev)
+    ops.gemm(Cout, k * Cin, Bn * L * N, dy, Cout, x, Cin, dpack, k * Cin, a_layout=ops.A_KM, b_layout=ops.B_KN,
+             b_win=ops.win(N, L, L, 1, k, Cin, (k - 1) // 2), split_k=3)
+    dw = ops.conv_weight_unpack(dpack, Cout, Cin, k)
+    xs.requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    out = torch.nn.functional.conv1d(xs, wd, None, padding=(k - 1) // 2)
+    gy = dy.permute(0, 2, 3, 1).reshape(Bn * N, Cout, L).double()
+    gx, gw = torch.autograd.grad(out, (xs, wd), gy)
+    assert _rel(dx, gx.view(Bn, N, Cin, L).permute(0, 3, 1, 2)) < TOL
+    assert _rel(dw, gw) < TOL
+
+
+def test_gemm_window_stride2_and_patch_and_cwin(dev):
+    from tecmollm import ops
+    Bn, L, N, Cc, Cout = 2, 24, 5, 192, 64
+    x = _rand(Bn, L, N, Cc, dev=dev, seed=1)
+    w = _rand(Cout, Cc, dev=dev, seed=2, scale=0.1)
+    Lo = L // 2
+    y = torch.empty(Bn, Lo, N, Cout, device=dev)
+    ops.gemm(Bn * Lo * N, Cout, Cc, x, Cc, w, Cc, y, Cout, a_win=ops.win(N, L, Lo, 2, 1, Cc, 0))
+    assert _rel(y, x[:, ::2].double() @ w.double().t()) < TOL
+    # latent patching 'b (p l) d -> b p (l d)' with l = 4, and its transpose through the C window
+    D, pl, P = 128, 4, 3
+    c = _rand(Bn, P * pl, N, D, dev=dev, seed=3)
+    Wp = _rand(96, pl * D, dev=dev, seed=4, scale=0.05)
+    tok = torch.empty(Bn, P, N, 96, device=dev)
+    wv = ops.win(N, P * pl, P, pl, pl, D, 0)
+    ops.gemm(Bn * P * N, 96, pl * D, c, D, Wp, pl * D, tok, 96, a_win=wv)
+    cp = c.view(Bn, P, pl, N, D).permute(0, 1, 3, 2, 4).reshape(Bn, P, N, pl * D).double()
+    assert _rel(tok, cp @ Wp.double().t()) < TOL
+    dtok = _rand(Bn, P, N, 96, dev=dev, seed=5)
+    dc = torch.full((Bn, P * pl, N, D), float("nan"), device=dev)
+    ops.gemm(Bn * P * N, pl * D, 96, dtok, 96, Wp, pl * D, dc, D, b_layout=ops.B_KN, c_win=wv)
+    ref = (dtok.double() @ Wp.double()).view(Bn, P, N, pl, D).permute(0, 1, 3, 2, 4).reshape(Bn, P * pl, N, D)
+    assert _rel(dc, ref) < TOL
+
+
+def test_gemm_rowbias_wpe(dev):
+    from tecmollm import ops
+    Bn, P, N, D, K = 2, 3, 7, 64, 32
+    A, W = _rand(Bn * P * N, K, dev=dev, seed=1), _rand(D, K, dev=dev, seed=2)
+    wpe = _rand(10, D, dev=dev, seed=3)
+    C = torch.empty(Bn, P, N, D, device=dev)
+    ops.gemm(Bn * P * N, D, K, A, K, W, K, C, D, rowbias=(wpe, D, N, P))
+    ref = (A.double() @ W.double().t()).view(Bn, P, N, D) + wpe[:P].double().view(1, P, 1, D)
+    assert _rel(C, ref) < TOL
+
+
+def test_gemm_rejects_bad_arguments(dev):
+    from tecmollm import ops
+    from tecmollm._lib import TecmError
+    A = _rand(8, 8, dev=dev)
+    with pytest.raises(TecmError):
+        ops.gemm(0, 8, 8, A, 8, A, 8, A, 8)
+    with pytest.raises(TecmError):
+        ops.gemm(8, 8, 8, A, 8, A, 8, A, 8, a_win=ops.win(2, 2, 2, 1, 3, 5, 1))     # taps*Cw != K
+
+
+# ----------------------------------------------------------------------------- normalisation
+@pytest.mark.parametrize("M,D", [(1000, 768), (37, 256), (5, 1024)])
+def test_layernorm_fwd_bwd(dev, M, D):
+    from tecmollm import ops
+    x = _rand(M, D, dev=dev, seed=1)
+    g, b = 1 + 0.1 * _rand(D, dev=dev, seed=2), 0.1 * _rand(D, dev=dev, seed=3)
+    y = torch.empty(M, D + 32, device=dev)
+    st = torch.empty(M, 2, device=dev)
+    ops.layernorm_fwd(x, D, g, b, y, D + 32, st, M, D)
+    xd = x.double().requires_grad_(True)
+    gd, bd = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xd, (D,), gd, bd, 1e-5)
+    assert _rel(y[:, :D], ref) < TOL
+    dy, dres = _rand(M, D, dev=dev, seed=4), _rand(M, D, dev=dev, seed=5)
+    dx = torch.empty(M, D, device=dev)
+    dg, db = ops.layernorm_bwd(dy, D, x, D, g, st, dres, dx, M, D)
+    gx, gg, gb = torch.autograd.grad(ref, (xd, gd, bd), dy.double())
+    assert _rel(dx, gx + dres.double()) < TOL and _rel(dg, gg) < TOL and _rel(db, gb) < TOL
+
+
+@pytest.mark.parametrize("Bn,L,N,Cout,stride", [(2, 48, 5, 64, 2), (1, 24, 9, 128, 2), (2, 6, 3, 64, 1)])
+def test_groupnorm_gelu_fwd_bwd(dev, Bn, L, N, Cout, stride):
+    from tecmollm import ops
+    CT = 3 * Cout
+    y = _rand(Bn, L, N, CT, dev=dev, seed=1)
+    g, b = 1 + 0.1 * _rand(CT, dev=dev, seed=2), 0.1 * _rand(CT, dev=dev, seed=3)
+    act = torch.empty_like(y)
+    st = torch.empty(Bn * N, 3, 2, device=dev)
+    ops.groupnorm_gelu_fwd(y, g, b, act, st, Bn, L, N, Cout)
+    yd = y.double().requires_grad_(True)
+    gd, bd = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    ys = yd.permute(0, 2, 3, 1).reshape(Bn * N, CT, L)
+    outs = []
+    for j in range(3):
+        sl = slice(j * Cout, (j + 1) * Cout)
+        outs.append(torch.nn.functional.gelu(torch.nn.functional.group_norm(ys[:, sl], 1, gd[sl], bd[sl], 1e-5)))
+    ref = torch.cat(outs, 1).view(Bn, N, CT, L).permute(0, 3, 1, 2)
+    assert _rel(act, ref) < TOL
+    Lo = (L - 1) // stride + 1
+    dact = _rand(Bn, Lo, N, CT, dev=dev, seed=4)
+    dy = torch.empty_like(y)
+    dg, db = ops.groupnorm_gelu_bwd(dact, stride, y, g, b, st, dy, Bn, L, N, Cout)
+    full = torch.zeros(Bn, L, N, CT, dtype=torch.float64, device=dev)
+    full[:, ::stride] = dact.double()
+    gy, gg, gb = torch.autograd.grad(ref, (yd, gd, bd), full)
+    assert _rel(dy, gy) < TOL and _rel(dg, gg) < TOL and _rel(db, gb) < TOL
+
+
+def test_colsum_segments_and_dropout(dev):
+    from tecmollm import ops, rng
+    Bn, P, N, Cn = 3, 4, 50, 70
+    x = _rand(Bn * P * N, Cn, dev=dev, seed=1)
+    out = ops.colsum(x, Cn, Bn, N, P, Cn)
+    assert _rel(out, x.double().view(Bn, P, N, Cn).sum((0, 2))) < TOL
+    p, seed = 0.1, 4242
+    out = ops.colsum(x, Cn, Bn * P * N, 1, 1, Cn, in_drop=ops.drop(p, seed, Cn), scale=2.0)
+    idx = np.arange(Bn * P * N * Cn, dtype=np.uint64).reshape(-1, Cn)
+    m = torch.from_numpy(rng.keep_mult(seed, idx, p)).double()
+    assert _rel(out[0], 2.0 * (x.double().cpu() * m).sum(0)) < TOL
+
+
+# ----------------------------------------------------------------------------- attention
+def _ref_attention(qkv, Bn, T, N, H, D, keep=None):
+    q, k, v = qkv.double().view(Bn, T, N, 3, H, D // H).permute(3, 0, 2, 4, 1, 5)     # (B,N,H,T,hd)
+    w = (q @ k.transpose(-1, -2)) / math.sqrt(D // H)
+    w = w.masked_fill(~torch.tril(torch.ones(T, T, dtype=torch.bool, device=qkv.device)), float("-inf")).softmax(-1)
+    if keep is not None:
+        w = w * keep
+    return (w @ v).permute(0, 3, 1, 2, 4).reshape(Bn, T, N, D)
+
+
+@pytest.mark.parametrize("T", [1, 3, 6, 5, 21])
+def test_attention_fwd_bwd(dev, T):
+    from tecmollm import ops
+    Bn, N, H, D = 2, 7, 12, 768
+    qkv = _rand(Bn, T, N, 3 * D, dev=dev, seed=1, scale=0.5)
+    ctx = torch.empty(Bn, T, N, D, device=dev)
+    ops.attention_fwd(qkv, ctx, Bn, T, N, H, D)
+    qd = qkv.double().requires_grad_(True)
+    ref = _ref_attention(qd, Bn, T, N, H, D)
+    assert _rel(ctx, ref) < TOL
+    dctx = _rand(Bn, T, N, D, dev=dev, seed=2)
+    dqkv = torch.empty_like(qkv)
+    ops.attention_bwd(qkv, dctx, dqkv, Bn, T, N, H, D)
+    (g,) = torch.autograd.grad(ref, qd, dctx.double())
+    assert _rel(dqkv, g) < TOL
+
+
+def test_attention_dropout_mask_is_consistent(dev):
+    from tecmollm import ops, rng
+    Bn, T, N, H, D = 2, 3, 5, 12, 768
+    p, seed = 0.1, 777
+    qkv = _rand(Bn, T, N, 3 * D, dev=dev, seed=1, scale=0.5)
+    ctx = torch.empty(Bn, T, N, D, device=dev)
+    ops.attention_fwd(qkv, ctx, Bn, T, N, H, D, ops.drop(p, seed, 1))
+    idx = np.arange(Bn * N * H * T * T, dtype=np.uint64)
+    keep = torch.from_numpy(rng.keep_mult(seed, idx, p)).double().view(Bn, N, H, T, T).to(dev)
+    qd = qkv.double().requires_grad_(True)
+    ref = _ref_attention(qd, Bn, T, N, H, D, keep)
+    assert _rel(ctx, ref) < TOL
+    dctx = _rand(Bn, T, N, D, dev=dev, seed=2)
+    dqkv = torch.empty_like(qkv)
+    ops.attention_bwd(qkv, dctx, dqkv, Bn, T, N, H, D, ops.drop(p, seed, 1))
+    (g,) = torch.autograd.grad(ref, qd, dctx.double())
+    assert _rel(dqkv, g) < TOL
+
+
+# ----------------------------------------------------------------------------- small ops
+def test_huber_and_transpose(dev):
+    from tecmollm import ops
+    pred, tgt = _rand(5000, dev=dev, seed=1, scale=2.0), _rand(5000, dev=dev, seed=2)
+    loss, dp = ops.huber_fwd_bwd(pred, tgt, 1.0, 1.0)
+    pd = pred.double().requires_grad_(True)
+    ref = torch.nn.functional.huber_loss(pd, tgt.double(), delta=1.0)
+    (g,) = torch.autograd.grad(ref, pd)
+    assert abs(loss.item() - ref.item()) < 1e-5 * abs(ref.item()) + 1e-7 and _rel(dp, g) < TOL
+    src = _rand(2304, 32, dev=dev, seed=3)
+    dst = torch.zeros(40, 2304, device=dev)
+    ops.transpose_scale(src, 32, dst, 2304, 32, 2304, 2.0, dst_off=8 * 2304)
+    assert torch.equal(dst[8:], 2.0 * src.t()) and float(dst[:8].abs().max()) == 0.0

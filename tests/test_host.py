@@ -1,0 +1,213 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol declared in
+include/tecmollm.h, the graph preparation (CSR + LDS windows), the dropout-hash mirror, the module
+API mirror (parameter names / freeze rule) and the data-parallel step on 2 gloo ranks."""
+import ctypes
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import ref_cpu as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "tec-mollm_amd", "tecmollm", "libtecmollm_hip.so")
+
+
+@pytest.fixture(scope="session")
+def built_lib():
+    if not os.path.exists(LIB):
+        import __graft_entry__ as g
+        g.build()
+    return LIB
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    header = open(os.path.join(ROOT, "include", "tecmollm.h")).read()
+    declared = set(re.findall(r"\b(tecm_[a-z0-9_]+)\s*\(", header))
+    assert {"tecm_gemm_f32", "tecm_spatial_fwd", "tecm_spatial_bwd", "tecm_attention_bwd"} <= declared
+    handle = ctypes.CDLL(built_lib)
+    for name in sorted(declared):
+        assert hasattr(handle, name), f"{name} declared in tecmollm.h but not exported"
+    handle.tecm_abi_version.restype = ctypes.c_int
+    assert handle.tecm_abi_version() == 1
+    handle.tecm_last_error.restype = ctypes.c_char_p
+    assert isinstance(handle.tecm_last_error(), bytes)
+
+
+def test_binding_matches_header(built_lib):
+    from tecmollm import _lib
+    header = open(os.path.join(ROOT, "include", "tecmollm.h")).read()
+    declared = set(re.findall(r"\b(tecm_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    assert ctypes.sizeof(_lib.TecmWin) == 32 and ctypes.sizeof(_lib.TecmDrop) == 24
+    _lib.lib()                                              # loads, sets prototypes, checks the ABI version
+
+
+def test_product_path_refuses_cpu_tensors(built_lib):
+    """No CPU fallback: the model raises instead of silently computing somewhere else."""
+    from tests.parity import build_model
+    from tecmollm import TecmError
+    cfg = R.default_config(L_in=16, num_nodes=12)
+    model = build_model(cfg, R.init_params(cfg, 0), "cpu")
+    x, tf, _ = R.synthetic_batch(1, 16, 12, 6, 12)
+    ei, _ = R.grid_graph(3, 4, threshold_km=170.0)
+    with pytest.raises(TecmError):
+        model(x, tf, ei)
+
+
+def test_state_dict_keys_and_freeze_rule_match_reference_names():
+    """SURVEY.md section 8a parameter names; freeze rule modules.py:195-203; census 3 081 996 trainable."""
+    from src.model.tec_mollm import TEC_MoLLM
+    cfg = R.default_config()
+    cfg.update(load_pretrained_gpt2=False, include_wte=True)
+    model = TEC_MoLLM(cfg)
+    oracle_names = set(R.init_params(R.default_config(num_nodes=8), 0, include_wte=True))
+    assert set(model.state_dict().keys()) == oracle_names
+    for n, p in model.named_parameters():
+        assert p.requires_grad == R.is_trainable(n), n
+    assert sum(p.numel() for p in model.parameters() if p.requires_grad) == 3_081_996
+    assert model.state_dict()["llm_backbone.model.base_model.model.wte.weight"].shape == (50257, 768)
+    model.llm_backbone.model.gradient_checkpointing_enable()
+
+
+def test_graph_csr_and_windows():
+    from tecmollm import graph
+    ei, _ = R.grid_graph()
+    rowptr, col = graph.csr_by_target(ei.numpy(), 2911)
+    assert rowptr[-1] == 20924 and (np.diff(rowptr) >= 2).all() and (np.diff(rowptr) <= 10).all()
+    for i in (0, 70, 1500, 2910):
+        assert sorted(col[rowptr[i]:rowptr[i + 1]].tolist()) == sorted(ei[0][ei[1] == i].tolist())
+    lo, hi = graph.tile_windows(rowptr, col, 2911, 128)
+    assert lo.shape == (23,) and (hi - lo).max() <= 128 + 2 * 73
+    for k in range(23):
+        n0, n1 = k * 128, min(2911, (k + 1) * 128)
+        c = col[rowptr[n0]:rowptr[n1]]
+        assert lo[k] <= min(n0, c.min()) and hi[k] >= max(n1, c.max() + 1)
+    meta = graph.build(ei, 2911, torch.device("cpu"))
+    assert meta.tile_nodes == 128 and meta.max_deg == 10 and meta.num_edges == 20924
+    assert graph.lds_bytes_bwd(meta.win_max, meta.tile_nodes) <= 160 * 1024
+
+
+def test_graph_self_loops_dropped_duplicates_kept_and_bad_ids_rejected():
+    from tecmollm import graph
+    ei = np.array([[0, 1, 1, 2, 2, 3], [1, 1, 0, 1, 1, 9]])
+    with pytest.raises(ValueError):
+        graph.csr_by_target(ei, 4)
+    rowptr, col = graph.csr_by_target(ei[:, :5], 4)
+    assert rowptr.tolist() == [0, 1, 4, 4, 4] and col.tolist() == [1, 0, 2, 2]
+    far = torch.tensor([[0, 49999], [49999, 0]])
+    with pytest.raises(ValueError, match="renumber"):
+        graph.build(far, 50000, torch.device("cpu"))
+    empty = graph.build(torch.zeros(2, 0, dtype=torch.long), 10, torch.device("cpu"))
+    assert empty.num_edges == 0 and empty.max_deg == 0
+
+
+def test_rng_mirror_statistics_and_determinism():
+    from tecmollm import rng
+    idx = np.arange(1 << 18, dtype=np.uint64)
+    a = rng.keep_mult(12345, idx, 0.1)
+    assert np.array_equal(a, rng.keep_mult(12345, idx, 0.1))
+    assert abs((a == 0).mean() - 0.1) < 0.005
+    assert np.allclose(a[a != 0], 1 / 0.9)
+    b = rng.keep_mult(12346, idx, 0.1)
+    assert abs(((a == 0) & (b == 0)).mean() - 0.01) < 0.003          # independent across seeds
+    assert rng.hash24(0, np.array([0], np.uint64))[0] == 0           # splitmix64(0) finaliser of 0 is 0
+
+
+def test_clip_matches_torch_clip_grad_norm():
+    from tecmollm.train import clip_flat_, flatten_grads
+    lin = torch.nn.Linear(7, 5)
+    flat = flatten_grads(lin.parameters())
+    flat.copy_(torch.randn(flat.numel(), generator=torch.Generator().manual_seed(0)) * 3)
+    ref = [p.grad.clone() for p in lin.parameters()]
+    total = torch.nn.utils.clip_grad_norm_([torch.nn.Parameter(torch.zeros_like(g)) for g in ref], 1.0)
+    lin2 = torch.nn.Linear(7, 5)
+    for p, g in zip(lin2.parameters(), ref):
+        p.grad = g.clone()
+    tn = torch.nn.utils.clip_grad_norm_(lin2.parameters(), 1.0)
+    got = clip_flat_(flat, 1.0)
+    assert torch.allclose(got, tn) and total == 0
+    for p, q in zip(lin.parameters(), lin2.parameters()):
+        assert torch.allclose(p.grad, q.grad, rtol=1e-6, atol=1e-7)
+
+
+class _Toy(torch.nn.Module):
+    """CPU stand-in with the TEC_MoLLM call signature, for the data-parallel plumbing test."""
+
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Linear(6, 4)
+        self.b = torch.nn.Linear(4, 12)
+        self.frozen = torch.nn.Parameter(torch.ones(3), requires_grad=False)
+
+    def forward(self, x, tf, ei, ew=None):
+        h = torch.tanh(self.a(x)).mean(1)                  # (B, N, 4)
+        return self.b(h).permute(0, 2, 1).unsqueeze(-1)    # (B, 12, N, 1)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tecmollm.train import TrainStep
+        torch.manual_seed(0)
+        model = _Toy()
+        ts = TrainStep(model, world_size=world, fused_huber=False)
+        g = torch.Generator().manual_seed(100)
+        X = torch.randn(4, 5, 9, 6, generator=g)
+        Y = torch.randn(4, 12, 9, 1, generator=g)
+        sl = slice(rank * 2, rank * 2 + 2)                 # each rank takes its shard of the global batch
+        for _ in range(3):
+            ts.step(X[sl], None, None, None, Y[sl])
+        out[rank] = torch.cat([p.detach().flatten() for p in model.parameters()])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_step_two_ranks_equals_single_rank_on_global_batch():
+    """world_size=2 over gloo: one all-reduce of the flat gradient per step reproduces the single-process
+    step on the concatenated batch (mean reduction => mean of per-rank gradients)."""
+    from tecmollm.train import TrainStep
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_dp_worker, args=(2, port, out), nprocs=2, join=True)
+    assert torch.allclose(out[0], out[1], rtol=0, atol=0)          # ranks stay bit-identical
+    torch.manual_seed(0)
+    model = _Toy()
+    ts = TrainStep(model, world_size=1, fused_huber=False)
+    g = torch.Generator().manual_seed(100)
+    X = torch.randn(4, 5, 9, 6, generator=g)
+    Y = torch.randn(4, 12, 9, 1, generator=g)
+    for _ in range(3):
+        ts.step(X, None, None, None, Y)
+    single = torch.cat([p.detach().flatten() for p in model.parameters()])
+    assert torch.allclose(out[0], single, rtol=1e-5, atol=1e-6)
+
+
+def test_accumulation_fires_optimizer_on_boundary_only():
+    from tecmollm.train import TrainStep
+    torch.manual_seed(0)
+    model = _Toy()
+    ts = TrainStep(model, accumulation_steps=3, fused_huber=False)
+    before = model.a.weight.detach().clone()
+    g = torch.Generator().manual_seed(1)
+    X, Y = torch.randn(2, 5, 9, 6, generator=g), torch.randn(2, 12, 9, 1, generator=g)
+    ts.step(X, None, None, None, Y)
+    ts.step(X, None, None, None, Y)
+    assert torch.equal(model.a.weight, before) and float(ts.flat_grad.abs().sum()) > 0
+    ts.step(X, None, None, None, Y)
+    assert not torch.equal(model.a.weight, before) and float(ts.flat_grad.abs().sum()) == 0

@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Throughput of one TEC-MoLLM training step on N MI355X (BASELINE.json metric: train samples/sec on
+synthetic (B,48,2911,10) -> (B,12,2911,1) batches).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = forward + HuberLoss + backward + (RCCL mean all-reduce of the flat 12.3 MB gradient) + clip(1.0)
++ AdamW + cosine-warm-restart scheduler, training mode (every dropout site active), inputs resident in HBM.
+Weak scaling: every rank processes `--batch` (default 8) samples; value = all samples / max-over-ranks time.
+Rank 0 prints ONE JSON line carrying `roofline` (dominant kernel, measured with events on the launch
+stream inside the timed region) and, at N=1, `cpu_baseline` (the CPU oracle's train step timed on the
+host cores of this box).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tec-mollm_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact f32, dense
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="samples per GPU (BASELINE configs[1]: B=8)")
+    ap.add_argument("--L_in", type=int, default=48)
+    ap.add_argument("--L_out", type=int, default=12)
+    ap.add_argument("--c_in", type=int, default=10, help="raw feature width F (BASELINE: 10 -> d_emb 12)")
+    ap.add_argument("--gat", choices=["per_timestep", "reference"], default="per_timestep")
+    ap.add_argument("--eval-mode", action="store_true", help="dropout off (diagnostics only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def make_config(args):
+    conv_len = args.L_in // 4
+    patch_len = 4
+    if conv_len % patch_len != 0:
+        patch_len = 2 if conv_len % 2 == 0 else 1
+    return {
+        "num_nodes": 2911, "d_emb": 22 - args.c_in, "spatial_in_channels_base": args.c_in,
+        "spatial_out_channels": 11, "spatial_heads": 2, "temporal_channel_list": [64, 128],
+        "temporal_strides": [2, 2], "patch_len": patch_len, "d_llm": 768, "llm_layers": 3,
+        "prediction_horizon": args.L_out, "temporal_seq_len": args.L_in, "num_years": 13,
+    }
+
+
+def cpu_baseline(cfg, args):
+    """The CPU oracle's full train step (fwd + Huber + bwd + clip + AdamW), fp32, all host cores, one timed
+    step at B = --cpu-batch after a B=1 forward-only warm-up of the allocator/threads."""
+    from oracle import ref_cpu as R
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    params = R.init_params(cfg, seed=0)
+    p = {k: v.clone().requires_grad_(R.is_trainable(k)) for k, v in params.items()}
+    train = [v for v in p.values() if v.requires_grad]
+    opt = torch.optim.AdamW(train, lr=1e-4, weight_decay=1e-2)
+    ei, _ = R.grid_graph()
+    gwe = None if args.gat == "per_timestep" else 1
+    B = args.cpu_batch
+    with torch.no_grad():
+        xw, tfw, _ = R.synthetic_batch(1, cfg["temporal_seq_len"], 2911, cfg["spatial_in_channels_base"],
+                                       cfg["prediction_horizon"], seed=5)
+        R.forward(xw, tfw, ei, p, cfg, 1)
+    x, tf, y = R.synthetic_batch(B, cfg["temporal_seq_len"], 2911, cfg["spatial_in_channels_base"],
+                                 cfg["prediction_horizon"], seed=1234)
+    t0 = time.perf_counter()
+    out = R.forward(x, tf, ei, p, cfg, gwe)
+    loss = R.huber(out, y)
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(train, 1.0)
+    opt.step()
+    dt = time.perf_counter() - t0
+    return {"value": B / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"1 full train step (fwd+Huber+bwd+clip+AdamW) of the fp32 PyTorch-CPU oracle at B={B}, "
+                      f"L_in={cfg['temporal_seq_len']}, N=2911, gat={args.gat}, eval-mode dropout; {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs MI355X GPUs (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from src.model.tec_mollm import TEC_MoLLM
+    from tecmollm import ops
+    from tecmollm.train import TrainStep
+    from oracle.ref_cpu import grid_graph, synthetic_batch       # synthetic inputs only (no oracle compute)
+
+    cfg = make_config(args)
+    mc = dict(cfg, gat_graphs=args.gat, include_wte=False, load_pretrained_gpt2=False)
+    torch.manual_seed(0)                                           # identical weights on every rank
+    model = TEC_MoLLM(mc)
+    with torch.no_grad():                                          # exercise the LoRA path (peft inits B = 0)
+        for blk in model.llm_backbone.trunk.h:
+            blk.attn.c_attn.lora_B.default.weight.normal_(std=0.02)
+    model = model.to(dev)
+    model.train(not args.eval_mode)
+    torch.manual_seed(1234 + rank)                                 # per-rank data and dropout streams
+    B = args.batch
+    x, tf, y = synthetic_batch(B, args.L_in, 2911, args.c_in, args.L_out, seed=1234 + rank)
+    x, y = x.to(dev), y.to(dev)
+    tf = tf[:, :, 0, :].contiguous().to(dev).unsqueeze(-2).expand(B, args.L_in, 2911, 4)   # train.py:65
+    ei, ew = grid_graph()
+    ei, ew = ei.to(dev), ew.to(dev)
+    ts = TrainStep(model, world_size=world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local])
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ts.step(x, tf, ei, ew, y)
+    barrier()
+    prof = None if args.no_kernel_timing else ops.enable_gemm_timing()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = ts.step(x, tf, ei, ew, y)
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.disable_gemm_timing()
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        total = B * world * args.steps
+        roof = None
+        if prof is not None:
+            agg = ops.summarize_gemm_timing(prof)
+            if agg:
+                name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
+                achieved = a["flops"] / (a["ms"] * 1e-3) / 1e12
+                roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                        "launches": a["n"], "avg_launch_ms": round(a["ms"] / a["n"], 4),
+                        "share_of_step": round(a["ms"] / (dt * 1e3), 4),
+                        "all_gemm_share_of_step": round(sum(v["ms"] for v in agg.values()) / (dt * 1e3), 4)}
+        line = {
+            "metric": "train samples/sec", "value": round(total / dt, 3), "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: B={B}/GPU, L_in={args.L_in}, L_out={args.L_out}, N=2911, "
+                                   f"F={args.c_in} (d_emb={22 - args.c_in}), full fwd+bwd+AdamW, fp32, "
+                                   f"GATv2 {args.gat}, dropout {'off' if args.eval_mode else 'on (p=0.1)'}",
+                       "global_batch": B * world, "parallelism": f"dp{world}", "final_loss": round(float(loss), 5)},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, args)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,509 @@
+// fp32 GEMM on the exact-f32 matrix cores of gfx950 (v_mfma_f32_32x32x2_f32) -- kernel template.
+//
+//   C[M,N] = epilogue(alpha * A_view[M,K] . B_view[K,N])
+//
+// One kernel family serves every dense contraction of the TEC-MoLLM path (see include/tecmollm.h):
+// operands are addressed through "row views" so that Conv1d-over-time, the strided 1x1 conv,
+// latent patching and the head's flatten never materialise an im2col / permuted copy.
+//
+// Block = 256 threads = 4 waves, tile BM x BN x BK = 128 x {128,32} x 32.
+//   BN=128: waves 2(m) x 2(n), each wave 64x64 = 2x2 MFMA 32x32 tiles (64 accumulator VGPRs)
+//   BN= 32: waves 4(m) x 1(n), each wave 32x32
+// LDS tiles keep the operand's own orientation:
+//   [row][k] tiles (MK / NK): leading dim 36 floats -> ds_read_b128 of 4 consecutive k is
+//       conflict-free (16 lanes x 4 banks, row stride 36 = 4 mod 32 hits 16 distinct slots);
+//   [k][row] tiles (KM / KN): leading dim rows+4 -> ds_read_b32, lanes 0..31 consecutive banks.
+// The k index fed to MFMA step (q,j) by lane half h is k = 8q + 4h + j for BOTH operands, which is
+// what makes the b128 read legal (any bijection of k works as long as A and B agree).
+// Global -> register prefetch of tile t+1 is issued before the MFMAs of tile t (one LDS buffer).
+//
+// The f32 MFMA is slow enough (64 cycles per 32x32x2) that the loop is MFMA-bound only if the loader
+// costs a few dozen VALU instructions per K-tile: all per-row address state is resolved before the
+// K loop and advanced incrementally; the window view and the dropout prologue are compile-time
+// variants (WIN / DROP) so the plain variant carries none of their code.
+#pragma once
+#include "common.h"
+#include <utility>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace tecm_gemm {
+
+// compile-time loop: indices reach the body as integral constants, so register arrays indexed with
+// them can never be demoted to scratch (a plain `#pragma unroll` is only a request).
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+constexpr int BM = 128;
+constexpr int BK = 32;
+constexpr int LDK = BK + 4;
+constexpr int NTHREADS = 256;
+
+struct DropCtx {
+  uint64_t seed;
+  int64_t ld;
+  uint32_t thresh;
+  float inv;
+};
+__device__ __forceinline__ DropCtx make_drop(const TecmDrop& d) {
+  DropCtx c;
+  c.seed = d.seed;
+  c.ld = d.ld;
+  c.thresh = d.p > 0.f ? tecm_drop_thresh(d.p) : 0u;
+  c.inv = d.p > 0.f ? 1.0f / (1.0f - d.p) : 1.0f;
+  return c;
+}
+
+template <int VEC>
+__device__ __forceinline__ void gload(const float* __restrict__ p, bool ok, float (&out)[VEC]) {
+  if (ok) {
+    if constexpr (VEC == 4) {
+      const float4 v = *reinterpret_cast<const float4*>(p);
+      out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+    } else if constexpr (VEC == 2) {
+      const float2 v = *reinterpret_cast<const float2*>(p);
+      out[0] = v.x; out[1] = v.y;
+    } else {
+      out[0] = p[0];
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) out[e] = 0.f;
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void apply_drop(const DropCtx& dc, int64_t didx, float (&v)[VEC]) {
+  if (dc.thresh) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] *= tecm_drop_mult(dc.seed, (uint64_t)(didx + e), dc.thresh, dc.inv);
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void lds_store(float* dst, const float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+  } else if constexpr (VEC == 2) {
+    *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[1]);
+  } else {
+    dst[0] = v[0];
+  }
+}
+
+// 32-bit row decomposition for the window view (host guarantees rows < 2^31)
+struct WinRow {
+  int64_t srow;   // source row of tap 0
+  int32_t t0;     // t_out*stride_t - pad, TECM_ROW_INVALID if the row is out of range
+};
+__device__ __forceinline__ WinRow win_row(const TecmWin& w, int64_t m, int64_t rows) {
+  WinRow r;
+  if (m >= rows) {
+    r.srow = 0;
+    r.t0 = TECM_ROW_INVALID;
+    return r;
+  }
+  const uint32_t mm = (uint32_t)m;
+  const uint32_t q = mm / (uint32_t)w.N;
+  const int32_t n = (int32_t)(mm - q * (uint32_t)w.N);
+  const uint32_t bq = q / (uint32_t)w.Lout;
+  const int32_t t_out = (int32_t)(q - bq * (uint32_t)w.Lout);
+  r.t0 = t_out * w.stride_t - w.pad;
+  r.srow = ((int64_t)bq * w.Lin + r.t0) * (int64_t)w.N + n;
+  return r;
+}
+
+// Tile stager.  ROWK=false: tile rows are the (fixed) M/N index, inner index is k  ([row][k], LD=36)
+//               ROWK=true : tile rows are k, inner index is the (fixed) M/N index ([k][row], LD=ROWS+4)
+template <bool ROWK, int ROWS, int VEC, bool WIN, bool DROP>
+struct Stager {
+  static constexpr int R = ROWK ? BK : ROWS;
+  static constexpr int CI = ROWK ? ROWS : BK;
+  static constexpr int LD = ROWK ? ROWS + 4 : LDK;
+  static constexpr int VPR = CI / VEC;
+  static constexpr int NV = (R * VPR) / NTHREADS;
+  static constexpr int RSTEP = NTHREADS / VPR;
+  static_assert((R * VPR) % NTHREADS == 0 && NTHREADS % VPR == 0, "tile/thread mapping");
+
+  float regs[NV][VEC];
+  // --- plain view state
+  const float* ptr[NV];                   // address of this thread's vector i in the NEXT tile to load
+  uint32_t rowok;                         // bit i: fixed row i in range (ROWK=false) / unused
+  bool inner_ok;                          // ROWK=true: fixed inner index in range
+  int64_t didx[DROP ? NV : 1];            // dropout index of the vector's first element
+  // --- window view state
+  WinRow wr[(WIN && !ROWK) ? NV : 1];     // fixed rows (A-window)
+  int32_t tap, c;                         // per-thread tap / channel of the inner index (kk = tap*Cw + c)
+  int32_t kk;                             // ROWK=false: current inner index k0 + cv
+
+  __device__ __forceinline__ void init(const float* __restrict__ P, const TecmWin& w, int64_t ld, int64_t row0,
+                                       int64_t rows_total, int32_t kbeg, int64_t fixed0, int64_t fixed_lim,
+                                       const DropCtx& dc) {
+    const int cv = (threadIdx.x % VPR) * VEC;
+    const int r0 = threadIdx.x / VPR;
+    rowok = 0;
+    inner_ok = true;
+    tap = 0;
+    c = 0;
+    kk = kbeg + cv;
+    const bool wen = WIN && w.enabled;       // WIN variants still serve plain operands at run time
+    if (!wen) {
+      if constexpr (!ROWK) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const int64_t row = row0 + r0 + i * RSTEP;
+          if (row < rows_total) rowok |= 1u << i;
+          ptr[i] = P + row * ld + kbeg + cv;
+          if constexpr (DROP) didx[i] = row * dc.ld + kbeg + cv;
+        }
+      } else {
+        inner_ok = (fixed0 + cv) < fixed_lim;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const int64_t row = (int64_t)kbeg + r0 + i * RSTEP;
+          ptr[i] = P + row * ld + fixed0 + cv;
+          if constexpr (DROP) didx[i] = row * dc.ld + fixed0 + cv;
+        }
+      }
+    } else if constexpr (WIN) {
+      if constexpr (!ROWK) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) wr[i] = win_row(w, row0 + r0 + i * RSTEP, rows_total);
+        tap = kk / w.Cw;
+        c = kk - tap * w.Cw;
+      } else {
+        const int32_t inner = (int32_t)(fixed0 + cv);
+        inner_ok = inner < fixed_lim;
+        tap = inner / w.Cw;
+        c = inner - tap * w.Cw;
+      }
+    }
+  }
+
+  // Load this thread's vectors of the tile starting at k0 and advance the state to the next tile.
+  __device__ __forceinline__ void load(const float* __restrict__ P, const TecmWin& w, int64_t ld, int32_t k0,
+                                       int32_t klim, const DropCtx& dc) {
+    const int r0 = threadIdx.x / VPR;
+    const bool wen = WIN && w.enabled;
+    if (!wen) {
+      if constexpr (!ROWK) {
+        const bool kok = kk < klim;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          gload<VEC>(ptr[i], kok && ((rowok >> i) & 1u), regs[i]);
+          if constexpr (DROP) { apply_drop<VEC>(dc, didx[i], regs[i]); didx[i] += BK; }
+          ptr[i] += BK;
+        }
+        kk += BK;
+      } else {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          gload<VEC>(ptr[i], inner_ok && (k0 + r0 + i * RSTEP) < klim, regs[i]);
+          if constexpr (DROP) { apply_drop<VEC>(dc, didx[i], regs[i]); didx[i] += (int64_t)BK * dc.ld; }
+          ptr[i] += (int64_t)BK * ld;
+        }
+      }
+    } else if constexpr (WIN) {
+      if constexpr (!ROWK) {
+        const bool kok = kk < klim;
+        const int64_t tapoff = (int64_t)tap * w.N;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const int32_t t_in = wr[i].t0 + tap;            // INVALID + tap stays hugely negative
+          const bool ok = kok && t_in >= 0 && t_in < w.Lin;
+          const int64_t row = wr[i].srow + tapoff;
+          gload<VEC>(P + row * ld + c, ok, regs[i]);
+          if constexpr (DROP) apply_drop<VEC>(dc, row * dc.ld + c, regs[i]);
+        }
+        kk += BK;
+        c += BK;
+        while (c >= w.Cw) { c -= w.Cw; ++tap; }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const WinRow rr = win_row(w, (int64_t)k0 + r0 + i * RSTEP, klim);
+          const int32_t t_in = rr.t0 + tap;
+          const bool ok = inner_ok && t_in >= 0 && t_in < w.Lin;
+          const int64_t row = rr.srow + (int64_t)tap * w.N;
+          gload<VEC>(P + row * ld + c, ok, regs[i]);
+          if constexpr (DROP) apply_drop<VEC>(dc, row * dc.ld + c, regs[i]);
+        }
+      }
+    }
+  }
+
+  __device__ __forceinline__ void store(float* lds) const {
+    const int cv = (threadIdx.x % VPR) * VEC;
+    const int r0 = threadIdx.x / VPR;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) lds_store<VEC>(lds + (r0 + i * RSTEP) * LD + cv, regs[i]);
+  }
+};
+
+// ---------------------------------------------------------------------------------------- epilogue
+// Row-dependent state (offsets, window decomposition, row bias) is resolved once per accumulator row,
+// column-dependent state (bias, window tap) once per accumulator column; the per-element core is a
+// handful of instructions behind wave-uniform feature branches.
+struct EpiRow {
+  int64_t m;
+  int64_t crow;        // plain: m*ldc ; window: source row of tap 0 (srow)
+  int64_t drow;        // plain: m*drop_ld
+  int32_t t0;          // window only
+  const float* rb;     // row bias row (or nullptr)
+};
+struct EpiCol {
+  int32_t n;
+  int32_t tap, c;      // window only
+  float bias;
+  bool ok;
+};
+
+__device__ __forceinline__ EpiRow epi_row(const TecmGemm& g, const DropCtx& odc, int64_t m) {
+  EpiRow r;
+  r.m = m;
+  r.t0 = 0;
+  if (g.c_win.enabled) {
+    const WinRow w = win_row(g.c_win, m, g.M);
+    r.crow = w.srow;
+    r.t0 = w.t0;
+    r.drow = 0;
+  } else {
+    r.crow = m * g.ldc;
+    r.drow = m * odc.ld;
+  }
+  r.rb = g.rowbias ? g.rowbias + (int64_t)(((uint32_t)m / (uint32_t)g.rb_div) % (uint32_t)g.rb_mod) * g.rb_ld
+                   : nullptr;
+  return r;
+}
+__device__ __forceinline__ EpiCol epi_col(const TecmGemm& g, int64_t n) {
+  EpiCol c;
+  c.n = (int32_t)n;
+  c.ok = n < g.N;
+  c.bias = (g.bias && c.ok) ? g.bias[n] : 0.f;
+  c.tap = 0;
+  c.c = 0;
+  if (g.c_win.enabled) {
+    c.tap = c.n / g.c_win.Cw;
+    c.c = c.n - c.tap * g.c_win.Cw;
+  }
+  return c;
+}
+__device__ __forceinline__ void epi_elem(const TecmGemm& g, const DropCtx& odc, const EpiRow& r, const EpiCol& c,
+                                         float v) {
+  const int32_t n = c.n;
+  v = v * g.alpha + c.bias;
+  if (r.rb) v += r.rb[n];
+  if (g.preact) g.preact[r.m * g.ldp + n] = v;
+  if (g.dact_src)
+    v *= apply_dact(g.act, g.dact_src[r.m * g.ldd + n]);   // backward through `act`
+  else if (g.act)
+    v = apply_act(g.act, v);
+  int64_t off, didx;
+  if (g.c_win.enabled) {
+    const int32_t t_in = r.t0 + c.tap;
+    if (t_in < 0 || t_in >= g.c_win.Lin) return;
+    const int64_t row = r.crow + (int64_t)c.tap * g.c_win.N;
+    off = row * g.ldc + c.c;
+    didx = row * odc.ld + c.c;
+  } else {
+    off = r.crow + n;
+    didx = r.drow + n;
+  }
+  if (odc.thresh) v *= tecm_drop_mult(odc.seed, (uint64_t)didx, odc.thresh, odc.inv);
+  if (g.residual) v += g.residual[r.m * g.ldr + n];
+  if (g.accumulate) v += g.C[off];
+  g.C[off] = v;
+}
+// one-element form for the split-K reducer
+__device__ __forceinline__ void epilogue_store(const TecmGemm& g, const DropCtx& odc, int64_t m, int32_t n, float v) {
+  const EpiRow r = epi_row(g, odc, m);
+  const EpiCol c = epi_col(g, n);
+  epi_elem(g, odc, r, c, v);
+}
+
+template <int ALAY, int BLAY, int AVEC, int BVEC, int BN, bool WIN, bool DROP>
+__global__ __launch_bounds__(NTHREADS, (AVEC == 4 && BVEC == 4) ? 2 : 1) void gemm_kernel(const TecmGemm g,
+                                                                                           int tiles_m, int tiles_n,
+                                                                                           int k_chunk) {
+  constexpr int WN = BN >= 128 ? 2 : 1;
+  constexpr int WM = 4 / WN;
+  constexpr int WTM = BM / WM;
+  constexpr int WTN = BN / WN;
+  constexpr int MT = WTM / 32;
+  constexpr int NT = WTN / 32;
+  using AStager = Stager<ALAY == TECM_A_KM, BM, AVEC, WIN, DROP>;
+  using BStager = Stager<BLAY == TECM_B_KN, BN, BVEC, WIN, DROP>;
+  constexpr int A_FLOATS = AStager::R * AStager::LD;
+  constexpr int B_FLOATS = BStager::R * BStager::LD;
+  constexpr int STG_LD = WTN + 1;                       // epilogue staging: 32 rows x WTN cols per wave
+  static_assert(4 * 32 * STG_LD <= A_FLOATS + B_FLOATS, "epilogue staging must fit the operand tiles");
+  __shared__ __attribute__((aligned(16))) float smem[A_FLOATS + B_FLOATS];
+  float* As = smem;
+  float* Bs = smem + A_FLOATS;
+
+  // XCD-aware, bijective block -> tile map: blocks that share an XCD (id % 8) get a contiguous
+  // run of tiles, n fastest, so an A row-panel is re-read from that XCD's L2.
+  const int nwg = tiles_m * tiles_n;
+  const int id = blockIdx.x;
+  const int xcd = id & 7, local = id >> 3;
+  const int q8 = nwg >> 3, r8 = nwg & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
+  const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+  const int64_t m0 = (int64_t)tm * BM;
+  const int64_t n0 = (int64_t)tn * BN;
+  const int32_t kbeg = blockIdx.z * k_chunk;
+  const int32_t kend = min((int32_t)g.K, kbeg + k_chunk);
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 31, h = lane >> 5;
+
+  const DropCtx adc = make_drop(g.a_drop), bdc = make_drop(g.b_drop);
+
+  AStager sa;
+  BStager sb;
+  sa.init(g.A, g.a_win, g.lda, m0, g.M, kbeg, m0, g.M, adc);
+  sb.init(g.B, g.b_win, g.ldb, n0, g.N, kbeg, n0, g.N, bdc);
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  sa.load(g.A, g.a_win, g.lda, kbeg, kend, adc);
+  sb.load(g.B, g.b_win, g.ldb, kbeg, kend, bdc);
+  sa.store(As);
+  sb.store(Bs);
+  __syncthreads();
+
+  for (int32_t k0 = kbeg; k0 < kend; k0 += BK) {
+    const bool more = k0 + BK < kend;
+    if (more) {
+      sa.load(g.A, g.a_win, g.lda, k0 + BK, kend, adc);
+      sb.load(g.B, g.b_win, g.ldb, k0 + BK, kend, bdc);
+    }
+#pragma unroll
+    for (int q = 0; q < BK / 8; ++q) {
+      float af[MT][4], bf[NT][4];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int row = wm * WTM + i * 32 + r;
+        if constexpr (ALAY == TECM_A_MK) {
+          const float4 v = *reinterpret_cast<const float4*>(&As[row * LDK + 8 * q + 4 * h]);
+          af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) af[i][j] = As[(8 * q + 4 * h + j) * AStager::LD + row];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const int col = wn * WTN + i * 32 + r;
+        if constexpr (BLAY == TECM_B_NK) {
+          const float4 v = *reinterpret_cast<const float4*>(&Bs[col * LDK + 8 * q + 4 * h]);
+          bf[i][0] = v.x; bf[i][1] = v.y; bf[i][2] = v.z; bf[i][3] = v.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bf[i][j] = Bs[(8 * q + 4 * h + j) * BStager::LD + col];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int jn = 0; jn < NT; ++jn)
+            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][j], bf[jn][j], acc[i][jn], 0, 0, 0);
+    }
+    __syncthreads();
+    if (more) {
+      sa.store(As);
+      sb.store(Bs);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
+  // Each wave parks one 32-row slab of its accumulators in LDS (the operand tiles are dead by now) and
+  // walks it row by row: a row is wave-uniform (its offsets / window decomposition are scalar work),
+  // a lane keeps one column, and the global stores are whole contiguous row segments.
+  const DropCtx odc = make_drop(g.out_drop);
+  const bool split = gridDim.z > 1;
+  float* stg = smem + wave * (32 * STG_LD);
+  constexpr int ROWS_PER_IT = 64 / WTN;                  // 1 (WTN = 64) or 2 (WTN = 32)
+  const int lcol = lane % WTN, lrow = lane / WTN;
+  const EpiCol ecol = epi_col(g, n0 + wn * WTN + lcol);
+  static_for<MT>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    __syncthreads();                                     // previous slab consumed / MFMA loop's LDS reads done
+    static_for<16>([&](auto ec) {
+      constexpr int e = decltype(ec)::value;
+      static_for<NT>([&](auto jc) {
+        constexpr int jn = decltype(jc)::value;
+        stg[((e & 3) + 8 * (e >> 2) + 4 * h) * STG_LD + jn * 32 + r] = acc[i][jn][e];
+      });
+    });
+    __syncthreads();
+#pragma unroll 2
+    for (int it = 0; it < 32 / ROWS_PER_IT; ++it) {
+      const int rl = it * ROWS_PER_IT + lrow;
+      const int64_t m = m0 + wm * WTM + i * 32 + rl;
+      if (m < g.M && ecol.ok) {
+        const float v = stg[rl * STG_LD + lcol];
+        if (split) {
+          g.workspace[((int64_t)blockIdx.z * g.M + m) * g.N + ecol.n] = v;
+        } else {
+          const EpiRow er = epi_row(g, odc, m);
+          epi_elem(g, odc, er, ecol, v);
+        }
+      }
+    }
+  });
+}
+
+template <int ALAY, int BLAY, int AVEC, int BVEC, int BN, bool WIN, bool DROP>
+int launch(const TecmGemm& g, hipStream_t st) {
+  const int tiles_m = (int)((g.M + BM - 1) / BM);
+  const int tiles_n = (int)((g.N + BN - 1) / BN);
+  int splits = g.split_k > 1 ? g.split_k : 1;
+  int k_chunk = (int)(((g.K + splits - 1) / splits + BK - 1) / BK) * BK;
+  splits = (int)((g.K + k_chunk - 1) / k_chunk);
+  dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)splits);
+  hipLaunchKernelGGL((gemm_kernel<ALAY, BLAY, AVEC, BVEC, BN, WIN, DROP>), grid, dim3(NTHREADS), 0, st, g, tiles_m,
+                     tiles_n, k_chunk);
+  TECM_CHECK_LAUNCH("tecm_gemm_f32");
+  return splits;      // > 0: number of K splits actually launched
+}
+
+// (4,4) vectors: all four WIN/DROP variants; narrower vectors: the general (WIN, DROP) variant only.
+template <int ALAY, int BLAY, int BN>
+int dispatch(const TecmGemm& g, int avec, int bvec, bool win, bool drop, hipStream_t st) {
+  if (avec == 4 && bvec == 4) {
+    if (!win && !drop) return launch<ALAY, BLAY, 4, 4, BN, false, false>(g, st);
+    if (win && !drop) return launch<ALAY, BLAY, 4, 4, BN, true, false>(g, st);
+    if (!win && drop) return launch<ALAY, BLAY, 4, 4, BN, false, true>(g, st);
+    return launch<ALAY, BLAY, 4, 4, BN, true, true>(g, st);
+  }
+  if constexpr (ALAY == TECM_A_MK) {
+    if (avec >= 2) return launch<ALAY, BLAY, 2, 1, BN, true, true>(g, st);
+  } else {
+    if (avec == 4 && bvec >= 2) return launch<ALAY, BLAY, 4, 2, BN, true, true>(g, st);
+  }
+  return launch<ALAY, BLAY, 1, 1, BN, true, true>(g, st);
+}
+
+}  // namespace tecm_gemm
+
+// one translation unit per layout pair (parallel compilation)
+int tecm_gemm_dispatch_mk_nk(const TecmGemm& g, int avec, int bvec, bool win, bool drop, hipStream_t st);
+int tecm_gemm_dispatch_mk_kn(const TecmGemm& g, int avec, int bvec, bool win, bool drop, hipStream_t st);
+int tecm_gemm_dispatch_km_kn(const TecmGemm& g, int avec, int bvec, bool win, bool drop, hipStream_t st);

@@ -82,7 +82,69 @@ def gemm(M: int, N: int, K: int, A: torch.Tensor, lda: int, B: torch.Tensor, ldb
         g.split_k, g.workspace = split_k, ws.data_ptr()
     else:
         g.split_k = 1
+    if _timing is None:
+        check(lib().tecm_gemm_f32(C.byref(g), stream_ptr()), "tecm_gemm_f32")
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     check(lib().tecm_gemm_f32(C.byref(g), stream_ptr()), "tecm_gemm_f32")
+    e1.record()
+    _timing.append((_kernel_name(g), 2.0 * M * N * K, e0, e1))
+
+
+# ------------------------------------------------------------------ per-launch timing (bench.py roofline)
+_timing = None
+
+
+def _vec(p: int, ld: int, w: TecmWin, inner_is_k: bool, K: int) -> int:
+    v = 4
+    while v > 1:
+        ok = p % (4 * v) == 0 and ld % v == 0
+        if w.enabled:
+            ok = ok and w.Cw % v == 0
+        if inner_is_k:
+            ok = ok and K % v == 0
+        if ok:
+            break
+        v >>= 1
+    return v
+
+
+def _kernel_name(g: TecmGemm) -> str:
+    """Name of the template instance csrc/gemm.hip dispatches to (mirrors pick_vec / dispatch_vec)."""
+    av = _vec(g.A, g.lda, g.a_win, g.a_layout == A_MK, g.K)
+    bv = _vec(g.B, g.ldb, g.b_win, g.b_layout == B_NK, g.K)
+    if av == 4 and bv == 4:
+        pair = (4, 4)
+    elif g.a_layout == A_MK:
+        pair = (2, 1) if av >= 2 else (1, 1)
+    else:
+        pair = (4, 2) if (av == 4 and bv >= 2) else (1, 1)
+    bn = 32 if g.N <= 32 else 128
+    return f"gemm_kernel<{g.a_layout},{g.b_layout},{pair[0]},{pair[1]},{bn}>"
+
+
+def enable_gemm_timing() -> list:
+    """Bracket every GEMM launch with events on the launch stream (torch's current stream)."""
+    global _timing
+    _timing = []
+    return _timing
+
+
+def disable_gemm_timing() -> None:
+    global _timing
+    _timing = None
+
+
+def summarize_gemm_timing(records: list) -> dict:
+    torch.cuda.synchronize()
+    agg: dict = {}
+    for name, flops, e0, e1 in records:
+        a = agg.setdefault(name, {"ms": 0.0, "flops": 0.0, "n": 0})
+        a["ms"] += e0.elapsed_time(e1)
+        a["flops"] += flops
+        a["n"] += 1
+    return agg
 
 
 def pick_split_k(Mo: int, No: int, K: int, target_blocks: int = 768, min_chunk: int = 512) -> int:

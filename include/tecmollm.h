@@ -150,11 +150,15 @@ int tecm_groupnorm_gelu_bwd(const float* dact, int32_t dstride, const float* y, 
 int tecm_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y,
                        int64_t ldy, float* stats /* (M,2) mean,rstd */, int64_t M, int32_t D, float eps,
                        void* stream);
-/* dx = dres (optional) + LN'(dy); then dropout(out_drop) on dx (the embd dropout of GPT2Model.drop
- * sits in front of layer 0's residual stream).  dgb_partials (num_blocks, 2*D). */
+/* dx = dres (optional) + LN'(dy).  Optional second output dx_masked = dropout(dx, mask_drop): the
+ * residual-stream gradient is consumed twice in GPT2Block's backward, once as is (residual path) and
+ * once through the resid dropout in front of a GEMM; emitting the masked copy here costs one extra
+ * store instead of one hash per element per GEMM column tile.  dgb_partials (num_blocks, 2*D);
+ * dx == NULL only queries *num_blocks. */
 int tecm_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
-                       const float* stats, const float* dres, float* dx, const TecmDrop* out_drop,
-                       float* dgb_partials, int32_t* num_blocks, int64_t M, int32_t D, void* stream);
+                       const float* stats, const float* dres, float* dx, float* dx_masked,
+                       const TecmDrop* mask_drop, float* dgb_partials, int32_t* num_blocks, int64_t M, int32_t D,
+                       void* stream);
 
 /* Causal multi-head self-attention over T tokens per sequence (GPT2Attention, modeling_gpt2.py:54-73,
  * :144-226; all-ones attention_mask tec_mollm.py:111 => pure causal).  qkv: (B,T,N,3*D) time-major

@@ -56,14 +56,19 @@ __device__ __forceinline__ float dgelu_erf(float x) {
   const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
   return cdf + x * pdf;
 }
+// tanh(u) = 1 - 2/(1 + e^{2u}) on the hardware exp/rcp units (abs error ~1e-7 .. 1e-6, saturates cleanly)
+__device__ __forceinline__ float fast_tanh(float u) {
+  const float e = __expf(2.0f * u);
+  return 1.0f - __fdividef(2.0f, 1.0f + e);
+}
 __device__ __forceinline__ float gelu_tanh(float x) {
   const float u = 0.79788456080286535588f * (x + 0.044715f * x * x * x);
-  return 0.5f * x * (1.0f + tanhf(u));
+  return 0.5f * x * (1.0f + fast_tanh(u));
 }
 __device__ __forceinline__ float dgelu_tanh(float x) {
   const float x2 = x * x;
   const float u = 0.79788456080286535588f * (x + 0.044715f * x * x2);
-  const float t = tanhf(u);
+  const float t = fast_tanh(u);
   const float du = 0.79788456080286535588f * (1.0f + 3.0f * 0.044715f * x2);
   return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * du;
 }

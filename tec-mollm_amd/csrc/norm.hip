@@ -83,8 +83,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ stats,
                                                             const float* __restrict__ dres, float* __restrict__ dx,
-                                                            DropCtxN odc, float* __restrict__ partials, int64_t M,
-                                                            int D) {
+                                                            float* __restrict__ dxm, DropCtxN odc,
+                                                            float* __restrict__ partials, int64_t M, int D) {
   __shared__ float red[4][2 * 4 * 64 * NCH];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float4 dg[NCH], db[NCH], gm[NCH];
@@ -129,12 +129,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
           const float4 r = *reinterpret_cast<const float4*>(dres + row * (int64_t)D + c);
           o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
         }
-        if (odc.thresh) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            o[e] *= tecm_drop_mult(odc.seed, (uint64_t)(row * odc.ld + c + e), odc.thresh, odc.inv);
-        }
         *reinterpret_cast<float4*>(dx + row * (int64_t)D + c) = make_float4(o[0], o[1], o[2], o[3]);
+        if (dxm) {          // second output: dropout(dx) for the GEMM that consumes the masked gradient
+          if (odc.thresh) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              o[e] *= tecm_drop_mult(odc.seed, (uint64_t)(row * odc.ld + c + e), odc.thresh, odc.inv);
+          }
+          *reinterpret_cast<float4*>(dxm + row * (int64_t)D + c) = make_float4(o[0], o[1], o[2], o[3]);
+        }
       }
     }
   }
@@ -336,14 +339,19 @@ __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ i
 __global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ ws, int RB, int nseg, int C,
                                                      float* __restrict__ out, int64_t ldo, int accumulate,
                                                      float scale) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= nseg * C) return;
-  const int s = i / C, c = i - s * C;
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane, s = blockIdx.y;
   float acc = 0.f;
-  for (int rb = 0; rb < RB; ++rb) acc += ws[((int64_t)s * RB + rb) * C + c];
-  acc *= scale;
-  float* o = out + (int64_t)s * ldo + c;
-  *o = accumulate ? *o + acc : acc;
+  if (c < C)
+    for (int rb = wave; rb < RB; rb += 4) acc += ws[((int64_t)s * RB + rb) * C + c];
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && c < C) {
+    const float v = ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) * scale;
+    float* o = out + (int64_t)s * ldo + c;
+    *o = accumulate ? *o + v : v;
+  }
 }
 
 int ln_blocks(int64_t M) {
@@ -382,22 +390,24 @@ extern "C" int tecm_layernorm_fwd(const float* x, int64_t ldx, const float* gamm
 }
 
 extern "C" int tecm_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
-                                  const float* stats, const float* dres, float* dx, const TecmDrop* out_drop,
-                                  float* dgb_partials, int32_t* num_blocks, int64_t M, int32_t D, void* stream) {
+                                  const float* stats, const float* dres, float* dx, float* dx_masked,
+                                  const TecmDrop* mask_drop, float* dgb_partials, int32_t* num_blocks, int64_t M,
+                                  int32_t D, void* stream) {
   TECM_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAXCH, TECM_E_ARG, "tecm_layernorm_bwd: bad M/D");
   const int nb = ln_blocks(M);
   if (num_blocks) *num_blocks = nb;
   if (dx == nullptr) return TECM_OK;   // query mode
   TECM_REQUIRE(dy && x && gamma && stats && dgb_partials, TECM_E_ARG, "tecm_layernorm_bwd: null pointer");
   TECM_REQUIRE(lddy % 4 == 0 && ldx % 4 == 0 && tecm_aligned(dy, 16) && tecm_aligned(x, 16) &&
-                   tecm_aligned(dx, 16) && (!dres || tecm_aligned(dres, 16)),
+                   tecm_aligned(dx, 16) && (!dres || tecm_aligned(dres, 16)) &&
+                   (!dx_masked || tecm_aligned(dx_masked, 16)),
                TECM_E_ALIGN, "tecm_layernorm_bwd: 16-byte alignment required");
-  const DropCtxN odc = make_dropn(out_drop);
+  const DropCtxN odc = make_dropn(mask_drop);
   const int nch = (D + 255) / 256;
   hipStream_t st = (hipStream_t)stream;
 #define LN_BWD(NCH)                                                                                              \
   hipLaunchKernelGGL((layernorm_bwd_kernel<NCH>), dim3(nb), dim3(256), 0, st, dy, lddy, x, ldx, gamma, stats, dres, \
-                     dx, odc, dgb_partials, M, D)
+                     dx, dx_masked, odc, dgb_partials, M, D)
   switch (nch) {
     case 1: LN_BWD(1); break;
     case 2: LN_BWD(2); break;
@@ -473,8 +483,8 @@ extern "C" int tecm_colsum(const float* in, int64_t ld, int64_t outer, int64_t i
   hipLaunchKernelGGL(colsum_stage1, dim3(colblocks, (unsigned)rb, nseg), dim3(256), 0, st, in, ld, outer, inner, nseg,
                      C, idc, workspace, chunk);
   TECM_CHECK_LAUNCH("tecm_colsum/stage1");
-  hipLaunchKernelGGL(colsum_stage2, dim3((nseg * C + 255) / 256), dim3(256), 0, st, workspace, (int)rb, nseg, C, out,
-                     ldo, accumulate, scale);
+  hipLaunchKernelGGL(colsum_stage2, dim3(colblocks, nseg), dim3(256), 0, st, workspace, (int)rb, nseg, C, out, ldo,
+                     accumulate, scale);
   TECM_CHECK_LAUNCH("tecm_colsum/stage2");
   return TECM_OK;
 }

@@ -325,7 +325,11 @@ class GPT2StackFn(torch.autograd.Function):
         dout = dout.contiguous()
         lnfw = params[n_layers * GPT2StackFn.PER_LAYER]
         dh = _empty(M, D, like=dout)
-        dlnfw, dlnfb = ops.layernorm_bwd(dout, D, h_last, D, lnfw, stf, None, dh, M, D)
+        # every LayerNorm backward also emits dropout(dx) for the GEMM that sits behind the next resid dropout
+        sp = plan.spec(site_res2(n_layers - 1), D)
+        dhm = _empty(M, D, like=dout) if sp is not None else dh
+        dlnfw, dlnfb = ops.layernorm_bwd(dout, D, h_last, D, lnfw, stf, None, dh, M, D,
+                                         dx_masked=dhm if sp is not None else None, mask_drop=sp)
         pgrads: List[Optional[torch.Tensor]] = [None] * (n_layers * GPT2StackFn.PER_LAYER)
         for i in reversed(range(n_layers)):
             (ln1w, ln1b, Wqkv, bqkv, lA, lB, Wo, bo, ln2w, ln2b, Wfc, bfc, Wpr,
@@ -334,16 +338,18 @@ class GPT2StackFn(torch.autograd.Function):
             F3, F4 = Wqkv.shape[1], Wfc.shape[1]
             # MLP:  h3 = h2 + drop(gelu(u2 Wfc + b) Wpr + b)
             da = _empty(M, F4, like=dh)
-            gemm(M, F4, D, dh, D, Wpr, D, da, F4, a_drop=plan.spec(site_res2(i), D), act=ACT_GELU_TANH,
-                 dact_src=(a, F4))
+            gemm(M, F4, D, dhm, D, Wpr, D, da, F4, act=ACT_GELU_TANH, dact_src=(a, F4))
             du2 = _empty(M, D, like=dh)
             gemm(M, D, F4, da, F4, Wfc, F4, du2, D)
             del da
             dh2 = _empty(M, D, like=dh)
-            dg2, db2 = ops.layernorm_bwd(du2, D, h2, D, ln2w, st2, dh, dh2, M, D)
+            sp = plan.spec(site_res1(i), D)
+            dh2m = dhm if sp is not None else dh2             # dhm is dead once da has been formed
+            dg2, db2 = ops.layernorm_bwd(du2, D, h2, D, ln2w, st2, dh, dh2, M, D,
+                                         dx_masked=dh2m if sp is not None else None, mask_drop=sp)
             # attention: h2 = h + drop(ctx Wo + b)
             dcx = du2                                         # reuse buffer
-            gemm(M, D, D, dh2, D, Wo, D, dcx, D, a_drop=plan.spec(site_res1(i), D))
+            gemm(M, D, D, dh2m, D, Wo, D, dcx, D)
             dqkv = _empty(M, F3, like=dh)
             ops.attention_bwd(qkv, dcx, dqkv, B, T, N, GPT_HEADS, D, plan.spec(site_attn(i), 1))
             du = _empty(M, KE, like=dh)                       # [ d LN1-out (base path) | dz ]
@@ -358,7 +364,10 @@ class GPT2StackFn(torch.autograd.Function):
             # LoRA path back to LN1's output: du[:, :D] += mask * (dz A)
             gemm(M, D, LORA_R, du, KE, lA, D, du, KE, b_layout=B_KN, a_off=D, out_drop=lspec, accumulate=True)
             dhn = _empty(M, D, like=dh)
-            dg1, db1 = ops.layernorm_bwd(du, KE, h, D, ln1w, st1, dh2, dhn, M, D)
+            sp = plan.spec(site_res2(i - 1), D) if i > 0 else None
+            dhm = _empty(M, D, like=dh) if sp is not None else dhn
+            dg1, db1 = ops.layernorm_bwd(du, KE, h, D, ln1w, st1, dh2, dhn, M, D,
+                                         dx_masked=dhm if sp is not None else None, mask_drop=sp)
             dh = dhn
             base = i * GPT2StackFn.PER_LAYER
             pgrads[base + 0], pgrads[base + 1] = dg1, db1

@@ -163,22 +163,23 @@ def layernorm_fwd(x: torch.Tensor, ldx: int, gamma: torch.Tensor, beta: torch.Te
 
 def layernorm_bwd_blocks(M: int, D: int) -> int:
     nb = C.c_int32(0)
-    check(lib().tecm_layernorm_bwd(None, 0, None, 0, None, None, None, None, None, None, C.byref(nb), M, D, None),
-          "tecm_layernorm_bwd(query)")
+    check(lib().tecm_layernorm_bwd(None, 0, None, 0, None, None, None, None, None, None, None, C.byref(nb), M, D,
+                                   None), "tecm_layernorm_bwd(query)")
     return nb.value
 
 
 def layernorm_bwd(dy: torch.Tensor, lddy: int, x: torch.Tensor, ldx: int, gamma: torch.Tensor, stats: torch.Tensor,
                   dres: Optional[torch.Tensor], dx: torch.Tensor, M: int, D: int,
-                  out_drop: Optional[TecmDrop] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Returns (dgamma, dbeta)."""
+                  dx_masked: Optional[torch.Tensor] = None,
+                  mask_drop: Optional[TecmDrop] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """dx = dres + LN'(dy); optional dx_masked = dropout(dx, mask_drop).  Returns (dgamma, dbeta)."""
     nb = layernorm_bwd_blocks(M, D)
     partials = torch.empty(nb, 2 * D, device=dx.device, dtype=torch.float32)
     nbc = C.c_int32(0)
-    od = out_drop if out_drop is not None else NO_DROP
+    od = mask_drop if mask_drop is not None else NO_DROP
     check(lib().tecm_layernorm_bwd(dy.data_ptr(), lddy, x.data_ptr(), ldx, gamma.data_ptr(), stats.data_ptr(),
-                                   ptr(dres), dx.data_ptr(), C.byref(od), partials.data_ptr(), C.byref(nbc), M, D,
-                                   stream_ptr()), "tecm_layernorm_bwd")
+                                   ptr(dres), dx.data_ptr(), ptr(dx_masked), C.byref(od), partials.data_ptr(),
+                                   C.byref(nbc), M, D, stream_ptr()), "tecm_layernorm_bwd")
     dgb = colsum(partials, 2 * D, nb, 1, 1, 2 * D)
     return dgb[0, :D], dgb[0, D:]
 

@@ -218,6 +218,12 @@ def test_layernorm_fwd_bwd(dev, M, D):
     dg, db = ops.layernorm_bwd(dy, D, x, D, g, st, dres, dx, M, D)
     gx, gg, gb = torch.autograd.grad(ref, (xd, gd, bd), dy.double())
     assert _rel(dx, gx + dres.double()) < TOL and _rel(dg, gg) < TOL and _rel(db, gb) < TOL
+    # second output: dropout(dx) with the device hash (consumed by the GEMM behind the resid dropout)
+    from tecmollm import rng
+    dx2, dxm = torch.empty(M, D, device=dev), torch.empty(M, D, device=dev)
+    ops.layernorm_bwd(dy, D, x, D, g, st, dres, dx2, M, D, dx_masked=dxm, mask_drop=ops.drop(0.1, 99, D))
+    mult = torch.from_numpy(rng.keep_mult(99, np.arange(M * D, dtype=np.uint64).reshape(M, D), 0.1)).to(dev)
+    assert torch.equal(dx2, dx) and torch.equal(dxm, dx * mult)
 
 
 @pytest.mark.parametrize("Bn,L,N,Cout,stride", [(2, 48, 5, 64, 2), (1, 24, 9, 128, 2), (2, 6, 3, 64, 1)])

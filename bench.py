@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--gat", choices=["per_timestep", "reference"], default="per_timestep")
     ap.add_argument("--eval-mode", action="store_true", help="dropout off (diagnostics only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=1)
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
 
@@ -64,10 +64,11 @@ def make_config(args):
 
 
 def cpu_baseline(cfg, args):
-    """The CPU oracle's full train step (fwd + Huber + bwd + clip + AdamW), fp32, all host cores, one timed
-    step at B = --cpu-batch after a B=1 forward-only warm-up of the allocator/threads."""
+    """The CPU oracle's full train step (fwd + Huber + bwd + clip + AdamW), fp32, on the host cores this
+    process may use, one timed step at B = --cpu-batch after a forward-only warm-up of allocator/threads."""
     from oracle import ref_cpu as R
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, int(os.environ.get("TECM_CPU_THREADS", cores)))
     torch.set_num_threads(cores)
     params = R.init_params(cfg, seed=0)
     p = {k: v.clone().requires_grad_(R.is_trainable(k)) for k, v in params.items()}

@@ -7,21 +7,29 @@
 //
 // A block owns one graph (b,t) and a tile of `tile_nodes` target nodes.  The host computes, from the
 // CSR-by-target of the graph, the window [lo,hi) of node ids that covers the tile and all of its
-// sources; x_l = lin_l(h) for the whole window is staged in LDS (neighbour features), the per-node
-// attention logits / online softmax live in registers, lin_l / lin_r weights arrive through the scalar
-// cache (wave-uniform addresses -> s_load), and the output tile goes back through LDS so the global
-// store is contiguous float4.  Graphs with g = t*B + b >= graphs_with_edges see only their self loop
-// (the reference's literal behaviour for everything but graph 0).
+// sources; x_l = lin_l(h) for the whole window is staged in LDS (neighbour features), lin_l / lin_r
+// live in LDS as 24-float rows read with broadcast ds_read_b128, the attention vector sits in
+// registers, the per-node logits / online softmax live in registers, and the output tile goes back
+// through LDS so the global store is contiguous float4.  Graphs with g = t*B + b >= graphs_with_edges
+// see only their self loop (the reference's literal behaviour for everything but graph 0).
 //
 // Backward recomputes the forward from x (no activations are saved) and reduces straight to parameter
 // gradients; x needs no gradient.  By linearity every edge's contribution to d x_l[j] is folded into
-// LDS accumulators of the block that owns the *target*, so no cross-block scatter of dx_l is needed:
-// only the (N, Demb) node table sees float atomics (256-byte contiguous per wave instruction).
+// LDS accumulators of the block that owns the *target*, so no cross-block scatter of dx_l is needed.
+// The 22x22 weight gradients are outer products sum_rows dxl^T [h,1]: they run on the f32 matrix cores
+// (one 32x32 accumulator per wave, kept in registers across the block's timesteps); only the (N, Demb)
+// node table sees float atomics (contiguous 256 B per wave instruction).
 #include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
 constexpr float NEG_SLOPE = 0.2f;
+constexpr int C = 22;      // feature channels (Cin + Demb)
+constexpr int H = 2;       // heads
+constexpr int CH = C / H;
+constexpr int CP = 24;     // padded row: 16-byte aligned, column 22 carries the constant 1 of the bias trick
 
 __device__ __forceinline__ int clampi(int v, int hi) { return v < 0 ? 0 : (v >= hi ? hi - 1 : v); }
 
@@ -45,7 +53,6 @@ __device__ __forceinline__ float temporal_emb(const TecmSpatial& d, const TimeId
 }
 
 // h = cat([x, node_emb + temporal_emb])  (modules.py:261-264)
-template <int C>
 __device__ __forceinline__ void build_h(const TecmSpatial& d, const float* xrow, int node, const float* temb_lds,
                                         int b, int t, float (&h)[C]) {
   TimeIdx ti;
@@ -62,25 +69,86 @@ __device__ __forceinline__ void build_h(const TecmSpatial& d, const float* xrow,
   }
 }
 
-// out = W h + b with W (C,C) row-major: wave-uniform addresses, so the compiler feeds the FMAs from SGPRs
-template <int C>
-__device__ __forceinline__ void dense(const float* __restrict__ W, const float* __restrict__ bias,
-                                      const float (&h)[C], float (&out)[C]) {
+// Weights staged once per block.  W*_s rows are padded to CP floats (cols 22,23 = 0) so a row is six
+// broadcast ds_read_b128.
+struct WeightsLds {
+  float* Wl;    // [C][CP]
+  float* Wr;    // [C][CP]
+  float* bl;    // [CP]
+  float* br;    // [CP]
+  float* bias;  // [CP]
+};
+constexpr int WEIGHT_FLOATS = 2 * C * CP + 3 * CP;
+
+__device__ __forceinline__ WeightsLds stage_weights(const TecmSpatial& d, float* base) {
+  WeightsLds w;
+  w.Wl = base;
+  w.Wr = w.Wl + C * CP;
+  w.bl = w.Wr + C * CP;
+  w.br = w.bl + CP;
+  w.bias = w.br + CP;
+  for (int i = threadIdx.x; i < C * CP; i += blockDim.x) {
+    const int r = i / CP, k = i - r * CP;
+    w.Wl[i] = k < C ? d.Wl[r * C + k] : 0.f;
+    w.Wr[i] = k < C ? d.Wr[r * C + k] : 0.f;
+  }
+  if (threadIdx.x < CP) {
+    const int k = threadIdx.x;
+    w.bl[k] = k < C ? d.bl[k] : 0.f;
+    w.br[k] = k < C ? d.br[k] : 0.f;
+    w.bias[k] = k < C ? d.bias[k] : 0.f;
+  }
+  return w;
+}
+
+// out = W h + b, W rows in LDS (wave-uniform addresses -> broadcast reads)
+__device__ __forceinline__ void dense_lds(const float* Ws, const float* bs, const float (&h)[C], float (&out)[C]) {
 #pragma unroll
   for (int c = 0; c < C; ++c) {
-    float a = bias[c];
+    const float4* wr = reinterpret_cast<const float4*>(Ws + c * CP);
+    float a = bs[c];
 #pragma unroll
-    for (int k = 0; k < C; ++k) a = fmaf(W[c * C + k], h[k], a);
+    for (int q = 0; q < CP / 4; ++q) {
+      const float4 w4 = wr[q];
+      a = fmaf(w4.x, h[4 * q], a);
+      a = fmaf(w4.y, h[4 * q + 1], a);
+      if (4 * q + 2 < C) a = fmaf(w4.z, h[4 * q + 2], a);
+      if (4 * q + 3 < C) a = fmaf(w4.w, h[4 * q + 3], a);
+    }
     out[c] = a;
+    // keep the scheduler from hoisting all 132 broadcast loads of the 22 rows at once (register blow-up)
+    if (c & 1) __builtin_amdgcn_sched_barrier(0);
   }
 }
 
 __device__ __forceinline__ float lrelu(float s) { return s > 0.f ? s : NEG_SLOPE * s; }
 
-template <int C, int H>
-__device__ __forceinline__ void logits(const float* xlj, const float (&xr)[C], const float* __restrict__ att,
+__device__ __forceinline__ void load_row(const float* row, float (&v)[C]) {
+  const float4* p = reinterpret_cast<const float4*>(row);
+#pragma unroll
+  for (int q = 0; q < CP / 4; ++q) {
+    const float4 t = p[q];
+    v[4 * q] = t.x;
+    v[4 * q + 1] = t.y;
+    if (4 * q + 2 < C) v[4 * q + 2] = t.z;
+    if (4 * q + 3 < C) v[4 * q + 3] = t.w;
+  }
+}
+__device__ __forceinline__ void store_row(float* row, const float (&v)[C], float c22, float c23) {
+  float4* p = reinterpret_cast<float4*>(row);
+#pragma unroll
+  for (int q = 0; q < CP / 4; ++q) {
+    float4 t;
+    t.x = v[4 * q];
+    t.y = v[4 * q + 1];
+    t.z = 4 * q + 2 < C ? v[4 * q + 2] : c22;
+    t.w = 4 * q + 3 < C ? v[4 * q + 3] : c23;
+    p[q] = t;
+  }
+}
+
+__device__ __forceinline__ void logits(const float (&xlj)[C], const float (&xr)[C], const float (&att)[C],
                                        float (&e)[H]) {
-  constexpr int CH = C / H;
 #pragma unroll
   for (int hh = 0; hh < H; ++hh) {
     float a = 0.f;
@@ -90,9 +158,8 @@ __device__ __forceinline__ void logits(const float* xlj, const float (&xr)[C], c
   }
 }
 
-template <int C, int H>
-__global__ __launch_bounds__(256) void spatial_fwd_kernel(const TecmSpatial d, int Cp) {
-  constexpr int CH = C / H;
+// ------------------------------------------------------------------------------------------ forward
+__global__ __launch_bounds__(256) void spatial_fwd_kernel(const TecmSpatial d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
   const int tile = blockIdx.x;
@@ -104,13 +171,14 @@ __global__ __launch_bounds__(256) void spatial_fwd_kernel(const TecmSpatial d, i
   const int hi = use_edges ? d.tile_hi[tile] : n1;
   const int W = hi - lo;
   const int wm4 = (d.win_max + 3) & ~3;
-  float* xin = smem;
-  float* xlw = xin + wm4 * d.Cin;
-  float* outt = xlw + wm4 * C;
-  float* temb = outt + d.tile_nodes * Cp;
+  float* xin = smem;                                   // [wm4][Cin]
+  float* xlw = xin + ((wm4 * d.Cin + 3) & ~3);         // [wm4][CP]
+  float* outt = xlw + wm4 * CP;                        // [tile_nodes][CP]
+  float* temb = outt + d.tile_nodes * CP;              // [32]
+  const WeightsLds ws = stage_weights(d, temb + 32);
   const bool tf_uniform = d.tf_sn == 0;
 
-  const int64_t grow = ((int64_t)b * d.L + t) * d.N;          // first row of this graph
+  const int64_t grow = ((int64_t)b * d.L + t) * d.N;   // first row of this graph
   {
     const float* src = d.x + (grow + lo) * d.Cin;
     for (int i = tid; i < W * d.Cin; i += 256) xin[i] = src[i];
@@ -119,16 +187,18 @@ __global__ __launch_bounds__(256) void spatial_fwd_kernel(const TecmSpatial d, i
     const TimeIdx ti = load_time_idx(d, b, t, 0);
     temb[tid] = temporal_emb(d, ti, tid);
   }
+  float att[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) att[c] = d.att[c];
   __syncthreads();
   const float* temb_p = tf_uniform ? temb : nullptr;
 
   if (use_edges) {
     for (int w = tid; w < W; w += 256) {
       float h[C], xl[C];
-      build_h<C>(d, xin + w * d.Cin, lo + w, temb_p, b, t, h);
-      dense<C>(d.Wl, d.bl, h, xl);
-#pragma unroll
-      for (int c = 0; c < C; ++c) xlw[w * C + c] = xl[c];
+      build_h(d, xin + w * d.Cin, lo + w, temb_p, b, t, h);
+      dense_lds(ws.Wl, ws.bl, h, xl);
+      store_row(xlw + w * CP, xl, 0.f, 0.f);
     }
     __syncthreads();
   }
@@ -136,14 +206,12 @@ __global__ __launch_bounds__(256) void spatial_fwd_kernel(const TecmSpatial d, i
   const int i = n0 + tid;
   if (i < n1) {
     float h[C], xr[C], xls[C];
-    build_h<C>(d, xin + (i - lo) * d.Cin, i, temb_p, b, t, h);
-    dense<C>(d.Wr, d.br, h, xr);
-    if (use_edges) {
-#pragma unroll
-      for (int c = 0; c < C; ++c) xls[c] = xlw[(i - lo) * C + c];
-    } else {
-      dense<C>(d.Wl, d.bl, h, xls);
-    }
+    build_h(d, xin + (i - lo) * d.Cin, i, temb_p, b, t, h);
+    dense_lds(ws.Wr, ws.br, h, xr);
+    if (use_edges)
+      load_row(xlw + (i - lo) * CP, xls);
+    else
+      dense_lds(ws.Wl, ws.bl, h, xls);
     float m[H], z[H], acc[C];
 #pragma unroll
     for (int hh = 0; hh < H; ++hh) { m[hh] = -INFINITY; z[hh] = 0.f; }
@@ -155,23 +223,20 @@ __global__ __launch_bounds__(256) void spatial_fwd_kernel(const TecmSpatial d, i
     const int e0 = use_edges ? d.rowptr[i] : 0;
     const int deg = use_edges ? d.rowptr[i + 1] - e0 : 0;
     for (int s = 0; s <= deg; ++s) {
-      const bool self = s == deg;
       float xlj[C];
-      if (self) {
+      if (s == deg) {
 #pragma unroll
         for (int c = 0; c < C; ++c) xlj[c] = xls[c];
       } else {
-        const int j = d.colidx[e0 + s] - lo;
-#pragma unroll
-        for (int c = 0; c < C; ++c) xlj[c] = xlw[j * C + c];
+        load_row(xlw + (d.colidx[e0 + s] - lo) * CP, xlj);
       }
       float e[H];
-      logits<C, H>(xlj, xr, d.att, e);
+      logits(xlj, xr, att, e);
 #pragma unroll
       for (int hh = 0; hh < H; ++hh) {
         const float mn = fmaxf(m[hh], e[hh]);
-        const float corr = expf(m[hh] - mn);     // exp(-inf) = 0 on the first edge
-        const float p = expf(e[hh] - mn);
+        const float corr = __expf(m[hh] - mn);      // exp(-inf) = 0 on the first edge
+        const float p = __expf(e[hh] - mn);
         float pm = p;
         if (dth) pm *= tecm_drop_mult(d.alpha_drop.seed, (uint64_t)((rowi * H + hh) * d.alpha_drop.ld + s), dth, dinv);
         z[hh] = z[hh] * corr + p;
@@ -180,33 +245,47 @@ __global__ __launch_bounds__(256) void spatial_fwd_kernel(const TecmSpatial d, i
         for (int c = 0; c < CH; ++c) acc[hh * CH + c] = acc[hh * CH + c] * corr + pm * xlj[hh * CH + c];
       }
     }
+    float o[C];
 #pragma unroll
     for (int hh = 0; hh < H; ++hh) {
       const float inv = 1.0f / (z[hh] + 1e-16f);
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
         const int k = hh * CH + c;
-        outt[tid * Cp + k] = h[k] + (acc[k] * inv + d.bias[k]);
+        o[k] = h[k] + (acc[k] * inv + ws.bias[k]);
       }
     }
-    for (int k = C; k < Cp; ++k) outt[tid * Cp + k] = 0.f;
+    store_row(outt + tid * CP, o, 0.f, 0.f);
   }
   __syncthreads();
   {
-    const int nf4 = (n1 - n0) * Cp / 4;
-    float4* dst = reinterpret_cast<float4*>(d.out + (grow + n0) * Cp);
+    const int nf4 = (n1 - n0) * CP / 4;
+    float4* dst = reinterpret_cast<float4*>(d.out + (grow + n0) * CP);
     const float4* src = reinterpret_cast<const float4*>(outt);
     for (int q = tid; q < nf4; q += 256) dst[q] = src[q];
   }
 }
 
-template <int C, int H>
-__global__ __launch_bounds__(256) void spatial_bwd_kernel(const TecmSpatial d, const TecmSpatialGrads gr, int Cp,
+// ------------------------------------------------------------------------------------------ backward
+// acc(32x32) += sum over `rows` of  A[row][0..23]^T  (x)  B[row][0..23]   on the f32 matrix core.
+// Rows are dealt to the 4 waves in pairs (one MFMA consumes k = 2 rows).
+__device__ __forceinline__ void outer_accumulate(f32x16& acc, const float* A, const float* Bm, int row_beg,
+                                                 int row_end, int wave, int lane) {
+  const int i = lane & 31, kq = lane >> 5;
+  const bool col_ok = i < CP;
+  for (int r0 = row_beg + 2 * wave; r0 < row_end; r0 += 8) {
+    const int row = r0 + kq;
+    const bool ok = col_ok && row < row_end;
+    const float a = ok ? A[row * CP + i] : 0.f;
+    const float bv = ok ? Bm[row * CP + i] : 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(256) void spatial_bwd_kernel(const TecmSpatial d, const TecmSpatialGrads gr,
                                                           int nchunks) {
-  constexpr int CH = C / H;
-  constexpr int NOUT = C * (C + 1);             // (a, k) with k == C the bias column
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tile = blockIdx.x % d.num_tiles;
   const int rest = blockIdx.x / d.num_tiles;
   const int tch = rest % nchunks, b = rest / nchunks;
@@ -216,22 +295,33 @@ __global__ __launch_bounds__(256) void spatial_bwd_kernel(const TecmSpatial d, c
   const int W = hi - lo;
   const int wm4 = (d.win_max + 3) & ~3;
   const int Demb = d.Demb, Cin = d.Cin;
-  float* hw = smem;                        // [wm4][C]
-  float* xlw = hw + wm4 * C;               // [wm4][C]
-  float* dxlw = xlw + wm4 * C;             // [wm4][C]
-  float* dxr = dxlw + wm4 * C;             // [tile_nodes][C]
-  float* dnode = dxr + d.tile_nodes * C;   // [wm4][Demb]
+  float* hw = smem;                        // [wm4][CP]   h, column 22 = 1 (bias trick), column 23 = 0
+  float* xlw = hw + wm4 * CP;              // [wm4][CP]
+  float* dxlw = xlw + wm4 * CP;            // [wm4][CP]
+  float* dxr = dxlw + wm4 * CP;            // [tile_nodes][CP]
+  float* dnode = dxr + d.tile_nodes * CP;  // [wm4][Demb]
   float* temb = dnode + wm4 * Demb;        // [32]
   float* tsum = temb + 32;                 // [32]
-  float* vec = tsum + 32;                  // [2*C]  datt | dbias block reduction
+  float* vec = tsum + 32;                  // [CP]      datt block reduction
+  float* WlE = vec + CP;                   // [Demb<=32][CP]  WlE[e][a] = Wl[a][Cin+e]
+  float* WrE = WlE + 32 * CP;              // [32][CP]
+  const WeightsLds ws = stage_weights(d, WrE + 32 * CP);
   const bool tf_uniform = d.tf_sn == 0;
 
-  float accL[2] = {0.f, 0.f}, accR[2] = {0.f, 0.f};
-  float datt_acc[C], dbias_acc[C];
-#pragma unroll
-  for (int c = 0; c < C; ++c) { datt_acc[c] = 0.f; dbias_acc[c] = 0.f; }
+  for (int q = tid; q < 32 * CP; q += 256) {
+    const int e = q / CP, a = q - e * CP;
+    const bool ok = e < Demb && a < C;
+    WlE[q] = ok ? d.Wl[a * C + Cin + e] : 0.f;
+    WrE[q] = ok ? d.Wr[a * C + Cin + e] : 0.f;
+  }
   for (int q = tid; q < W * Demb; q += 256) dnode[q] = 0.f;
-  if (tid < 2 * C) vec[tid] = 0.f;
+  if (tid < CP) vec[tid] = 0.f;
+  float att[C], datt_acc[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) { att[c] = d.att[c]; datt_acc[c] = 0.f; }
+  f32x16 accL, accR;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { accL[e] = 0.f; accR[e] = 0.f; }
 
   const uint32_t dth = d.alpha_drop.p > 0.f ? tecm_drop_thresh(d.alpha_drop.p) : 0u;
   const float dinv = d.alpha_drop.p > 0.f ? 1.0f / (1.0f - d.alpha_drop.p) : 1.0f;
@@ -254,133 +344,120 @@ __global__ __launch_bounds__(256) void spatial_bwd_kernel(const TecmSpatial d, c
     // ---- A: recompute h and x_l for the window, clear d x_l
     for (int w = wa + tid; w < wb; w += 256) {
       float h[C], xl[C];
-      build_h<C>(d, d.x + (grow + lo + w) * Cin, lo + w, temb_p, b, t, h);
-      dense<C>(d.Wl, d.bl, h, xl);
+      build_h(d, d.x + (grow + lo + w) * Cin, lo + w, temb_p, b, t, h);
+      dense_lds(ws.Wl, ws.bl, h, xl);
+      store_row(hw + w * CP, h, 1.0f, 0.f);
+      store_row(xlw + w * CP, xl, 0.f, 0.f);
+      float4* z4 = reinterpret_cast<float4*>(dxlw + w * CP);
 #pragma unroll
-      for (int c = 0; c < C; ++c) {
-        hw[w * C + c] = h[c];
-        xlw[w * C + c] = xl[c];
-        dxlw[w * C + c] = 0.f;
-      }
+      for (int q = 0; q < CP / 4; ++q) z4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
 
-    // ---- B: per target node, edge phase
+    // ---- B: per target node, two passes over its edges
     const int i = n0 + tid;
     if (i < n1) {
       const int wi = i - lo;
-      float h[C], xr[C], g[C], dxr_acc[C];
+      float xr[C], g[C], dxr_acc[C];
+      {
+        float h[C];
+        load_row(hw + wi * CP, h);
+        dense_lds(ws.Wr, ws.br, h, xr);
+      }
+      load_row(gr.dout + (grow + i) * CP, g);
 #pragma unroll
-      for (int c = 0; c < C; ++c) { h[c] = hw[wi * C + c]; dxr_acc[c] = 0.f; }
-      dense<C>(d.Wr, d.br, h, xr);
-      const float* grow_p = gr.dout + (grow + i) * Cp;
-#pragma unroll
-      for (int c = 0; c < C; ++c) { g[c] = grow_p[c]; dbias_acc[c] += g[c]; }
+      for (int c = 0; c < C; ++c) dxr_acc[c] = 0.f;
       const int64_t rowi = (int64_t)(t * d.B + b) * d.N + i;
       const int e0 = use_edges ? d.rowptr[i] : 0;
       const int deg = use_edges ? d.rowptr[i + 1] - e0 : 0;
-      float m[H], z[H], dot[H];
+      // pass 1: online softmax statistics and the numerator of dot_h = sum_j alpha_ij dalpha_ij
+      float m[H], z[H], num[H];
 #pragma unroll
-      for (int hh = 0; hh < H; ++hh) { m[hh] = -INFINITY; z[hh] = 0.f; dot[hh] = 0.f; }
-      // pass 1: softmax statistics
+      for (int hh = 0; hh < H; ++hh) { m[hh] = -INFINITY; z[hh] = 0.f; num[hh] = 0.f; }
       for (int s = 0; s <= deg; ++s) {
         const int j = s == deg ? wi : d.colidx[e0 + s] - lo;
-        float e[H];
-        logits<C, H>(xlw + j * C, xr, d.att, e);
+        float xlj[C], e[H];
+        load_row(xlw + j * CP, xlj);
+        logits(xlj, xr, att, e);
 #pragma unroll
         for (int hh = 0; hh < H; ++hh) {
+          float da = 0.f;
+#pragma unroll
+          for (int c = 0; c < CH; ++c) da = fmaf(g[hh * CH + c], xlj[hh * CH + c], da);
+          if (dth) da *= tecm_drop_mult(d.alpha_drop.seed, (uint64_t)((rowi * H + hh) * d.alpha_drop.ld + s), dth, dinv);
           const float mn = fmaxf(m[hh], e[hh]);
-          z[hh] = z[hh] * expf(m[hh] - mn) + expf(e[hh] - mn);
+          const float corr = __expf(m[hh] - mn), p = __expf(e[hh] - mn);
+          z[hh] = z[hh] * corr + p;
+          num[hh] = num[hh] * corr + p * da;
           m[hh] = mn;
         }
       }
-      float zinv[H];
+      float zinv[H], dot[H];
 #pragma unroll
-      for (int hh = 0; hh < H; ++hh) zinv[hh] = 1.0f / (z[hh] + 1e-16f);
-      // pass 2: dot_h = sum_j alpha_ij * dalpha_ij
-      for (int s = 0; s <= deg; ++s) {
-        const int j = s == deg ? wi : d.colidx[e0 + s] - lo;
-        float e[H];
-        logits<C, H>(xlw + j * C, xr, d.att, e);
-#pragma unroll
-        for (int hh = 0; hh < H; ++hh) {
-          const float alpha = expf(e[hh] - m[hh]) * zinv[hh];
-          float mult = 1.0f;
-          if (dth) mult = tecm_drop_mult(d.alpha_drop.seed, (uint64_t)((rowi * H + hh) * d.alpha_drop.ld + s), dth, dinv);
-          float da = 0.f;
-#pragma unroll
-          for (int c = 0; c < CH; ++c) da = fmaf(g[hh * CH + c], xlw[j * C + hh * CH + c], da);
-          dot[hh] += alpha * (da * mult);
-        }
+      for (int hh = 0; hh < H; ++hh) {
+        zinv[hh] = 1.0f / (z[hh] + 1e-16f);
+        dot[hh] = num[hh] * zinv[hh];
       }
-      // pass 3: gradients
+      // pass 2: gradients
       for (int s = 0; s <= deg; ++s) {
         const int j = s == deg ? wi : d.colidx[e0 + s] - lo;
-        float e[H];
-        logits<C, H>(xlw + j * C, xr, d.att, e);
+        float xlj[C], e[H];
+        load_row(xlw + j * CP, xlj);
+        logits(xlj, xr, att, e);
 #pragma unroll
         for (int hh = 0; hh < H; ++hh) {
-          const float alpha = expf(e[hh] - m[hh]) * zinv[hh];
+          const float alpha = __expf(e[hh] - m[hh]) * zinv[hh];
           float mult = 1.0f;
           if (dth) mult = tecm_drop_mult(d.alpha_drop.seed, (uint64_t)((rowi * H + hh) * d.alpha_drop.ld + s), dth, dinv);
           float da = 0.f;
 #pragma unroll
-          for (int c = 0; c < CH; ++c) da = fmaf(g[hh * CH + c], xlw[j * C + hh * CH + c], da);
+          for (int c = 0; c < CH; ++c) da = fmaf(g[hh * CH + c], xlj[hh * CH + c], da);
           const float de = alpha * (da * mult - dot[hh]);
           const float am = alpha * mult;
 #pragma unroll
           for (int c = 0; c < CH; ++c) {
             const int k = hh * CH + c;
-            const float sv = xlw[j * C + k] + xr[k];
-            const float ds = de * d.att[k] * (sv > 0.f ? 1.0f : NEG_SLOPE);
+            const float sv = xlj[k] + xr[k];
+            const float ds = de * att[k] * (sv > 0.f ? 1.0f : NEG_SLOPE);
             datt_acc[k] += de * lrelu(sv);
             dxr_acc[k] += ds;
-            atomicAdd(&dxlw[j * C + k], am * g[k] + ds);
+            atomicAdd(&dxlw[j * CP + k], am * g[k] + ds);
           }
         }
       }
-#pragma unroll
-      for (int c = 0; c < C; ++c) dxr[tid * C + c] = dxr_acc[c];
+      store_row(dxr + tid * CP, dxr_acc, 0.f, 0.f);
     }
     __syncthreads();
 
-    // ---- C1: dWl[a][k] += sum_w dxl[w][a] h[w][k], dWr[a][k] += sum_i dxr[i][a] h[i][k]; k == C -> bias
-#pragma unroll
-    for (int sl = 0; sl < 2; ++sl) {
-      const int o = tid + sl * 256;
-      if (o < NOUT) {
-        const int a = o / (C + 1), k = o - a * (C + 1);
-        float sL = 0.f, sR = 0.f;
-        if (k < C) {
-          for (int w = wa; w < wb; ++w) sL = fmaf(dxlw[w * C + a], hw[w * C + k], sL);
-          for (int q = 0; q < n1 - n0; ++q) sR = fmaf(dxr[q * C + a], hw[(n0 - lo + q) * C + k], sR);
-        } else {
-          for (int w = wa; w < wb; ++w) sL += dxlw[w * C + a];
-          for (int q = 0; q < n1 - n0; ++q) sR += dxr[q * C + a];
-        }
-        accL[sl] += sL;
-        accR[sl] += sR;
-      }
-    }
-    // ---- C2: embedding part of dh -> node table accumulators and temporal tables
+    // ---- C1: [dWl | dbl] += dxl^T [h, 1] over the window, [dWr | dbr] += dxr^T [h, 1] over the tile
+    outer_accumulate(accL, dxlw, hw, wa, wb, wave, lane);
+    outer_accumulate(accR, dxr - (n0 - lo) * CP, hw, n0 - lo, n1 - lo, wave, lane);
+
+    // ---- C2: embedding part of dh -> node-table accumulators and temporal tables
     for (int w0 = wa; w0 < wb; w0 += 256) {
       const int w = w0 + tid;
       const bool act = w < wb;
       const int node = lo + w;
       const bool intile = act && node >= n0 && node < n1;
+      float dl[C], dr[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) { dl[c] = 0.f; dr[c] = 0.f; }
+      if (act) load_row(dxlw + w * CP, dl);
+      if (intile) load_row(dxr + (node - n0) * CP, dr);
       TimeIdx ti;
       if (act && !tf_uniform) ti = load_time_idx(d, b, t, node);
       for (int e = 0; e < Demb; ++e) {
         float v = 0.f;
         if (act) {
-          const int col = Cin + e;
+          float wl[C], wr[C];
+          load_row(WlE + e * CP, wl);
 #pragma unroll
-          for (int a = 0; a < C; ++a) v = fmaf(d.Wl[a * C + col], dxlw[w * C + a], v);
+          for (int a = 0; a < C; ++a) v = fmaf(wl[a], dl[a], v);
           if (intile) {
-            const int q = node - n0;
+            load_row(WrE + e * CP, wr);
 #pragma unroll
-            for (int a = 0; a < C; ++a) v = fmaf(d.Wr[a * C + col], dxr[q * C + a], v);
-            v += gr.dout[(grow + node) * Cp + col];
+            for (int a = 0; a < C; ++a) v = fmaf(wr[a], dr[a], v);
+            v += gr.dout[(grow + node) * CP + Cin + e];
           }
           dnode[w * Demb + e] += v;
           if (!tf_uniform) {
@@ -406,41 +483,48 @@ __global__ __launch_bounds__(256) void spatial_bwd_kernel(const TecmSpatial d, c
     }
   }
 
-  // ---- block results
+  // ---- block results.  partial row layout: dWl (C*C) | dbl (C) | dWr (C*C) | dbr (C) | datt (C) | (C unused)
   __syncthreads();
 #pragma unroll
   for (int c = 0; c < C; ++c) {
     const float a = wave_sum(datt_acc[c]);
-    const float bsum = wave_sum(dbias_acc[c]);
-    if (lane == 0) {
-      atomicAdd(&vec[c], a);
-      atomicAdd(&vec[C + c], bsum);
-    }
+    if (lane == 0) atomicAdd(&vec[c], a);
   }
   __syncthreads();
   float* part = gr.partials + (int64_t)blockIdx.x * gr.partial_ld;
-  // layout: dWl (C*C) | dbl (C) | dWr (C*C) | dbr (C) | datt (C) | dbias (C)
+  if (tid < C) part[2 * C * C + 2 * C + tid] = vec[tid];
+  for (int q = tid; q < W * Demb; q += 256) atomicAdd(&gr.d_node_tab[(int64_t)lo * Demb + q], dnode[q]);
+  __syncthreads();                                     // every LDS array is dead from here on
+  // reduce the four waves' MFMA accumulators through LDS: [2][4][32][32] floats (host guarantees the size)
+  float* red = smem;
+  {
+    const int col = lane & 31, hq = lane >> 5;
 #pragma unroll
-  for (int sl = 0; sl < 2; ++sl) {
-    const int o = tid + sl * 256;
-    if (o < NOUT) {
-      const int a = o / (C + 1), k = o - a * (C + 1);
-      if (k < C) {
-        part[a * C + k] = accL[sl];
-        part[C * C + C + a * C + k] = accR[sl];
-      } else {
-        part[C * C + a] = accL[sl];
-        part[2 * C * C + C + a] = accR[sl];
-      }
+    for (int e = 0; e < 16; ++e) {
+      const int row = (e & 3) + 8 * (e >> 2) + 4 * hq;
+      red[((0 * 4 + wave) * 32 + row) * 32 + col] = accL[e];
+      red[((1 * 4 + wave) * 32 + row) * 32 + col] = accR[e];
     }
   }
-  if (tid < 2 * C) part[2 * C * C + 2 * C + tid] = vec[tid];
-  for (int q = tid; q < W * Demb; q += 256) atomicAdd(&gr.d_node_tab[(int64_t)lo * Demb + q], dnode[q]);
+  __syncthreads();
+  for (int o = tid; o < 2 * C * (C + 1); o += 256) {
+    const int mtx = o / (C * (C + 1));
+    const int rem = o - mtx * C * (C + 1);
+    const int a = rem / (C + 1), k = rem - a * (C + 1);
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) s += red[((mtx * 4 + w) * 32 + a) * 32 + k];
+    const int base = mtx * (C * C + C);
+    if (k < C)
+      part[base + a * C + k] = s;
+    else
+      part[base + C * C + a] = s;
+  }
 }
 
 int check_common(const char* who, const TecmSpatial& d) {
   TECM_REQUIRE(d.B > 0 && d.L > 0 && d.N > 0 && d.Cin > 0 && d.Demb > 0 && d.H > 0, TECM_E_ARG, "%s: bad shape", who);
-  TECM_REQUIRE(d.Cin + d.Demb == 22 && d.H == 2, TECM_E_ARG,
+  TECM_REQUIRE(d.Cin + d.Demb == C && d.H == H, TECM_E_ARG,
                "%s: built for C = Cin + Demb = 22 channels and 2 heads (got C=%d H=%d)", who, d.Cin + d.Demb, d.H);
   TECM_REQUIRE(d.Demb <= 32, TECM_E_ARG, "%s: Demb must be <= 32", who);
   TECM_REQUIRE(d.x && d.tf && d.node_tab && d.tod_tab && d.doy_tab && d.year_tab && d.season_tab && d.Wl && d.bl &&
@@ -463,21 +547,19 @@ extern "C" int tecm_spatial_fwd(const TecmSpatial* dp, void* stream) {
   const int rc = check_common("tecm_spatial_fwd", d);
   if (rc) return rc;
   TECM_REQUIRE(d.out != nullptr && tecm_aligned(d.out, 16), TECM_E_ALIGN, "tecm_spatial_fwd: out must be 16-byte aligned");
-  constexpr int C = 22;
-  const int Cp = (C + 3) & ~3;
   const int wm4 = (d.win_max + 3) & ~3;
-  const size_t lds = sizeof(float) * ((size_t)wm4 * d.Cin + (size_t)wm4 * C + (size_t)d.tile_nodes * Cp + 32);
+  const size_t lds = sizeof(float) * ((size_t)((wm4 * d.Cin + 3) & ~3) + (size_t)wm4 * CP + (size_t)d.tile_nodes * CP +
+                                      32 + WEIGHT_FLOATS);
   TECM_REQUIRE(lds <= (size_t)kLdsBudget, TECM_E_LDS,
                "tecm_spatial_fwd: neighbour window of %d rows needs %zu B of LDS (> 160 KiB); renumber the graph "
                "(e.g. RCM) or shrink tile_nodes", d.win_max, lds);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_fwd_kernel<22, 2>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        kLdsBudget);
     attr_set = true;
   }
-  hipLaunchKernelGGL((spatial_fwd_kernel<22, 2>), dim3(d.num_tiles, d.B * d.L), dim3(256), lds, (hipStream_t)stream, d,
-                     Cp);
+  hipLaunchKernelGGL(spatial_fwd_kernel, dim3(d.num_tiles, d.B * d.L), dim3(256), lds, (hipStream_t)stream, d);
   TECM_CHECK_LAUNCH("tecm_spatial_fwd");
   return TECM_OK;
 }
@@ -488,10 +570,9 @@ extern "C" int tecm_spatial_bwd(const TecmSpatial* dp, const TecmSpatialGrads* g
   const TecmSpatialGrads& g = *gp;
   const int rc = check_common("tecm_spatial_bwd", d);
   if (rc) return rc;
-  constexpr int C = 22;
-  const int Cp = (C + 3) & ~3;
   TECM_REQUIRE(g.dout && g.d_node_tab && g.d_tod_tab && g.d_doy_tab && g.d_year_tab && g.d_season_tab && g.partials,
                TECM_E_ARG, "tecm_spatial_bwd: null pointer");
+  TECM_REQUIRE(tecm_aligned(g.dout, 16), TECM_E_ALIGN, "tecm_spatial_bwd: dout must be 16-byte aligned");
   TECM_REQUIRE(g.t_chunk > 0, TECM_E_ARG, "tecm_spatial_bwd: t_chunk must be positive");
   const int nchunks = (d.L + g.t_chunk - 1) / g.t_chunk;
   const int nblocks = d.num_tiles * d.B * nchunks;
@@ -500,18 +581,20 @@ extern "C" int tecm_spatial_bwd(const TecmSpatial* dp, const TecmSpatialGrads* g
   TECM_REQUIRE(g.partial_ld >= 2 * C * C + 4 * C, TECM_E_ARG, "tecm_spatial_bwd: partial_ld must be >= %d",
                2 * C * C + 4 * C);
   const int wm4 = (d.win_max + 3) & ~3;
-  const size_t lds =
-      sizeof(float) * ((size_t)3 * wm4 * C + (size_t)d.tile_nodes * C + (size_t)wm4 * d.Demb + 64 + 2 * C);
+  size_t floats = (size_t)3 * wm4 * CP + (size_t)d.tile_nodes * CP + (size_t)wm4 * d.Demb + 64 + CP + 64 * CP +
+                  WEIGHT_FLOATS;
+  if (floats < 8192 + 64) floats = 8192 + 64;          // the final 4-wave MFMA reduction needs 2*4*32*32 floats
+  const size_t lds = sizeof(float) * floats;
   TECM_REQUIRE(lds <= (size_t)kLdsBudget, TECM_E_LDS,
                "tecm_spatial_bwd: neighbour window of %d rows needs %zu B of LDS (> 160 KiB); renumber the graph "
                "(e.g. RCM) or shrink tile_nodes", d.win_max, lds);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_bwd_kernel<22, 2>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        kLdsBudget);
     attr_set = true;
   }
-  hipLaunchKernelGGL((spatial_bwd_kernel<22, 2>), dim3(nblocks), dim3(256), lds, (hipStream_t)stream, d, g, Cp, nchunks);
+  hipLaunchKernelGGL(spatial_bwd_kernel, dim3(nblocks), dim3(256), lds, (hipStream_t)stream, d, g, nchunks);
   TECM_CHECK_LAUNCH("tecm_spatial_bwd");
   return TECM_OK;
 }

@@ -135,8 +135,8 @@ class SpatialFn(torch.autograd.Function):
         dbl = s[o:o + Cc]; o += Cc
         dWr = s[o:o + Cc * Cc].view(Cc, Cc); o += Cc * Cc
         dbr = s[o:o + Cc]; o += Cc
-        datt = s[o:o + Cc].view_as(att); o += Cc
-        dbias = s[o:o + Cc]
+        datt = s[o:o + Cc].view_as(att)
+        dbias = colsum(dout, CP, B * L * N, 1, 1, Cc)[0]        # d bias = column sums of dout (out = h + gat + bias)
         return (None, None, d_node, d_tod, d_doy, d_year, d_season, dWl, dbl, dWr, dbr, datt, dbias,
                 None, None, None, None)
 

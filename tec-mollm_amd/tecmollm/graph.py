@@ -59,9 +59,15 @@ def tile_windows(rowptr: np.ndarray, colidx: np.ndarray, num_nodes: int, tile_no
     return lo, hi
 
 
+CP = 24
+WEIGHT_FLOATS = 2 * C_FEAT * CP + 3 * CP
+
+
 def lds_bytes_bwd(win: int, tile_nodes: int, demb: int = 16) -> int:
+    """Dynamic LDS of spatial_bwd_kernel (must match csrc/spatial.hip:tecm_spatial_bwd)."""
     wm4 = (win + 3) & ~3
-    return 4 * (3 * wm4 * C_FEAT + tile_nodes * C_FEAT + wm4 * demb + 64 + 2 * C_FEAT)
+    floats = 3 * wm4 * CP + tile_nodes * CP + wm4 * demb + 64 + CP + 64 * CP + WEIGHT_FLOATS
+    return 4 * max(floats, 8192 + 64)
 
 
 def build(edge_index: torch.Tensor, num_nodes: int, device: torch.device, demb: int = 16) -> GraphMeta:

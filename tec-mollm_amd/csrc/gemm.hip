@@ -15,6 +15,22 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const TecmGemm g, in
   }
 }
 
+// erf-GELU (nn.GELU() of the prediction head, modules.py:288) is applied by this small elementwise pass after
+// the GEMM has written alpha*acc + bias: keeping the erf polynomial out of the GEMM epilogue keeps that
+// kernel's code small (it is streamed through the instruction cache once per block).
+__global__ __launch_bounds__(256) void erf_post_kernel(float* __restrict__ C, int64_t ldc, const float* __restrict__ src,
+                                                       int64_t lds, int64_t M, int32_t N, tecm_gemm::DropCtx odc) {
+  const int64_t total = M * N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / N;
+    const int32_t n = (int32_t)(i - m * N);
+    float v = C[m * ldc + n];
+    v = src ? v * dgelu_erf(src[m * lds + n]) : gelu_erf(v);
+    if (odc.thresh) v *= tecm_drop_mult(odc.seed, (uint64_t)(m * odc.ld + n), odc.thresh, odc.inv);
+    C[m * ldc + n] = v;
+  }
+}
+
 // widest vector (4, 2 or 1 floats) the operand's address pattern allows
 int pick_vec(const float* p, int64_t ld, const TecmWin& w, bool inner_is_k, int64_t K) {
   int v = 4;
@@ -62,20 +78,42 @@ extern "C" int tecm_gemm_f32(const TecmGemm* d, void* stream) {
   const int bvec = pick_vec(g.B, g.ldb, g.b_win, g.b_layout == TECM_B_NK, g.K);
   const bool win = g.a_win.enabled || g.b_win.enabled;
   const bool drop = g.a_drop.p > 0.f || g.b_drop.p > 0.f;
+  // float4 epilogue only when everything it touches is 16-byte friendly
+  auto ok4 = [](const void* p, int64_t ld) { return p == nullptr || (tecm_aligned(p, 16) && ld % 4 == 0); };
+  const bool vec4 = g.N % 4 == 0 && ok4(g.C, g.ldc) && ok4(g.bias, 4) && ok4(g.rowbias, g.rb_ld) &&
+                    ok4(g.preact, g.ldp) && ok4(g.dact_src, g.ldd) && ok4(g.residual, g.ldr) &&
+                    (!g.c_win.enabled || g.c_win.Cw % 4 == 0) &&
+                    (g.split_k <= 1 || tecm_aligned(g.workspace, 16));
+  TecmGemm gk = g;                 // private copy: _p0 carries the epilogue-vectorisation flag to the kernel
+  gk._p0 = vec4 ? 1 : 0;
+  const bool erf = g.act == TECM_ACT_GELU_ERF;
+  if (erf) {                       // GEMM writes the pre-activation, erf_post_kernel finishes (see above)
+    TECM_REQUIRE(!g.residual && !g.accumulate && !g.c_win.enabled, TECM_E_ARG,
+                 "tecm_gemm_f32: GELU_ERF cannot be combined with residual / accumulate / c_win");
+    gk.act = TECM_ACT_NONE;
+    gk.dact_src = nullptr;
+    gk.out_drop.p = 0.f;
+  }
   int splits;
   if (g.a_layout == TECM_A_MK && g.b_layout == TECM_B_NK)
-    splits = tecm_gemm_dispatch_mk_nk(g, avec, bvec, win, drop, st);
+    splits = tecm_gemm_dispatch_mk_nk(gk, avec, bvec, win, drop, st);
   else if (g.a_layout == TECM_A_MK)
-    splits = tecm_gemm_dispatch_mk_kn(g, avec, bvec, win, drop, st);
+    splits = tecm_gemm_dispatch_mk_kn(gk, avec, bvec, win, drop, st);
   else
-    splits = tecm_gemm_dispatch_km_kn(g, avec, bvec, win, drop, st);
+    splits = tecm_gemm_dispatch_km_kn(gk, avec, bvec, win, drop, st);
   if (splits < 0) return splits;
   if (splits > 1) {
     const int64_t total = g.M * g.N;
     const int64_t want = (total + 255) / 256;
     const int blocks = (int)(want < 2048 ? want : 2048);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, g, splits);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, gk, splits);
     TECM_CHECK_LAUNCH("tecm_gemm_f32/splitk_reduce");
+  }
+  if (erf) {
+    const int64_t want = (g.M * g.N + 255) / 256;
+    hipLaunchKernelGGL(erf_post_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, st, g.C, g.ldc,
+                       g.dact_src, g.ldd, g.M, (int32_t)g.N, tecm_gemm::make_drop_host(g.out_drop));
+    TECM_CHECK_LAUNCH("tecm_gemm_f32/erf_post");
   }
   return TECM_OK;
 }

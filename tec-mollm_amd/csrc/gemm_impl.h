@@ -51,6 +51,14 @@ struct DropCtx {
   uint32_t thresh;
   float inv;
 };
+inline DropCtx make_drop_host(const TecmDrop& d) {
+  DropCtx c;
+  c.seed = d.seed;
+  c.ld = d.ld;
+  c.thresh = d.p > 0.f ? tecm_drop_thresh(d.p) : 0u;
+  c.inv = d.p > 0.f ? 1.0f / (1.0f - d.p) : 1.0f;
+  return c;
+}
 __device__ __forceinline__ DropCtx make_drop(const TecmDrop& d) {
   DropCtx c;
   c.seed = d.seed;
@@ -60,21 +68,22 @@ __device__ __forceinline__ DropCtx make_drop(const TecmDrop& d) {
   return c;
 }
 
+// Branch-free guarded load: out-of-range lanes read `safe` (always a valid address of the same operand); the
+// caller zeroes them later, at LDS-store time (tile_finish), so that nothing consumes the loaded registers --
+// and forces an s_waitcnt vmcnt -- right after the load has been issued.  No exec-mask branches => the whole
+// K-tile body stays ONE scheduling region, which the sched_group_barrier interleave in the main loop needs.
 template <int VEC>
-__device__ __forceinline__ void gload(const float* __restrict__ p, bool ok, float (&out)[VEC]) {
-  if (ok) {
-    if constexpr (VEC == 4) {
-      const float4 v = *reinterpret_cast<const float4*>(p);
-      out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
-    } else if constexpr (VEC == 2) {
-      const float2 v = *reinterpret_cast<const float2*>(p);
-      out[0] = v.x; out[1] = v.y;
-    } else {
-      out[0] = p[0];
-    }
+__device__ __forceinline__ void gload(const float* __restrict__ p, const float* __restrict__ safe, bool ok,
+                                      float (&out)[VEC]) {
+  const float* q = ok ? p : safe;
+  if constexpr (VEC == 4) {
+    const float4 v = *reinterpret_cast<const float4*>(q);
+    out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+  } else if constexpr (VEC == 2) {
+    const float2 v = *reinterpret_cast<const float2*>(q);
+    out[0] = v.x; out[1] = v.y;
   } else {
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) out[e] = 0.f;
+    out[0] = q[0];
   }
 }
 
@@ -132,6 +141,8 @@ struct Stager {
   static_assert((R * VPR) % NTHREADS == 0 && NTHREADS % VPR == 0, "tile/thread mapping");
 
   float regs[NV][VEC];
+  uint32_t okbits;                        // bit i: vector i of the tile held in regs is in range (else stored as 0)
+  int64_t dsave[DROP ? NV : 1];           // dropout index of vector i of the tile held in regs
   // --- plain view state
   const float* ptr[NV];                   // address of this thread's vector i in the NEXT tile to load
   uint32_t rowok;                         // bit i: fixed row i in range (ROWK=false) / unused
@@ -148,6 +159,7 @@ struct Stager {
     const int cv = (threadIdx.x % VPR) * VEC;
     const int r0 = threadIdx.x / VPR;
     rowok = 0;
+    okbits = 0;
     inner_ok = true;
     tap = 0;
     c = 0;
@@ -186,26 +198,38 @@ struct Stager {
     }
   }
 
-  // Load this thread's vectors of the tile starting at k0 and advance the state to the next tile.
+  // Load this thread's vectors [IB, IE) of the tile starting at k0; the call that covers the last vector
+  // (IE == NV) advances the per-tile state.  load() = all vectors.
   __device__ __forceinline__ void load(const float* __restrict__ P, const TecmWin& w, int64_t ld, int32_t k0,
                                        int32_t klim, const DropCtx& dc) {
+    load_part<0, NV>(P, w, ld, k0, klim, dc);
+  }
+  template <int IB, int IE>
+  __device__ __forceinline__ void load_part(const float* __restrict__ P, const TecmWin& w, int64_t ld, int32_t k0,
+                                            int32_t klim, const DropCtx& dc) {
+    if constexpr (IB >= IE) return;
     const int r0 = threadIdx.x / VPR;
     const bool wen = WIN && w.enabled;
+    constexpr bool LAST = IE == NV;
     if (!wen) {
       if constexpr (!ROWK) {
         const bool kok = kk < klim;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-          gload<VEC>(ptr[i], kok && ((rowok >> i) & 1u), regs[i]);
-          if constexpr (DROP) { apply_drop<VEC>(dc, didx[i], regs[i]); didx[i] += BK; }
+        for (int i = IB; i < IE; ++i) {
+          const bool ok = kok && ((rowok >> i) & 1u);
+          gload<VEC>(ptr[i], P, ok, regs[i]);
+          okbits = (okbits & ~(1u << i)) | ((ok ? 1u : 0u) << i);
+          if constexpr (DROP) { dsave[i] = didx[i]; didx[i] += BK; }
           ptr[i] += BK;
         }
-        kk += BK;
+        if constexpr (LAST) kk += BK;
       } else {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-          gload<VEC>(ptr[i], inner_ok && (k0 + r0 + i * RSTEP) < klim, regs[i]);
-          if constexpr (DROP) { apply_drop<VEC>(dc, didx[i], regs[i]); didx[i] += (int64_t)BK * dc.ld; }
+        for (int i = IB; i < IE; ++i) {
+          const bool ok = inner_ok && (k0 + r0 + i * RSTEP) < klim;
+          gload<VEC>(ptr[i], P, ok, regs[i]);
+          okbits = (okbits & ~(1u << i)) | ((ok ? 1u : 0u) << i);
+          if constexpr (DROP) { dsave[i] = didx[i]; didx[i] += (int64_t)BK * dc.ld; }
           ptr[i] += (int64_t)BK * ld;
         }
       }
@@ -214,35 +238,49 @@ struct Stager {
         const bool kok = kk < klim;
         const int64_t tapoff = (int64_t)tap * w.N;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
+        for (int i = IB; i < IE; ++i) {
           const int32_t t_in = wr[i].t0 + tap;            // INVALID + tap stays hugely negative
           const bool ok = kok && t_in >= 0 && t_in < w.Lin;
           const int64_t row = wr[i].srow + tapoff;
-          gload<VEC>(P + row * ld + c, ok, regs[i]);
-          if constexpr (DROP) apply_drop<VEC>(dc, row * dc.ld + c, regs[i]);
+          gload<VEC>(P + row * ld + c, P, ok, regs[i]);
+          okbits = (okbits & ~(1u << i)) | ((ok ? 1u : 0u) << i);
+          if constexpr (DROP) dsave[i] = row * dc.ld + c;
         }
-        kk += BK;
-        c += BK;
-        while (c >= w.Cw) { c -= w.Cw; ++tap; }
+        if constexpr (LAST) {
+          kk += BK;
+          c += BK;
+          while (c >= w.Cw) { c -= w.Cw; ++tap; }
+        }
       } else {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
+        for (int i = IB; i < IE; ++i) {
           const WinRow rr = win_row(w, (int64_t)k0 + r0 + i * RSTEP, klim);
           const int32_t t_in = rr.t0 + tap;
           const bool ok = inner_ok && t_in >= 0 && t_in < w.Lin;
           const int64_t row = rr.srow + (int64_t)tap * w.N;
-          gload<VEC>(P + row * ld + c, ok, regs[i]);
-          if constexpr (DROP) apply_drop<VEC>(dc, row * dc.ld + c, regs[i]);
+          gload<VEC>(P + row * ld + c, P, ok, regs[i]);
+          okbits = (okbits & ~(1u << i)) | ((ok ? 1u : 0u) << i);
+          if constexpr (DROP) dsave[i] = row * dc.ld + c;
         }
       }
     }
   }
 
-  __device__ __forceinline__ void store(float* lds) const {
+  __device__ __forceinline__ void store(float* lds, const DropCtx& dc) { store_part<0, NV>(lds, dc); }
+  template <int IB, int IE>
+  __device__ __forceinline__ void store_part(float* lds, const DropCtx& dc) {
+    if constexpr (IB >= IE) return;
     const int cv = (threadIdx.x % VPR) * VEC;
     const int r0 = threadIdx.x / VPR;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) lds_store<VEC>(lds + (r0 + i * RSTEP) * LD + cv, regs[i]);
+    for (int i = IB; i < IE; ++i) {
+      float v[VEC];
+      const bool ok = (okbits >> i) & 1u;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) v[e] = ok ? regs[i][e] : 0.f;
+      if constexpr (DROP) apply_drop<VEC>(dc, dsave[i], v);
+      lds_store<VEC>(lds + (r0 + i * RSTEP) * LD + cv, v);
+    }
   }
 };
 
@@ -301,9 +339,9 @@ __device__ __forceinline__ void epi_elem(const TecmGemm& g, const DropCtx& odc, 
   if (r.rb) v += r.rb[n];
   if (g.preact) g.preact[r.m * g.ldp + n] = v;
   if (g.dact_src)
-    v *= apply_dact(g.act, g.dact_src[r.m * g.ldd + n]);   // backward through `act`
+    v *= dgelu_tanh(g.dact_src[r.m * g.ldd + n]);          // backward through tanh-GELU
   else if (g.act)
-    v = apply_act(g.act, v);
+    v = gelu_tanh(v);
   int64_t off, didx;
   if (g.c_win.enabled) {
     const int32_t t_in = r.t0 + c.tap;
@@ -327,6 +365,51 @@ __device__ __forceinline__ void epilogue_store(const TecmGemm& g, const DropCtx&
   epi_elem(g, odc, r, c, v);
 }
 
+// Four consecutive columns of one row (n % 4 == 0).  Only used when every pointer / leading dimension the
+// epilogue touches is 16-byte friendly (checked on the host: TecmGemm::_p0 carries the flag).
+__device__ __forceinline__ void epi_vec4(const TecmGemm& g, const DropCtx& odc, const EpiRow& r, const EpiCol& c,
+                                         const float4& bias4, float4 v) {
+  const int32_t n = c.n;
+  float o[4] = {v.x * g.alpha + bias4.x, v.y * g.alpha + bias4.y, v.z * g.alpha + bias4.z, v.w * g.alpha + bias4.w};
+  if (r.rb) {
+    const float4 t = *reinterpret_cast<const float4*>(r.rb + n);
+    o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w;
+  }
+  if (g.preact) *reinterpret_cast<float4*>(g.preact + r.m * g.ldp + n) = make_float4(o[0], o[1], o[2], o[3]);
+  if (g.dact_src) {
+    const float4 t = *reinterpret_cast<const float4*>(g.dact_src + r.m * g.ldd + n);
+    o[0] *= dgelu_tanh(t.x); o[1] *= dgelu_tanh(t.y);
+    o[2] *= dgelu_tanh(t.z); o[3] *= dgelu_tanh(t.w);
+  } else if (g.act) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = gelu_tanh(o[e]);
+  }
+  int64_t off, didx;
+  if (g.c_win.enabled) {
+    const int32_t t_in = r.t0 + c.tap;
+    if (t_in < 0 || t_in >= g.c_win.Lin) return;
+    const int64_t row = r.crow + (int64_t)c.tap * g.c_win.N;
+    off = row * g.ldc + c.c;
+    didx = row * odc.ld + c.c;
+  } else {
+    off = r.crow + n;
+    didx = r.drow + n;
+  }
+  if (odc.thresh) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] *= tecm_drop_mult(odc.seed, (uint64_t)(didx + e), odc.thresh, odc.inv);
+  }
+  if (g.residual) {
+    const float4 t = *reinterpret_cast<const float4*>(g.residual + r.m * g.ldr + n);
+    o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w;
+  }
+  if (g.accumulate) {
+    const float4 t = *reinterpret_cast<const float4*>(g.C + off);
+    o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w;
+  }
+  *reinterpret_cast<float4*>(g.C + off) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
 template <int ALAY, int BLAY, int AVEC, int BVEC, int BN, bool WIN, bool DROP>
 __global__ __launch_bounds__(NTHREADS, (AVEC == 4 && BVEC == 4) ? 2 : 1) void gemm_kernel(const TecmGemm g,
                                                                                            int tiles_m, int tiles_n,
@@ -341,11 +424,12 @@ __global__ __launch_bounds__(NTHREADS, (AVEC == 4 && BVEC == 4) ? 2 : 1) void ge
   using BStager = Stager<BLAY == TECM_B_KN, BN, BVEC, WIN, DROP>;
   constexpr int A_FLOATS = AStager::R * AStager::LD;
   constexpr int B_FLOATS = BStager::R * BStager::LD;
-  constexpr int STG_LD = WTN + 1;                       // epilogue staging: 32 rows x WTN cols per wave
-  static_assert(4 * 32 * STG_LD <= A_FLOATS + B_FLOATS, "epilogue staging must fit the operand tiles");
-  __shared__ __attribute__((aligned(16))) float smem[A_FLOATS + B_FLOATS];
-  float* As = smem;
-  float* Bs = smem + A_FLOATS;
+  constexpr int TILE_FLOATS = A_FLOATS + B_FLOATS;
+  constexpr int STG_LD = WTN + 4;                       // epilogue staging: 32 rows x WTN cols per wave, 16-B rows
+  // two operand buffers: tile t+1 is written into the idle one between the MFMAs of tile t (one barrier per tile)
+  constexpr int STG_FLOATS = 4 * WTM * STG_LD;          // whole accumulator block of the 4 waves
+  constexpr int SMEM_FLOATS = 2 * TILE_FLOATS > STG_FLOATS ? 2 * TILE_FLOATS : STG_FLOATS;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
 
   // XCD-aware, bijective block -> tile map: blocks that share an XCD (id % 8) get a contiguous
   // run of tiles, n fastest, so an A row-panel is re-read from that XCD's L2.
@@ -354,7 +438,15 @@ __global__ __launch_bounds__(NTHREADS, (AVEC == 4 && BVEC == 4) ? 2 : 1) void ge
   const int xcd = id & 7, local = id >> 3;
   const int q8 = nwg >> 3, r8 = nwg & 7;
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
-  const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+  // grouped order inside the XCD's run: 8 m-tiles x all n-tiles per group, m fastest, so the ~64 blocks
+  // resident on one XCD form an (8 m) x (8 n) super-tile whose A and B panels both live in that XCD's 4 MiB L2
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * tiles_n;
+  const int group = wg / per_group;
+  const int first_m = group * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int in_group = wg - group * per_group;
+  const int tm = first_m + in_group % gsz, tn = in_group / gsz;
   const int64_t m0 = (int64_t)tm * BM;
   const int64_t n0 = (int64_t)tn * BN;
   const int32_t kbeg = blockIdx.z * k_chunk;
@@ -379,84 +471,158 @@ __global__ __launch_bounds__(NTHREADS, (AVEC == 4 && BVEC == 4) ? 2 : 1) void ge
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  // one q-step = k sub-range [8q, 8q+8): fragment reads and the MT*NT*4 MFMAs that consume them
+  auto read_frags = [&](const float* As, const float* Bs, auto qc, float (&af)[MT][4], float (&bf)[NT][4]) {
+    constexpr int q = decltype(qc)::value;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int row = wm * WTM + i * 32 + r;
+      if constexpr (ALAY == TECM_A_MK) {
+        const float4 v = *reinterpret_cast<const float4*>(&As[row * LDK + 8 * q + 4 * h]);
+        af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) af[i][j] = As[(8 * q + 4 * h + j) * AStager::LD + row];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int col = wn * WTN + i * 32 + r;
+      if constexpr (BLAY == TECM_B_NK) {
+        const float4 v = *reinterpret_cast<const float4*>(&Bs[col * LDK + 8 * q + 4 * h]);
+        bf[i][0] = v.x; bf[i][1] = v.y; bf[i][2] = v.z; bf[i][3] = v.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf[i][j] = Bs[(8 * q + 4 * h + j) * BStager::LD + col];
+      }
+    }
+  };
+  auto do_mfma = [&](const float (&af)[MT][4], const float (&bf)[NT][4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int jn = 0; jn < NT; ++jn)
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][j], bf[jn][j], acc[i][jn], 0, 0, 0);
+  };
+
+  // prologue: tile 0 -> LDS buffer 0, tile 1 -> registers (in flight)
   sa.load(g.A, g.a_win, g.lda, kbeg, kend, adc);
   sb.load(g.B, g.b_win, g.ldb, kbeg, kend, bdc);
-  sa.store(As);
-  sb.store(Bs);
+  sa.store(smem, adc);
+  sb.store(smem + A_FLOATS, bdc);
+  if (kbeg + BK < kend) {
+    sa.load(g.A, g.a_win, g.lda, kbeg + BK, kend, adc);
+    sb.load(g.B, g.b_win, g.ldb, kbeg + BK, kend, bdc);
+  }
   __syncthreads();
 
-  for (int32_t k0 = kbeg; k0 < kend; k0 += BK) {
-    const bool more = k0 + BK < kend;
-    if (more) {
-      sa.load(g.A, g.a_win, g.lda, k0 + BK, kend, adc);
-      sb.load(g.B, g.b_win, g.ldb, k0 + BK, kend, bdc);
-    }
+  // ---- main loop.  One K-tile = 4 q-steps of MT*NT*4 MFMAs.  Per q-step the wave also has to issue
+  //   * the fragment reads of the NEXT q-step (second fragment register set),
+  //   * a quarter of the staging work: park tile t+1 (already in registers) in the idle LDS buffer and refill
+  //     those registers with tile t+2 from global memory.
+  // In the steady state (FULL: tiles t+1 and t+2 exist) the body is branch-free, i.e. one scheduling region,
+  // and sched_group_barrier pins the order "1 MFMA, 1 memory instruction, 1 MFMA, ..." so every LDS / global
+  // instruction issues in the shadow of a 64-cycle MFMA and nothing is waited for right after it was issued.
+  float fa[2][MT][4], fb[2][NT][4];
+  constexpr int ANV = AStager::NV, BNV = BStager::NV;
+  auto tile_body = [&](const float* Ac, const float* Bc, float* An, int32_t k0, auto fullc) {
+    constexpr bool FULL = decltype(fullc)::value;
+    read_frags(Ac, Bc, std::integral_constant<int, 0>{}, fa[0], fb[0]);
+    static_for<4>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      if constexpr (q < 3) read_frags(Ac, Bc, std::integral_constant<int, q + 1>{}, fa[(q + 1) & 1], fb[(q + 1) & 1]);
+      do_mfma(fa[q & 1], fb[q & 1]);
+      constexpr int AB = (ANV * q) / 4, AE = (ANV * (q + 1)) / 4;
+      constexpr int BB = (BNV * q) / 4, BE = (BNV * (q + 1)) / 4;
+      if (FULL || k0 + BK < kend) {
+        sa.template store_part<AB, AE>(An, adc);
+        sb.template store_part<BB, BE>(An + A_FLOATS, bdc);
+      }
+      if (FULL || k0 + 2 * BK < kend) {
+        sa.template load_part<AB, AE>(g.A, g.a_win, g.lda, k0 + 2 * BK, kend, adc);
+        sb.template load_part<BB, BE>(g.B, g.b_win, g.ldb, k0 + 2 * BK, kend, bdc);
+      }
+      if constexpr (FULL && !WIN && !DROP && AVEC == 4 && BVEC == 4) {
+        // 16 (or MT*NT*4) MFMAs; between them: next-step fragment reads first, then LDS writes, then global loads
+        constexpr int NMFMA = MT * NT * 4;
+        constexpr int NREAD = q < 3 ? 12 : 0;            // upper bound on ds_read instructions of one read_frags
 #pragma unroll
-    for (int q = 0; q < BK / 8; ++q) {
-      float af[MT][4], bf[NT][4];
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int row = wm * WTM + i * 32 + r;
-        if constexpr (ALAY == TECM_A_MK) {
-          const float4 v = *reinterpret_cast<const float4*>(&As[row * LDK + 8 * q + 4 * h]);
-          af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) af[i][j] = As[(8 * q + 4 * h + j) * AStager::LD + row];
+        for (int m = 0; m < NMFMA; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // 1 MFMA
+          if (m < NREAD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // 1 DS read
+          else if (m < NREAD + 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // 1 DS write
+          else if (m < NREAD + 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
         }
       }
-#pragma unroll
-      for (int i = 0; i < NT; ++i) {
-        const int col = wn * WTN + i * 32 + r;
-        if constexpr (BLAY == TECM_B_NK) {
-          const float4 v = *reinterpret_cast<const float4*>(&Bs[col * LDK + 8 * q + 4 * h]);
-          bf[i][0] = v.x; bf[i][1] = v.y; bf[i][2] = v.z; bf[i][3] = v.w;
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) bf[i][j] = Bs[(8 * q + 4 * h + j) * BStager::LD + col];
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int jn = 0; jn < NT; ++jn)
-            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][j], bf[jn][j], acc[i][jn], 0, 0, 0);
-    }
+    });
+  };
+
+  int cur = 0;
+  int32_t k0 = kbeg;
+  for (; k0 + 2 * BK < kend; k0 += BK) {                 // steady state
+    tile_body(smem + cur * TILE_FLOATS, smem + cur * TILE_FLOATS + A_FLOATS, smem + (cur ^ 1) * TILE_FLOATS, k0,
+              std::true_type{});
     __syncthreads();
-    if (more) {
-      sa.store(As);
-      sb.store(Bs);
-      __syncthreads();
-    }
+    cur ^= 1;
+  }
+  for (; k0 < kend; k0 += BK) {                          // last two tiles
+    tile_body(smem + cur * TILE_FLOATS, smem + cur * TILE_FLOATS + A_FLOATS, smem + (cur ^ 1) * TILE_FLOATS, k0,
+              std::false_type{});
+    __syncthreads();
+    cur ^= 1;
   }
 
   // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
-  // Each wave parks one 32-row slab of its accumulators in LDS (the operand tiles are dead by now) and
-  // walks it row by row: a row is wave-uniform (its offsets / window decomposition are scalar work),
-  // a lane keeps one column, and the global stores are whole contiguous row segments.
+  // Each wave parks its WTM x WTN accumulator block in LDS (the operand buffers are dead by now) and walks it
+  // row by row in ONE rolled loop (small code: the epilogue is executed once per block and must not thrash the
+  // instruction cache): row state is resolved once per row, a lane keeps its columns, and the global stores are
+  // whole contiguous row segments (float4 per lane when the host found every pointer / leading dimension
+  // 16-byte friendly: g._p0 == 1).
   const DropCtx odc = make_drop(g.out_drop);
   const bool split = gridDim.z > 1;
-  float* stg = smem + wave * (32 * STG_LD);
-  constexpr int ROWS_PER_IT = 64 / WTN;                  // 1 (WTN = 64) or 2 (WTN = 32)
-  const int lcol = lane % WTN, lrow = lane / WTN;
-  const EpiCol ecol = epi_col(g, n0 + wn * WTN + lcol);
+  float* stg = smem + wave * (WTM * STG_LD);
   static_for<MT>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
-    __syncthreads();                                     // previous slab consumed / MFMA loop's LDS reads done
     static_for<16>([&](auto ec) {
       constexpr int e = decltype(ec)::value;
       static_for<NT>([&](auto jc) {
         constexpr int jn = decltype(jc)::value;
-        stg[((e & 3) + 8 * (e >> 2) + 4 * h) * STG_LD + jn * 32 + r] = acc[i][jn][e];
+        stg[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * STG_LD + jn * 32 + r] = acc[i][jn][e];
       });
     });
-    __syncthreads();
-#pragma unroll 2
-    for (int it = 0; it < 32 / ROWS_PER_IT; ++it) {
-      const int rl = it * ROWS_PER_IT + lrow;
-      const int64_t m = m0 + wm * WTM + i * 32 + rl;
+  });
+  __syncthreads();
+  if (g._p0 != 0) {
+    constexpr int LPR = WTN / 4;                       // lanes per row
+    constexpr int RPI = 64 / LPR;                      // rows per iteration
+    const int lcol = (lane % LPR) * 4, lrow = lane / LPR;
+    const EpiCol ecol = epi_col(g, n0 + wn * WTN + lcol);
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.bias && ecol.ok) bias4 = *reinterpret_cast<const float4*>(g.bias + ecol.n);
+#pragma unroll 1
+    for (int it = 0; it < WTM / RPI; ++it) {
+      const int rl = it * RPI + lrow;
+      const int64_t m = m0 + wm * WTM + rl;
+      if (m < g.M && ecol.ok) {
+        const float4 v = *reinterpret_cast<const float4*>(&stg[rl * STG_LD + lcol]);
+        if (split) {
+          *reinterpret_cast<float4*>(g.workspace + ((int64_t)blockIdx.z * g.M + m) * g.N + ecol.n) = v;
+        } else {
+          const EpiRow er = epi_row(g, odc, m);
+          epi_vec4(g, odc, er, ecol, bias4, v);
+        }
+      }
+    }
+  } else {
+    constexpr int RPI = 64 / WTN;                      // 1 (WTN = 64) or 2 (WTN = 32)
+    const int lcol = lane % WTN, lrow = lane / WTN;
+    const EpiCol ecol = epi_col(g, n0 + wn * WTN + lcol);
+#pragma unroll 1
+    for (int it = 0; it < WTM / RPI; ++it) {
+      const int rl = it * RPI + lrow;
+      const int64_t m = m0 + wm * WTM + rl;
       if (m < g.M && ecol.ok) {
         const float v = stg[rl * STG_LD + lcol];
         if (split) {
@@ -467,7 +633,7 @@ __global__ __launch_bounds__(NTHREADS, (AVEC == 4 && BVEC == 4) ? 2 : 1) void ge
         }
       }
     }
-  });
+  }
 }
 
 template <int ALAY, int BLAY, int AVEC, int BVEC, int BN, bool WIN, bool DROP>

@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--gat", choices=["per_timestep", "reference"], default="per_timestep")
     ap.add_argument("--eval-mode", action="store_true", help="dropout off (diagnostics only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=1)
+    ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
 
@@ -68,7 +68,8 @@ def cpu_baseline(cfg, args):
     process may use, one timed step at B = --cpu-batch after a forward-only warm-up of allocator/threads."""
     from oracle import ref_cpu as R
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = min(cores, int(os.environ.get("TECM_CPU_THREADS", cores)))
+    # a 1-GPU box exposes every host core but grants a 16-core share; more threads only add contention
+    cores = min(cores, int(os.environ.get("TECM_CPU_THREADS", 16)))
     torch.set_num_threads(cores)
     params = R.init_params(cfg, seed=0)
     p = {k: v.clone().requires_grad_(R.is_trainable(k)) for k, v in params.items()}

@@ -23,6 +23,9 @@
 // variants (WIN / DROP) so the plain variant carries none of their code.
 #pragma once
 #include "common.h"
+#ifndef TECM_BIG_THREADS
+#define TECM_BIG_THREADS 512
+#endif
 #include <utility>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -43,7 +46,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 constexpr int BM = 128;
 constexpr int BK = 32;
 constexpr int LDK = BK + 4;
-constexpr int NTHREADS = 256;
+constexpr int NTHREADS_MAX = 512;
+__host__ __device__ constexpr int threads_for(int bn) { return bn >= 128 ? TECM_BIG_THREADS : 256; }
 
 struct DropCtx {
   uint64_t seed;
@@ -130,7 +134,7 @@ __device__ __forceinline__ WinRow win_row(const TecmWin& w, int64_t m, int64_t r
 
 // Tile stager.  ROWK=false: tile rows are the (fixed) M/N index, inner index is k  ([row][k], LD=36)
 //               ROWK=true : tile rows are k, inner index is the (fixed) M/N index ([k][row], LD=ROWS+4)
-template <bool ROWK, int ROWS, int VEC, bool WIN, bool DROP>
+template <bool ROWK, int ROWS, int VEC, bool WIN, bool DROP, int NTHREADS>
 struct Stager {
   static constexpr int R = ROWK ? BK : ROWS;
   static constexpr int CI = ROWK ? ROWS : BK;
@@ -411,23 +415,25 @@ __device__ __forceinline__ void epi_vec4(const TecmGemm& g, const DropCtx& odc, 
 }
 
 template <int ALAY, int BLAY, int AVEC, int BVEC, int BN, bool WIN, bool DROP>
-__global__ __launch_bounds__(NTHREADS, (AVEC == 4 && BVEC == 4) ? 2 : 1) void gemm_kernel(const TecmGemm g,
+__global__ __launch_bounds__(threads_for(BN), (AVEC == 4 && BVEC == 4) ? (threads_for(BN) == 512 ? 4 : 2) : 1) void gemm_kernel(const TecmGemm g,
                                                                                            int tiles_m, int tiles_n,
                                                                                            int k_chunk) {
-  constexpr int WN = BN >= 128 ? 2 : 1;
-  constexpr int WM = 4 / WN;
+  constexpr int NTHREADS = threads_for(BN);
+  constexpr int NWAVES = NTHREADS / 64;
+  constexpr int WN = BN >= 128 ? (NWAVES == 8 ? 4 : 2) : 1;
+  constexpr int WM = NWAVES / WN;
   constexpr int WTM = BM / WM;
   constexpr int WTN = BN / WN;
   constexpr int MT = WTM / 32;
   constexpr int NT = WTN / 32;
-  using AStager = Stager<ALAY == TECM_A_KM, BM, AVEC, WIN, DROP>;
-  using BStager = Stager<BLAY == TECM_B_KN, BN, BVEC, WIN, DROP>;
+  using AStager = Stager<ALAY == TECM_A_KM, BM, AVEC, WIN, DROP, NTHREADS>;
+  using BStager = Stager<BLAY == TECM_B_KN, BN, BVEC, WIN, DROP, NTHREADS>;
   constexpr int A_FLOATS = AStager::R * AStager::LD;
   constexpr int B_FLOATS = BStager::R * BStager::LD;
   constexpr int TILE_FLOATS = A_FLOATS + B_FLOATS;
   constexpr int STG_LD = WTN + 4;                       // epilogue staging: 32 rows x WTN cols per wave, 16-B rows
   // two operand buffers: tile t+1 is written into the idle one between the MFMAs of tile t (one barrier per tile)
-  constexpr int STG_FLOATS = 4 * WTM * STG_LD;          // whole accumulator block of the 4 waves
+  constexpr int STG_FLOATS = NWAVES * WTM * STG_LD;          // whole accumulator block of the 4 waves
   constexpr int SMEM_FLOATS = 2 * TILE_FLOATS > STG_FLOATS ? 2 * TILE_FLOATS : STG_FLOATS;
   __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
 
@@ -644,7 +650,7 @@ int launch(const TecmGemm& g, hipStream_t st) {
   int k_chunk = (int)(((g.K + splits - 1) / splits + BK - 1) / BK) * BK;
   splits = (int)((g.K + k_chunk - 1) / k_chunk);
   dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)splits);
-  hipLaunchKernelGGL((gemm_kernel<ALAY, BLAY, AVEC, BVEC, BN, WIN, DROP>), grid, dim3(NTHREADS), 0, st, g, tiles_m,
+  hipLaunchKernelGGL((gemm_kernel<ALAY, BLAY, AVEC, BVEC, BN, WIN, DROP>), grid, dim3(threads_for(BN)), 0, st, g, tiles_m,
                      tiles_n, k_chunk);
   TECM_CHECK_LAUNCH("tecm_gemm_f32");
   return splits;      // > 0: number of K splits actually launched

@@ -30,6 +30,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16
 HBM_PEAK_GBS = 8000.0
 
 
@@ -43,6 +44,8 @@ def parse():
     ap.add_argument("--L_out", type=int, default=12)
     ap.add_argument("--c_in", type=int, default=10, help="raw feature width F (BASELINE: 10 -> d_emb 12)")
     ap.add_argument("--gat", choices=["per_timestep", "reference"], default="per_timestep")
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
+                    help="fp32 = BASELINE configs[1] (exact-f32 MFMA); bf16 = configs[2] (bf16 MFMA, fp32 accumulate)")
     ap.add_argument("--eval-mode", action="store_true", help="dropout off (diagnostics only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
@@ -116,7 +119,7 @@ def main():
     from oracle.ref_cpu import grid_graph, synthetic_batch       # synthetic inputs only (no oracle compute)
 
     cfg = make_config(args)
-    mc = dict(cfg, gat_graphs=args.gat, include_wte=False, load_pretrained_gpt2=False)
+    mc = dict(cfg, gat_graphs=args.gat, include_wte=False, load_pretrained_gpt2=False, precision=args.precision)
     torch.manual_seed(0)                                           # identical weights on every rank
     model = TEC_MoLLM(mc)
     with torch.no_grad():                                          # exercise the LoRA path (peft inits B = 0)
@@ -161,8 +164,9 @@ def main():
             if agg:
                 name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
                 achieved = a["flops"] / (a["ms"] * 1e-3) / 1e12
-                roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                peak = BF16_MFMA_PEAK_TFLOPS if "bf16" in name else F32_MFMA_PEAK_TFLOPS
+                roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak,
+                        "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
                         "launches": a["n"], "avg_launch_ms": round(a["ms"] / a["n"], 4),
                         "share_of_step": round(a["ms"] / (dt * 1e3), 4),
                         "all_gemm_share_of_step": round(sum(v["ms"] for v in agg.values()) / (dt * 1e3), 4)}
@@ -170,9 +174,11 @@ def main():
             "metric": "train samples/sec", "value": round(total / dt, 3), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: B={B}/GPU, L_in={args.L_in}, L_out={args.L_out}, N=2911, "
-                                   f"F={args.c_in} (d_emb={22 - args.c_in}), full fwd+bwd+AdamW, fp32, "
+            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[{1 if args.precision == 'fp32' else 2}]: B={B}/GPU, "
+                                   f"L_in={args.L_in}, L_out={args.L_out}, N=2911, "
+                                   f"F={args.c_in} (d_emb={22 - args.c_in}), full fwd+bwd+AdamW, "
+                                   f"{'fp32' if args.precision == 'fp32' else 'bf16 MFMA / fp32 accumulate'}, "
                                    f"GATv2 {args.gat}, dropout {'off' if args.eval_mode else 'on (p=0.1)'}",
                        "global_batch": B * world, "parallelism": f"dp{world}", "final_loss": round(float(loss), 5)},
             "roofline": roof,

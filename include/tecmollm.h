@@ -94,6 +94,10 @@ typedef struct TecmGemm {
   float* workspace;            /* >= split_k*M*N floats when split_k > 1 */
 } TecmGemm;
 int tecm_gemm_f32(const TecmGemm* desc, void* stream);
+/* Same contract on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16): operands are rounded to bf16 (RNE) while
+ * staged into LDS, accumulation / epilogue / outputs stay fp32 -- what torch.autocast(bf16) does to the inputs
+ * of Linear / Conv1d / Conv1D (train.py:68).  Operands must be 16-byte friendly (else TECM_E_ALIGN). */
+int tecm_gemm_bf16(const TecmGemm* desc, void* stream);
 
 /* ------------------------------------------------------------------ stage a-1..a-3 (fused)
  * SpatioTemporalEmbedding.forward (modules.py:230-266) + GATv2Conv (modules.py:329-336,:356)

@@ -131,29 +131,39 @@ def spatial(h: torch.Tensor, edge_index: torch.Tensor, p: Params, heads: int,
 
 
 # ------------------------------------------------------------------- stage a-4/a-5
-def conv_block(x: torch.Tensor, p: Params, idx: int, stride: int) -> torch.Tensor:
-    """Multi_Scale_Conv_Block.forward, modules.py:43-60: x (S, C_in, L)."""
+def bf16_round(t: torch.Tensor) -> torch.Tensor:
+    """Round to bf16 (RNE) and back: what the bf16 MFMA path does to GEMM operands (autocast semantics)."""
+    return t.bfloat16().float()
+
+
+def _ident(t: torch.Tensor) -> torch.Tensor:
+    return t
+
+
+def conv_block(x: torch.Tensor, p: Params, idx: int, stride: int, q=_ident) -> torch.Tensor:
+    """Multi_Scale_Conv_Block.forward, modules.py:43-60: x (S, C_in, L).
+    q: operand rounding of the dense contractions (identity = fp32; bf16_round emulates the bf16 MFMA mode)."""
     outs = []
     for j, k in enumerate((3, 5, 7)):
         pre = f"{P_CONV}{idx}.convs.{j}."
-        y = F.conv1d(x, p[pre + "0.weight"], p[pre + "0.bias"], padding=(k - 1) // 2)
+        y = F.conv1d(q(x), q(p[pre + "0.weight"]), p[pre + "0.bias"], padding=(k - 1) // 2)
         y = F.group_norm(y, 1, p[pre + "1.weight"], p[pre + "1.bias"], eps=1e-5)
         outs.append(F.gelu(y))
     cat = torch.cat(outs, dim=1)
     pre = f"{P_CONV}{idx}.final_conv."
-    return F.conv1d(cat, p[pre + "weight"], p[pre + "bias"], stride=stride)
+    return F.conv1d(q(cat), q(p[pre + "weight"]), p[pre + "bias"], stride=stride)
 
 
-def temporal_encoder(x: torch.Tensor, p: Params, strides, patch_len: int) -> torch.Tensor:
+def temporal_encoder(x: torch.Tensor, p: Params, strides, patch_len: int, q=_ident) -> torch.Tensor:
     """TemporalEncoder.forward modules.py:134-154 + LatentPatchingProjection :100-119.
     x (S, L, C) -> (S, P, d_llm).  Patch vector index = l*D + d (einops 'b (p l) d -> b p (l d)')."""
     y = x.permute(0, 2, 1)
     for i, s in enumerate(strides):
-        y = conv_block(y, p, i, s)
+        y = conv_block(y, p, i, s, q)
     y = y.permute(0, 2, 1)                                   # (S, L', D)
     S, Lc, D = y.shape
     y = y.reshape(S, Lc // patch_len, patch_len * D)
-    return y @ p[P_PATCH + "weight"].t() + p[P_PATCH + "bias"]
+    return q(y) @ q(p[P_PATCH + "weight"]).t() + p[P_PATCH + "bias"]
 
 
 # ------------------------------------------------------------------- stage a-6
@@ -162,7 +172,7 @@ def gelu_new(x: torch.Tensor) -> torch.Tensor:
     return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * x.pow(3))))
 
 
-def gpt2_lora(h: torch.Tensor, p: Params, n_layers: int) -> torch.Tensor:
+def gpt2_lora(h: torch.Tensor, p: Params, n_layers: int, q=_ident) -> torch.Tensor:
     """LLMBackbone.forward modules.py:205-209 -> peft(GPT2Model)(inputs_embeds=h, all-ones mask).
     Eval-mode (all dropouts off).  h (S, T, 768).  c_attn' = base Conv1D + 2.0 * B(A(u))."""
     S, T, D = h.shape
@@ -172,44 +182,47 @@ def gpt2_lora(h: torch.Tensor, p: Params, n_layers: int) -> torch.Tensor:
     for i in range(n_layers):
         pre = f"{P_GPT}h.{i}."
         u = F.layer_norm(h, (D,), p[pre + "ln_1.weight"], p[pre + "ln_1.bias"], LN_EPS)
-        qkv = u @ p[pre + "attn.c_attn.base_layer.weight"] + p[pre + "attn.c_attn.base_layer.bias"]
         A = p[pre + "attn.c_attn.lora_A.default.weight"]     # (r, 768)
         Bm = p[pre + "attn.c_attn.lora_B.default.weight"]    # (2304, r)
-        qkv = qkv + LORA_SCALE * ((u @ A.t()) @ Bm.t())
-        q, k, v = qkv.split(D, dim=-1)
-        q = q.view(S, T, GPT2_HEADS, hd).transpose(1, 2)
+        z = u @ A.t()                                        # 32 output columns: stays on the exact fp32 kernel
+        qkv = q(u) @ q(p[pre + "attn.c_attn.base_layer.weight"]) + p[pre + "attn.c_attn.base_layer.bias"]
+        qkv = qkv + q(z) @ q(LORA_SCALE * Bm.t())            # one K-extended GEMM in the HIP path
+        qq, k, v = qkv.split(D, dim=-1)
+        qq = qq.view(S, T, GPT2_HEADS, hd).transpose(1, 2)
         k = k.view(S, T, GPT2_HEADS, hd).transpose(1, 2)
         v = v.view(S, T, GPT2_HEADS, hd).transpose(1, 2)
-        w = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
+        w = (qq @ k.transpose(-1, -2)) / math.sqrt(hd)
         w = w.masked_fill(~causal, float("-inf")).softmax(-1)
         ctx = (w @ v).transpose(1, 2).reshape(S, T, D)
-        h = h + ctx @ p[pre + "attn.c_proj.weight"] + p[pre + "attn.c_proj.bias"]
+        h = h + q(ctx) @ q(p[pre + "attn.c_proj.weight"]) + p[pre + "attn.c_proj.bias"]
         u = F.layer_norm(h, (D,), p[pre + "ln_2.weight"], p[pre + "ln_2.bias"], LN_EPS)
-        f = gelu_new(u @ p[pre + "mlp.c_fc.weight"] + p[pre + "mlp.c_fc.bias"])
-        h = h + f @ p[pre + "mlp.c_proj.weight"] + p[pre + "mlp.c_proj.bias"]
+        f = gelu_new(q(u) @ q(p[pre + "mlp.c_fc.weight"]) + p[pre + "mlp.c_fc.bias"])
+        h = h + q(f) @ q(p[pre + "mlp.c_proj.weight"]) + p[pre + "mlp.c_proj.bias"]
     return F.layer_norm(h, (D,), p[P_GPT + "ln_f.weight"], p[P_GPT + "ln_f.bias"], LN_EPS)
 
 
 # ------------------------------------------------------------------- stage a-8
-def head(x: torch.Tensor, p: Params) -> torch.Tensor:
-    """PredictionHead.forward modules.py:295-313 (eval): (S,T,768) -> (S, L_out)."""
+def head(x: torch.Tensor, p: Params, q=_ident) -> torch.Tensor:
+    """PredictionHead.forward modules.py:295-313 (eval): (S,T,768) -> (S, L_out).
+    The 12-column output layer stays fp32 in the bf16 mode (fewer than 64 output columns)."""
     z = x.reshape(x.shape[0], -1)
-    z = F.gelu(z @ p[P_HEAD + "0.weight"].t() + p[P_HEAD + "0.bias"])
+    z = F.gelu(q(z) @ q(p[P_HEAD + "0.weight"]).t() + p[P_HEAD + "0.bias"])
     return z @ p[P_HEAD + "3.weight"].t() + p[P_HEAD + "3.bias"]
 
 
 # ------------------------------------------------------------------- full path
 def forward(x: torch.Tensor, tf: torch.Tensor, edge_index: torch.Tensor, p: Params, cfg: dict,
-            graphs_with_edges: Optional[int] = 1) -> torch.Tensor:
-    """TEC_MoLLM.forward tec_mollm.py:59-125, eval mode.  Returns (B, L_out, N, 1)."""
+            graphs_with_edges: Optional[int] = 1, q=_ident) -> torch.Tensor:
+    """TEC_MoLLM.forward tec_mollm.py:59-125, eval mode.  Returns (B, L_out, N, 1).
+    q=bf16_round emulates the bf16 MFMA mode (GATv2's 22x22 transforms stay fp32 there)."""
     B, L, N, _ = x.shape
     h = embed(x, tf, p)
     xs = spatial(h, edge_index, p, cfg["spatial_heads"], graphs_with_edges)
     C = xs.shape[-1]
     xt = xs.view(L, B, N, C).permute(1, 2, 0, 3).reshape(B * N, L, C)
-    tok = temporal_encoder(xt, p, cfg["temporal_strides"], cfg["patch_len"])
-    hid = gpt2_lora(tok, p, cfg["llm_layers"])
-    pred = head(hid, p)
+    tok = temporal_encoder(xt, p, cfg["temporal_strides"], cfg["patch_len"], q)
+    hid = gpt2_lora(tok, p, cfg["llm_layers"], q)
+    pred = head(hid, p, q)
     return pred.view(B, N, -1).permute(0, 2, 1).unsqueeze(-1)
 
 

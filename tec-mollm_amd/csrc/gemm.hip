@@ -1,6 +1,6 @@
 // extern "C" entry point of the fp32 MFMA GEMM (kernel template: gemm_impl.h; instantiations:
 // gemm_mk_nk.hip, gemm_mk_kn.hip, gemm_km_kn.hip -- one translation unit per operand-layout pair).
-#include "gemm_impl.h"
+#include "gemm_bf16_impl.h"
 
 namespace {
 
@@ -50,7 +50,16 @@ bool win_ok(const TecmWin& w) {
 
 }  // namespace
 
-extern "C" int tecm_gemm_f32(const TecmGemm* d, void* stream) {
+static int gemm_entry(const TecmGemm* d, void* stream, bool bf16);
+
+extern "C" int tecm_gemm_f32(const TecmGemm* d, void* stream) { return gemm_entry(d, stream, false); }
+
+// Same contract as tecm_gemm_f32, operands rounded to bf16 on the way into LDS, fp32 accumulate / epilogue /
+// outputs.  Needs 16-byte friendly operands (the float4 loader); returns TECM_E_ALIGN otherwise so that the
+// caller can decide to use tecm_gemm_f32 for that call.
+extern "C" int tecm_gemm_bf16(const TecmGemm* d, void* stream) { return gemm_entry(d, stream, true); }
+
+static int gemm_entry(const TecmGemm* d, void* stream, bool bf16) {
   TECM_REQUIRE(d != nullptr, TECM_E_ARG, "tecm_gemm_f32: null descriptor");
   const TecmGemm& g = *d;
   TECM_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, TECM_E_ARG, "tecm_gemm_f32: M,N,K must be positive (%lld,%lld,%lld)",
@@ -84,6 +93,9 @@ extern "C" int tecm_gemm_f32(const TecmGemm* d, void* stream) {
                     ok4(g.preact, g.ldp) && ok4(g.dact_src, g.ldd) && ok4(g.residual, g.ldr) &&
                     (!g.c_win.enabled || g.c_win.Cw % 4 == 0) &&
                     (g.split_k <= 1 || tecm_aligned(g.workspace, 16));
+  if (bf16)
+    TECM_REQUIRE(avec == 4 && bvec == 4, TECM_E_ALIGN,
+                 "tecm_gemm_bf16: operands must be 16-byte aligned with leading dims / K / Cw multiples of 4");
   TecmGemm gk = g;                 // private copy: _p0 carries the epilogue-vectorisation flag to the kernel
   gk._p0 = vec4 ? 1 : 0;
   const bool erf = g.act == TECM_ACT_GELU_ERF;
@@ -95,7 +107,14 @@ extern "C" int tecm_gemm_f32(const TecmGemm* d, void* stream) {
     gk.out_drop.p = 0.f;
   }
   int splits;
-  if (g.a_layout == TECM_A_MK && g.b_layout == TECM_B_NK)
+  if (bf16) {
+    if (g.a_layout == TECM_A_MK && g.b_layout == TECM_B_NK)
+      splits = tecm_gemm16_dispatch_mk_nk(gk, win, drop, st);
+    else if (g.a_layout == TECM_A_MK)
+      splits = tecm_gemm16_dispatch_mk_kn(gk, win, drop, st);
+    else
+      splits = tecm_gemm16_dispatch_km_kn(gk, win, drop, st);
+  } else if (g.a_layout == TECM_A_MK && g.b_layout == TECM_B_NK)
     splits = tecm_gemm_dispatch_mk_nk(gk, avec, bvec, win, drop, st);
   else if (g.a_layout == TECM_A_MK)
     splits = tecm_gemm_dispatch_mk_kn(gk, avec, bvec, win, drop, st);

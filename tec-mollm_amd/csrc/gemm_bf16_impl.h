@@ -1,0 +1,440 @@
+// bf16 MFMA GEMM (v_mfma_f32_32x32x16_bf16, fp32 accumulate) for BASELINE configs[2]
+// ("bf16 autocast, MFMA QKV/proj"): same descriptor, views, prologue dropout and epilogue as the fp32 kernel
+// (gemm_impl.h); only the operand path differs.
+//
+//   * tensors stay fp32 in HBM; each operand element is rounded to bf16 (RNE, v_cvt_pk_bf16_f32) while it is
+//     staged into LDS -- exactly what torch.autocast does to the inputs of Linear / Conv1d / Conv1D
+//     (reference train.py:68), with fp32 accumulation and fp32 outputs;
+//   * block = 512 threads = 8 waves as 4(m) x 2(n), tile 256 x 128 x 64; a wave owns 64 x 64 = 2 x 2 MFMA
+//     tiles (64 accumulator VGPRs) and issues 16 MFMAs per K-tile;
+//   * LDS tiles are ALWAYS [row][k] bf16 with a 144-byte row pitch (64 k + 8 pad): a fragment (8 consecutive k
+//     of one row) is one conflict-free ds_read_b128.  Sources whose contiguous dimension is the row index
+//     ([k][m] / [k][n]: the KM / KN layouts) are transposed on the way in: a thread loads the float4s of two
+//     adjacent k rows and writes four packed (k, k+1) bf16 pairs with ds_write_b32;
+//   * two LDS operand buffers, one barrier per K-tile, tile t+1 parked / tile t+2 fetched between the MFMAs
+//     of tile t (same pipeline as the fp32 kernel).
+#pragma once
+#include "gemm_impl.h"
+
+namespace tecm_gemm16 {
+
+using tecm_gemm::DropCtx;
+using tecm_gemm::EpiCol;
+using tecm_gemm::EpiRow;
+using tecm_gemm::WinRow;
+using tecm_gemm::apply_drop;
+using tecm_gemm::epi_col;
+using tecm_gemm::epi_elem;
+using tecm_gemm::epi_row;
+using tecm_gemm::epi_vec4;
+using tecm_gemm::gload;
+using tecm_gemm::make_drop;
+using tecm_gemm::static_for;
+using tecm_gemm::win_row;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int BM = 256;
+constexpr int BN = 128;
+constexpr int BK = 64;
+constexpr int NTH = 512;
+constexpr int LDH = BK + 8;          // LDS row pitch in bf16 elements (144 B: conflict-free b128 fragment reads)
+
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+  bf16x2 v;
+  v[0] = (__bf16)lo;                 // plain casts: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN-safe)
+  v[1] = (__bf16)hi;
+  return __builtin_bit_cast(uint32_t, v);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Direct stager: source rows are the tile rows, k contiguous ([m][k] / [n][k]).  One vector = float4 along k.
+template <int ROWS, bool WIN, bool DROP>
+struct DStager {
+  static constexpr int VPR = BK / 4;                  // 16 vectors per row
+  static constexpr int NV = ROWS * VPR / NTH;         // 8 (A) or 4 (B)
+  static constexpr int RSTEP = NTH / VPR;             // 32 rows between a thread's vectors
+  static constexpr int NITEMS = NV;
+  float regs[NV][4];
+  const float* ptr[NV];
+  uint32_t rowok, okbits;
+  int64_t didx[DROP ? NV : 1], dsave[DROP ? NV : 1];
+  WinRow wr[WIN ? NV : 1];
+  int32_t tap, c, kk;
+
+  __device__ __forceinline__ void init(const float* __restrict__ P, const TecmWin& w, int64_t ld, int64_t row0,
+                                       int64_t rows_total, int32_t kbeg, const DropCtx& dc) {
+    const int cv = (threadIdx.x % VPR) * 4;
+    const int r0 = threadIdx.x / VPR;
+    rowok = 0;
+    okbits = 0;
+    tap = 0;
+    c = 0;
+    kk = kbeg + cv;
+    const bool wen = WIN && w.enabled;
+    if (!wen) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int64_t row = row0 + r0 + i * RSTEP;
+        if (row < rows_total) rowok |= 1u << i;
+        ptr[i] = P + row * ld + kbeg + cv;
+        if constexpr (DROP) didx[i] = row * dc.ld + kbeg + cv;
+      }
+    } else if constexpr (WIN) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) wr[i] = win_row(w, row0 + r0 + i * RSTEP, rows_total);
+      tap = kk / w.Cw;
+      c = kk - tap * w.Cw;
+    }
+  }
+  template <int IB, int IE>
+  __device__ __forceinline__ void load_part(const float* __restrict__ P, const TecmWin& w, int64_t ld, int32_t k0,
+                                            int32_t klim, const DropCtx& dc) {
+    if constexpr (IB >= IE) return;
+    constexpr bool LAST = IE == NV;
+    const bool wen = WIN && w.enabled;
+    const bool kok = kk < klim;
+    if (!wen) {
+#pragma unroll
+      for (int i = IB; i < IE; ++i) {
+        const bool ok = kok && ((rowok >> i) & 1u);
+        gload<4>(ptr[i], P, ok, regs[i]);
+        okbits = (okbits & ~(1u << i)) | ((ok ? 1u : 0u) << i);
+        if constexpr (DROP) { dsave[i] = didx[i]; didx[i] += BK; }
+        ptr[i] += BK;
+      }
+      if constexpr (LAST) kk += BK;
+    } else if constexpr (WIN) {
+      const int64_t tapoff = (int64_t)tap * w.N;
+#pragma unroll
+      for (int i = IB; i < IE; ++i) {
+        const int32_t t_in = wr[i].t0 + tap;
+        const bool ok = kok && t_in >= 0 && t_in < w.Lin;
+        const int64_t row = wr[i].srow + tapoff;
+        gload<4>(P + row * ld + c, P, ok, regs[i]);
+        okbits = (okbits & ~(1u << i)) | ((ok ? 1u : 0u) << i);
+        if constexpr (DROP) dsave[i] = row * dc.ld + c;
+      }
+      if constexpr (LAST) {
+        kk += BK;
+        c += BK;
+        while (c >= w.Cw) { c -= w.Cw; ++tap; }
+      }
+    }
+    (void)k0;
+  }
+  template <int IB, int IE>
+  __device__ __forceinline__ void store_part(__bf16* lds, const DropCtx& dc) {
+    if constexpr (IB >= IE) return;
+    const int cv = (threadIdx.x % VPR) * 4;
+    const int r0 = threadIdx.x / VPR;
+#pragma unroll
+    for (int i = IB; i < IE; ++i) {
+      float v[4];
+      const bool ok = (okbits >> i) & 1u;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = ok ? regs[i][e] : 0.f;
+      if constexpr (DROP) apply_drop<4>(dc, dsave[i], v);
+      uint2 pk;
+      pk.x = pack_bf16(v[0], v[1]);
+      pk.y = pack_bf16(v[2], v[3]);
+      *reinterpret_cast<uint2*>(lds + (r0 + i * RSTEP) * LDH + cv) = pk;
+    }
+  }
+};
+
+// Transposing stager: source rows are k, the tile-row index is contiguous ([k][m] / [k][n]).
+// One item = k rows (2kp, 2kp+1) x 4 consecutive tile rows: two float4 loads, four ds_write_b32 of (k,k+1) pairs.
+template <int ROWS, bool WIN, bool DROP>
+struct TStager {
+  static constexpr int QPR = ROWS / 4;                // row quads per k pair
+  static constexpr int NI = (BK / 2) * QPR / NTH;     // 4 (A, 256 rows) or 2 (B, 128 rows)
+  static constexpr int KSTEP = NTH / QPR;             // k pairs between a thread's items
+  static constexpr int NITEMS = NI;
+  float regs[NI][8];
+  const float* ptr[NI];
+  bool inner_ok;
+  uint32_t okbits;                                    // bit 2i: row 2kp valid, bit 2i+1: row 2kp+1 valid
+  int64_t didx[DROP ? NI : 1], dsave[DROP ? NI : 1], dsave_hi[DROP ? NI : 1];
+  int32_t tap, c, inner;
+
+  __device__ __forceinline__ void init(const float* __restrict__ P, const TecmWin& w, int64_t ld, int32_t kbeg,
+                                       int64_t fixed0, int64_t fixed_lim, const DropCtx& dc) {
+    const int q4 = (threadIdx.x % QPR) * 4;
+    const int kp0 = threadIdx.x / QPR;
+    inner = (int32_t)(fixed0 + q4);
+    inner_ok = inner < fixed_lim;
+    okbits = 0;
+    tap = 0;
+    c = 0;
+    const bool wen = WIN && w.enabled;
+    if (!wen) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int64_t krow = (int64_t)kbeg + 2 * (kp0 + i * KSTEP);
+        ptr[i] = P + krow * ld + inner;
+        if constexpr (DROP) didx[i] = krow * dc.ld + inner;
+      }
+    } else if constexpr (WIN) {
+      tap = inner / w.Cw;
+      c = inner - tap * w.Cw;
+    }
+  }
+  template <int IB, int IE>
+  __device__ __forceinline__ void load_part(const float* __restrict__ P, const TecmWin& w, int64_t ld, int32_t k0,
+                                            int32_t klim, const DropCtx& dc) {
+    if constexpr (IB >= IE) return;
+    const int kp0 = threadIdx.x / QPR;
+    const bool wen = WIN && w.enabled;
+#pragma unroll
+    for (int i = IB; i < IE; ++i) {
+      const int32_t krow = k0 + 2 * (kp0 + i * KSTEP);
+      bool ok0, ok1;
+      float lo[4], hi[4];
+      if (!wen) {
+        ok0 = inner_ok && krow < klim;
+        ok1 = inner_ok && krow + 1 < klim;
+        gload<4>(ptr[i], P, ok0, lo);
+        gload<4>(ptr[i] + ld, P, ok1, hi);
+        if constexpr (DROP) { dsave[i] = didx[i]; dsave_hi[i] = didx[i] + dc.ld; didx[i] += (int64_t)BK * dc.ld; }
+        ptr[i] += (int64_t)BK * ld;
+      } else {
+        // window rows are the reduction index (weight-gradient form): decompose both k rows
+        const WinRow ra = win_row(w, krow, klim), rb = win_row(w, krow + 1, klim);
+        const int32_t ta = ra.t0 + tap, tb = rb.t0 + tap;
+        ok0 = inner_ok && ta >= 0 && ta < w.Lin;
+        ok1 = inner_ok && tb >= 0 && tb < w.Lin;
+        const int64_t rowa = ra.srow + (int64_t)tap * w.N, rowb = rb.srow + (int64_t)tap * w.N;
+        gload<4>(P + rowa * ld + c, P, ok0, lo);
+        gload<4>(P + rowb * ld + c, P, ok1, hi);
+        if constexpr (DROP) { dsave[i] = rowa * dc.ld + c; dsave_hi[i] = rowb * dc.ld + c; }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { regs[i][e] = lo[e]; regs[i][4 + e] = hi[e]; }
+      okbits = (okbits & ~(3u << (2 * i))) | ((ok0 ? 1u : 0u) << (2 * i)) | ((ok1 ? 1u : 0u) << (2 * i + 1));
+    }
+  }
+  template <int IB, int IE>
+  __device__ __forceinline__ void store_part(__bf16* lds, const DropCtx& dc) {
+    if constexpr (IB >= IE) return;
+    const int q4 = (threadIdx.x % QPR) * 4;
+    const int kp0 = threadIdx.x / QPR;
+#pragma unroll
+    for (int i = IB; i < IE; ++i) {
+      float lo[4], hi[4];
+      const bool ok0 = (okbits >> (2 * i)) & 1u, ok1 = (okbits >> (2 * i + 1)) & 1u;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { lo[e] = ok0 ? regs[i][e] : 0.f; hi[e] = ok1 ? regs[i][4 + e] : 0.f; }
+      if constexpr (DROP) {
+        apply_drop<4>(dc, dsave[i], lo);
+        apply_drop<4>(dc, dsave_hi[i], hi);
+      }
+      const int kcol = 2 * (kp0 + i * KSTEP);
+      uint32_t* base = reinterpret_cast<uint32_t*>(lds + q4 * LDH + kcol);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) base[e * (LDH / 2)] = pack_bf16(lo[e], hi[e]);
+    }
+  }
+};
+
+template <bool TRANS, int ROWS, bool WIN, bool DROP>
+struct StagerSel {
+  using type = DStager<ROWS, WIN, DROP>;
+};
+template <int ROWS, bool WIN, bool DROP>
+struct StagerSel<true, ROWS, WIN, DROP> {
+  using type = TStager<ROWS, WIN, DROP>;
+};
+
+template <int ALAY, int BLAY, bool WIN, bool DROP>
+__global__ __launch_bounds__(NTH, 2) void gemm_bf16_kernel(const TecmGemm g, int tiles_m, int tiles_n, int k_chunk) {
+  constexpr int WN = 2, WM = 4;
+  constexpr int WTM = BM / WM, WTN = BN / WN;          // 64 x 64 per wave
+  constexpr int MT = WTM / 32, NT = WTN / 32;
+  constexpr bool ATR = ALAY == TECM_A_KM, BTR = BLAY == TECM_B_KN;
+  using AStager = typename StagerSel<ATR, BM, WIN, DROP>::type;
+  using BStager = typename StagerSel<BTR, BN, WIN, DROP>::type;
+  constexpr int A_ELEMS = BM * LDH, B_ELEMS = BN * LDH, TILE_ELEMS = A_ELEMS + B_ELEMS;   // bf16 elements
+  constexpr int STG_LD = WTN + 4;
+  constexpr int STG_BYTES = 8 * 32 * STG_LD * 4;       // one 32-row slab per wave, fp32
+  constexpr int SMEM_BYTES = 2 * TILE_ELEMS * 2 > STG_BYTES ? 2 * TILE_ELEMS * 2 : STG_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_BYTES];
+  __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);
+
+  // XCD-aware bijective block -> tile map with 8-m-tile groups (see gemm_impl.h)
+  const int nwg = tiles_m * tiles_n;
+  const int id = blockIdx.x;
+  const int xcd = id & 7, local = id >> 3;
+  const int q8 = nwg >> 3, r8 = nwg & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
+  constexpr int GROUP_M = 4;
+  const int per_group = GROUP_M * tiles_n;
+  const int group = wg / per_group;
+  const int first_m = group * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int in_group = wg - group * per_group;
+  const int tm = first_m + in_group % gsz, tn = in_group / gsz;
+  const int64_t m0 = (int64_t)tm * BM;
+  const int64_t n0 = (int64_t)tn * BN;
+  const int32_t kbeg = blockIdx.z * k_chunk;
+  const int32_t kend = min((int32_t)g.K, kbeg + k_chunk);
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 31, h = lane >> 5;
+  const DropCtx adc = make_drop(g.a_drop), bdc = make_drop(g.b_drop);
+
+  AStager sa;
+  BStager sb;
+  if constexpr (ATR) sa.init(g.A, g.a_win, g.lda, kbeg, m0, g.M, adc);
+  else sa.init(g.A, g.a_win, g.lda, m0, g.M, kbeg, adc);
+  if constexpr (BTR) sb.init(g.B, g.b_win, g.ldb, kbeg, n0, g.N, bdc);
+  else sb.init(g.B, g.b_win, g.ldb, n0, g.N, kbeg, bdc);
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  auto a_store = [&](auto ib, auto ie, __bf16* dst) {
+    sa.template store_part<decltype(ib)::value, decltype(ie)::value>(dst, adc);
+  };
+  auto b_store = [&](auto ib, auto ie, __bf16* dst) {
+    sb.template store_part<decltype(ib)::value, decltype(ie)::value>(dst, bdc);
+  };
+  constexpr int ANV = AStager::NITEMS;
+  constexpr int BNV = BStager::NITEMS;
+  using I0 = std::integral_constant<int, 0>;
+
+  // prologue: tile 0 -> LDS buffer 0, tile 1 -> registers (in flight)
+  sa.template load_part<0, ANV>(g.A, g.a_win, g.lda, kbeg, kend, adc);
+  sb.template load_part<0, BNV>(g.B, g.b_win, g.ldb, kbeg, kend, bdc);
+  a_store(I0{}, std::integral_constant<int, ANV>{}, smem);
+  b_store(I0{}, std::integral_constant<int, BNV>{}, smem + A_ELEMS);
+  if (kbeg + BK < kend) {
+    sa.template load_part<0, ANV>(g.A, g.a_win, g.lda, kbeg + BK, kend, adc);
+    sb.template load_part<0, BNV>(g.B, g.b_win, g.ldb, kbeg + BK, kend, bdc);
+  }
+  __syncthreads();
+
+  int cur = 0;
+  for (int32_t k0 = kbeg; k0 < kend; k0 += BK) {
+    const __bf16* Ac = smem + cur * TILE_ELEMS;
+    const __bf16* Bc = Ac + A_ELEMS;
+    __bf16* An = smem + (cur ^ 1) * TILE_ELEMS;
+    static_for<4>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;              // k-step of 16 inside the 64-deep tile
+      bf16x8 af[MT], bf[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+        af[i] = *reinterpret_cast<const bf16x8*>(Ac + (wm * WTM + i * 32 + r) * LDH + 16 * s + 8 * h);
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+        bf[i] = *reinterpret_cast<const bf16x8*>(Bc + (wn * WTN + i * 32 + r) * LDH + 16 * s + 8 * h);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int jn = 0; jn < NT; ++jn)
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[jn], acc[i][jn], 0, 0, 0);
+      // a quarter of the staging work per k-step (see gemm_impl.h)
+      constexpr int AB = (ANV * s) / 4, AE = (ANV * (s + 1)) / 4;
+      constexpr int BB = (BNV * s) / 4, BE = (BNV * (s + 1)) / 4;
+      if (k0 + BK < kend) {
+        a_store(std::integral_constant<int, AB>{}, std::integral_constant<int, AE>{}, An);
+        b_store(std::integral_constant<int, BB>{}, std::integral_constant<int, BE>{}, An + A_ELEMS);
+      }
+      if (k0 + 2 * BK < kend) {
+        sa.template load_part<AB, AE>(g.A, g.a_win, g.lda, k0 + 2 * BK, kend, adc);
+        sb.template load_part<BB, BE>(g.B, g.b_win, g.ldb, k0 + 2 * BK, kend, bdc);
+      }
+    });
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: identical to the fp32 kernel's, two 32-row slabs per wave through LDS
+  const DropCtx odc = make_drop(g.out_drop);
+  const bool split = gridDim.z > 1;
+  float* stg = reinterpret_cast<float*>(smem_raw) + wave * (32 * STG_LD);
+  static_for<MT>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    if (i > 0) __syncthreads();
+    static_for<16>([&](auto ec) {
+      constexpr int e = decltype(ec)::value;
+      static_for<NT>([&](auto jc) {
+        constexpr int jn = decltype(jc)::value;
+        stg[((e & 3) + 8 * (e >> 2) + 4 * h) * STG_LD + jn * 32 + r] = acc[i][jn][e];
+      });
+    });
+    __syncthreads();
+    if (g._p0 != 0) {
+      constexpr int LPR = WTN / 4, RPI = 64 / LPR;
+      const int lcol = (lane % LPR) * 4, lrow = lane / LPR;
+      const EpiCol ecol = epi_col(g, n0 + wn * WTN + lcol);
+      float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (g.bias && ecol.ok) bias4 = *reinterpret_cast<const float4*>(g.bias + ecol.n);
+#pragma unroll 1
+      for (int it = 0; it < 32 / RPI; ++it) {
+        const int rl = it * RPI + lrow;
+        const int64_t m = m0 + wm * WTM + i * 32 + rl;
+        if (m < g.M && ecol.ok) {
+          const float4 v = *reinterpret_cast<const float4*>(&stg[rl * STG_LD + lcol]);
+          if (split) {
+            *reinterpret_cast<float4*>(g.workspace + ((int64_t)blockIdx.z * g.M + m) * g.N + ecol.n) = v;
+          } else {
+            const EpiRow er = epi_row(g, odc, m);
+            epi_vec4(g, odc, er, ecol, bias4, v);
+          }
+        }
+      }
+    } else {
+      const int lcol = lane % WTN, lrow = lane / WTN;     // WTN = 64: one row per iteration
+      const EpiCol ecol = epi_col(g, n0 + wn * WTN + lcol);
+#pragma unroll 1
+      for (int it = 0; it < 32; ++it) {
+        const int rl = it + lrow;
+        const int64_t m = m0 + wm * WTM + i * 32 + rl;
+        if (m < g.M && ecol.ok) {
+          const float v = stg[rl * STG_LD + lcol];
+          if (split) {
+            g.workspace[((int64_t)blockIdx.z * g.M + m) * g.N + ecol.n] = v;
+          } else {
+            const EpiRow er = epi_row(g, odc, m);
+            epi_elem(g, odc, er, ecol, v);
+          }
+        }
+      }
+    }
+  });
+}
+
+template <int ALAY, int BLAY, bool WIN, bool DROP>
+int launch(const TecmGemm& g, hipStream_t st) {
+  const int tiles_m = (int)((g.M + BM - 1) / BM);
+  const int tiles_n = (int)((g.N + BN - 1) / BN);
+  int splits = g.split_k > 1 ? g.split_k : 1;
+  int k_chunk = (int)(((g.K + splits - 1) / splits + BK - 1) / BK) * BK;
+  splits = (int)((g.K + k_chunk - 1) / k_chunk);
+  dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)splits);
+  hipLaunchKernelGGL((gemm_bf16_kernel<ALAY, BLAY, WIN, DROP>), grid, dim3(NTH), 0, st, g, tiles_m, tiles_n, k_chunk);
+  TECM_CHECK_LAUNCH("tecm_gemm_bf16");
+  return splits;
+}
+
+template <int ALAY, int BLAY>
+int dispatch(const TecmGemm& g, bool win, bool drop, hipStream_t st) {
+  if (!win && !drop) return launch<ALAY, BLAY, false, false>(g, st);
+  if (win && !drop) return launch<ALAY, BLAY, true, false>(g, st);
+  if (!win && drop) return launch<ALAY, BLAY, false, true>(g, st);
+  return launch<ALAY, BLAY, true, true>(g, st);
+}
+
+}  // namespace tecm_gemm16
+
+int tecm_gemm16_dispatch_mk_nk(const TecmGemm& g, bool win, bool drop, hipStream_t st);
+int tecm_gemm16_dispatch_mk_kn(const TecmGemm& g, bool win, bool drop, hipStream_t st);
+int tecm_gemm16_dispatch_km_kn(const TecmGemm& g, bool win, bool drop, hipStream_t st);

@@ -1,0 +1,6 @@
+// Instantiations of the bf16 MFMA GEMM for the A_MK x B_NK operand layouts (see gemm_bf16_impl.h).
+#include "gemm_bf16_impl.h"
+
+int tecm_gemm16_dispatch_mk_nk(const TecmGemm& g, bool win, bool drop, hipStream_t st) {
+  return tecm_gemm16::dispatch<TECM_A_MK, TECM_B_NK>(g, win, drop, st);
+}

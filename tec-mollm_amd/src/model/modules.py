@@ -28,10 +28,18 @@ log = logging.getLogger(__name__)
 _seed_counter = [0]
 
 
-def make_plan(module: nn.Module, p: float = 0.1) -> F_.DropPlan:
-    """One dropout plan per forward call: base seed = torch seed (+ rank via the user's seeding) + call count."""
+def autocast_bf16() -> bool:
+    """True inside `torch.autocast('cuda', dtype=torch.bfloat16)` -- how the reference trains (train.py:68)."""
+    return torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
+
+
+def make_plan(module: nn.Module, p: float = 0.1, precision: str = "auto") -> F_.DropPlan:
+    """One plan per forward call: dropout seeds (base seed = torch seed + call count) and the GEMM precision:
+    "fp32" = exact-f32 MFMA, "bf16" = bf16 MFMA with fp32 accumulate, "auto" = bf16 iff under bf16 autocast."""
     _seed_counter[0] += 1
-    return F_.DropPlan(training=module.training, p=p, base_seed=(torch.initial_seed() + 7919 * _seed_counter[0]))
+    bf16 = precision == "bf16" or (precision == "auto" and autocast_bf16())
+    return F_.DropPlan(training=module.training, p=p, base_seed=(torch.initial_seed() + 7919 * _seed_counter[0]),
+                       bf16=bf16)
 
 
 def _need_cuda(t: torch.Tensor, name: str):
@@ -56,12 +64,12 @@ class Multi_Scale_Conv_Block(nn.Module):
                           nn.GroupNorm(1, out_channels), nn.GELU()) for k in kernel_sizes])
         self.final_conv = nn.Conv1d(out_channels * len(kernel_sizes), out_channels, kernel_size=1, stride=stride)
 
-    def forward_tm(self, inp: torch.Tensor, cin: int, need_dinp: bool = True) -> torch.Tensor:
+    def forward_tm(self, inp: torch.Tensor, cin: int, need_dinp: bool = True, bf16: bool = False) -> torch.Tensor:
         """inp (B, Lc, N, ld) time-major with `cin` real channels -> (B, Lc/stride, N, Cout)."""
         args = []
         for seq in self.convs:
             args += [seq[0].weight, seq[0].bias, seq[1].weight, seq[1].bias]
-        return F_.ConvBlockFn.apply(inp, cin, self.stride, need_dinp, *args, self.final_conv.weight,
+        return F_.ConvBlockFn.apply(inp, cin, self.stride, need_dinp, bf16, *args, self.final_conv.weight,
                                     self.final_conv.bias)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -69,7 +77,7 @@ class Multi_Scale_Conv_Block(nn.Module):
         _need_cuda(x, "x")
         S, Cc, L = x.shape
         tm = x.permute(0, 2, 1).contiguous().view(S, L, 1, Cc)
-        out = self.forward_tm(tm, Cc)
+        out = self.forward_tm(tm, Cc, bf16=autocast_bf16())
         return out.view(S, out.shape[1], self.out_channels).permute(0, 2, 1)
 
 
@@ -86,9 +94,9 @@ class MultiScaleConvEmbedder(nn.Module):
             cur = out_channels
         self.embedder = nn.Sequential(*layers)
 
-    def forward_tm(self, inp: torch.Tensor, cin: int, need_dinp: bool = True) -> torch.Tensor:
+    def forward_tm(self, inp: torch.Tensor, cin: int, need_dinp: bool = True, bf16: bool = False) -> torch.Tensor:
         for i, blk in enumerate(self.embedder):
-            inp = blk.forward_tm(inp, cin, need_dinp or i > 0)
+            inp = blk.forward_tm(inp, cin, need_dinp or i > 0, bf16)
             cin = blk.out_channels
         return inp
 
@@ -113,7 +121,7 @@ class LatentPatchingProjection(nn.Module):
         """Reference signature: x (S, L, D_latent) -> (S, num_patches, d_llm)."""
         _need_cuda(x, "x")
         S, L, D = x.shape
-        out = self.forward_tm(x.contiguous().view(S, L, 1, D), None, F_.DropPlan(False, 0.0, 0))
+        out = self.forward_tm(x.contiguous().view(S, L, 1, D), None, F_.DropPlan(False, 0.0, 0, autocast_bf16()))
         return out.view(S, out.shape[1], -1)
 
 
@@ -127,14 +135,14 @@ class TemporalEncoder(nn.Module):
         self.patcher = LatentPatchingProjection(channel_list[-1], patch_len, d_llm)
 
     def forward_tm(self, inp, cin, wpe, plan, need_dinp=True):
-        return self.patcher.forward_tm(self.conv_embedder.forward_tm(inp, cin, need_dinp), wpe, plan)
+        return self.patcher.forward_tm(self.conv_embedder.forward_tm(inp, cin, need_dinp, plan.bf16), wpe, plan)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """Reference signature: x (S, L_in, C_in) -> (S, num_patches, d_llm).  A sequence-major (S, L, C)
         tensor IS time-major with B=S, N=1, so no permute is needed (the reference's :143/:149 copies vanish)."""
         _need_cuda(x, "x")
         S, L, Cc = x.shape
-        out = self.forward_tm(x.contiguous().view(S, L, 1, Cc), Cc, None, F_.DropPlan(False, 0.0, 0),
+        out = self.forward_tm(x.contiguous().view(S, L, 1, Cc), Cc, None, F_.DropPlan(False, 0.0, 0, autocast_bf16()),
                               need_dinp=x.requires_grad)
         return out.view(S, out.shape[1], -1)
 
@@ -375,7 +383,6 @@ class PredictionHead(nn.Module):
         _need_cuda(x, "x")
         S, T, D = x.shape
         plan = make_plan(self, self.dropout_rate)
-        plan = F_.DropPlan(plan.training, plan.p, plan.base_seed)
         out = F_.HeadFn.apply(x.contiguous().view(S, T, 1, D), self.mlp[0].weight, self.mlp[0].bias,
                               self.mlp[3].weight, self.mlp[3].bias, _NoPostDrop(plan))
         return out.view(S, -1)
@@ -385,7 +392,7 @@ class _NoPostDrop(F_.DropPlan):
     """Plan that keeps the head's own dropout but not the post-LLM one (stand-alone PredictionHead)."""
 
     def __init__(self, plan: F_.DropPlan):
-        super().__init__(plan.training, plan.p, plan.base_seed)
+        super().__init__(plan.training, plan.p, plan.base_seed, plan.bf16)
 
     def spec(self, site: int, ld: int):
         return None if site == F_.SITE_POST else super().spec(site, ld)

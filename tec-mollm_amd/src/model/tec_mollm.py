@@ -8,6 +8,8 @@ dict, same forward signature and output shape, same parameter names.  Difference
   * stages 1-4 of the reference forward (embedding, GATv2, residual, layout) are ONE kernel;
   * `edge_weight` is optional (it is ignored by the reference too, modules.py:355-356), which also
     makes test.py:37's 3-argument call valid;
+  * model_config may carry `precision`: "auto" (default: bf16 matrix cores iff called under
+    `torch.autocast('cuda', torch.bfloat16)` as train.py:68 does, exact fp32 otherwise), "fp32", "bf16";
   * model_config may carry `gat_graphs`: "reference" (default: a single-graph edge_index only
     connects graph 0 = (t=0, b=0), exactly what the reference computes -- SURVEY.md section 0) or
     "per_timestep" (every (b, t) graph aggregates neighbours, what the reference's comments intend).
@@ -51,6 +53,9 @@ class TEC_MoLLM(nn.Module):
             raise ValueError("d_llm must be 768 (GPT-2 hidden size)")
         if len(cfg["temporal_strides"]) != 2 or len(cfg["temporal_channel_list"]) != 2:
             raise ValueError("exactly two temporal conv blocks are supported (tec_mollm.py:51)")
+        self.precision = cfg.get("precision", "auto")
+        if self.precision not in ("auto", "fp32", "bf16"):
+            raise ValueError("precision must be 'auto' (follow torch.autocast), 'fp32' or 'bf16'")
         self.gat_graphs = cfg.get("gat_graphs", "reference")
         if self.gat_graphs not in ("reference", "per_timestep"):
             raise ValueError("gat_graphs must be 'reference' or 'per_timestep'")
@@ -85,7 +90,7 @@ class TEC_MoLLM(nn.Module):
             raise ValueError(f"x has (N, C_in) = ({N}, {Cin}), model was built for ({self.num_nodes}, {self.c_in})")
         if time_features.shape != (B, L, N, 4):
             raise ValueError(f"time_features must be (B, L, N, 4), got {tuple(time_features.shape)}")
-        plan = make_plan(self)
+        plan = make_plan(self, precision=self.precision)
         meta = graph_.get(edge_index, N, x.device, self.spatio_temporal_embedding.d_emb)
         R = 1 if self.gat_graphs == "reference" else B * L
         # 1-4. embedding + GATv2 + residual  -> (B, L, N, 24) time-major

@@ -53,6 +53,7 @@ class DropPlan:
     training: bool
     p: float
     base_seed: int
+    bf16: bool = False      # run the dense contractions on the bf16 matrix cores (autocast semantics)
 
     def spec(self, site: int, ld: int):
         if not self.training or self.p <= 0.0:
@@ -148,7 +149,7 @@ class ConvBlockFn(torch.autograd.Function):
     (ld_in - cin zero pad channels); returns (B, Lc//stride, N, Cout)."""
 
     @staticmethod
-    def forward(ctx, inp, cin: int, stride: int, need_dinp: bool,
+    def forward(ctx, inp, cin: int, stride: int, need_dinp: bool, bf16: bool,
                 w3, b3, g3, be3, w5, b5, g5, be5, w7, b7, g7, be7, wf, bf):
         B, Lc, N, ld_in = inp.shape
         Cout = w3.shape[0]
@@ -164,7 +165,7 @@ class ConvBlockFn(torch.autograd.Function):
             fp, bp = ops.conv_weight_pack(wp.contiguous(), want_bwd=True)
             packs.append(bp)
             gemm(M, Cout, k * ld_in, inp, ld_in, fp, k * ld_in, y, CT, c_off=j * Cout,
-                 a_win=win(N, Lc, Lc, 1, k, ld_in, (k - 1) // 2), bias=b)
+                 a_win=win(N, Lc, Lc, 1, k, ld_in, (k - 1) // 2), bias=b, bf16=bf16)
         gamma = torch.cat([g3, g5, g7])
         beta = torch.cat([be3, be5, be7])
         act = _empty(B, Lc, N, CT, like=inp)
@@ -173,15 +174,15 @@ class ConvBlockFn(torch.autograd.Function):
         Lo = (Lc - 1) // stride + 1
         out = _empty(B, Lo, N, Cout, like=inp)
         wf2 = wf.view(Cout, CT)
-        gemm(B * Lo * N, Cout, CT, act, CT, wf2, CT, out, Cout, a_win=win(N, Lc, Lo, stride, 1, CT, 0), bias=bf)
+        gemm(B * Lo * N, Cout, CT, act, CT, wf2, CT, out, Cout, a_win=win(N, Lc, Lo, stride, 1, CT, 0), bias=bf, bf16=bf16)
         ctx.save_for_backward(inp, y, act, stats, gamma, beta, wf, *packs)
-        ctx.dims = (B, Lc, N, ld_in, cin, Cout, stride, Lo, need_dinp)
+        ctx.dims = (B, Lc, N, ld_in, cin, Cout, stride, Lo, need_dinp, bf16)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         inp, y, act, stats, gamma, beta, wf, bp3, bp5, bp7 = ctx.saved_tensors
-        B, Lc, N, ld_in, cin, Cout, stride, Lo, need_dinp = ctx.dims
+        B, Lc, N, ld_in, cin, Cout, stride, Lo, need_dinp, bf16 = ctx.dims
         CT = 3 * Cout
         M = B * Lc * N
         Mo = B * Lo * N
@@ -191,9 +192,9 @@ class ConvBlockFn(torch.autograd.Function):
         dbf = colsum(dout, Cout, Mo, 1, 1, Cout)[0]
         dwf = _empty(Cout, CT, like=inp)
         gemm(Cout, CT, Mo, dout, Cout, act, CT, dwf, CT, a_layout=A_KM, b_layout=B_KN,
-             b_win=win(N, Lc, Lo, stride, 1, CT, 0), split_k=pick_split_k(Cout, CT, Mo))
+             b_win=win(N, Lc, Lo, stride, 1, CT, 0), split_k=pick_split_k(Cout, CT, Mo), bf16=bf16)
         dact = _empty(B, Lo, N, CT, like=inp)
-        gemm(Mo, CT, Cout, dout, Cout, wf2, CT, dact, CT, b_layout=B_KN)
+        gemm(Mo, CT, Cout, dout, Cout, wf2, CT, dact, CT, b_layout=B_KN, bf16=bf16)
         # GroupNorm + GELU
         dy = _empty(B, Lc, N, CT, like=inp)
         dgamma, dbeta = ops.groupnorm_gelu_bwd(dact, stride, y, gamma, beta, stats, dy, B, Lc, N, Cout)
@@ -204,15 +205,15 @@ class ConvBlockFn(torch.autograd.Function):
             db = colsum(dy, CT, M, 1, 1, Cout, in_off=j * Cout)[0]
             dpack = _empty(Cout, K, like=inp)
             gemm(Cout, K, M, dy, CT, inp, ld_in, dpack, K, a_layout=A_KM, b_layout=B_KN, a_off=j * Cout,
-                 b_win=win(N, Lc, Lc, 1, k, ld_in, (k - 1) // 2), split_k=pick_split_k(Cout, K, M))
+                 b_win=win(N, Lc, Lc, 1, k, ld_in, (k - 1) // 2), split_k=pick_split_k(Cout, K, M), bf16=bf16)
             dw = ops.conv_weight_unpack(dpack, Cout, ld_in, k)
             if ld_in != cin:
                 dw = dw[:, :cin, :].contiguous()
             if need_dinp:
                 gemm(M, ld_in, k * Cout, dy, CT, bp, ld_in, dinp, ld_in, b_layout=B_KN, a_off=j * Cout,
-                     a_win=win(N, Lc, Lc, 1, k, Cout, (k - 1) // 2), accumulate=(j > 0))
+                     a_win=win(N, Lc, Lc, 1, k, Cout, (k - 1) // 2), accumulate=(j > 0), bf16=bf16)
             grads += [dw, db, dgamma[j * Cout:(j + 1) * Cout], dbeta[j * Cout:(j + 1) * Cout]]
-        return (dinp, None, None, None, *grads, dwf.view_as(wf), dbf)
+        return (dinp, None, None, None, None, *grads, dwf.view_as(wf), dbf)
 
 
 # ============================================================================ stage a-5 (+ wpe / embd dropout of a-6)
@@ -231,15 +232,17 @@ class PatchEmbedFn(torch.autograd.Function):
         w = win(N, Lc, P, patch_len, patch_len, D, 0)
         dspec = plan.spec(SITE_EMBD, d_llm) if wpe is not None else None
         gemm(M, d_llm, K, conv, D, Wp, K, h0, d_llm, a_win=w, bias=bp,
-             rowbias=(wpe, wpe.shape[1], N, P) if wpe is not None else None, out_drop=dspec)
+             rowbias=(wpe, wpe.shape[1], N, P) if wpe is not None else None, out_drop=dspec, bf16=plan.bf16)
         ctx.save_for_backward(conv, Wp, wpe if wpe is not None else Wp)
         ctx.meta = (B, Lc, N, D, P, d_llm, patch_len, wpe is not None, dspec)
+        ctx.plan = plan
         return h0
 
     @staticmethod
     def backward(ctx, dh0):
         conv, Wp, wpe = ctx.saved_tensors
         B, Lc, N, D, P, d_llm, patch_len, has_wpe, dspec = ctx.meta
+        plan = ctx.plan
         M = B * P * N
         K = patch_len * D
         dh0 = dh0.contiguous()
@@ -251,11 +254,11 @@ class PatchEmbedFn(torch.autograd.Function):
             colsum(dh0, d_llm, B, N, P, d_llm, in_drop=dspec, out=dwpe)      # rows 0..P-1 of wpe
         dWp = _empty(d_llm, K, like=conv)
         gemm(d_llm, K, M, dh0, d_llm, conv, D, dWp, K, a_layout=A_KM, b_layout=B_KN, b_win=w, a_drop=dspec,
-             split_k=pick_split_k(d_llm, K, M))
+             split_k=pick_split_k(d_llm, K, M), bf16=plan.bf16)
         dconv = _empty(B, Lc, N, D, like=conv)
         if P * patch_len != Lc:
             dconv.zero_()
-        gemm(M, K, d_llm, dh0, d_llm, Wp, K, dconv, D, b_layout=B_KN, c_win=w, a_drop=dspec)
+        gemm(M, K, d_llm, dh0, d_llm, Wp, K, dconv, D, b_layout=B_KN, c_win=w, a_drop=dspec, bf16=plan.bf16)
         return dconv, dWp, dbp, dwpe, None, None
 
 
@@ -282,27 +285,27 @@ class GPT2StackFn(torch.autograd.Function):
             st1 = _empty(M, 2, like=h)
             ops.layernorm_fwd(h, D, ln1w, ln1b, u, KE, st1, M, D)
             lspec = plan.spec(site_lora(i), KE)
-            gemm(M, LORA_R, D, u, KE, lA, D, u, KE, c_off=D, a_drop=lspec)
+            gemm(M, LORA_R, D, u, KE, lA, D, u, KE, c_off=D, a_drop=lspec, bf16=plan.bf16)
             wcat = _empty(KE, F3, like=h)                   # [ W ; (alpha/r) B^T ]  K-extended c_attn
             wcat[:D].copy_(Wqkv)
             ops.transpose_scale(lB, LORA_R, wcat, F3, LORA_R, F3, LORA_SCALE, dst_off=D * F3)
             qkv = _empty(M, F3, like=h)
-            gemm(M, F3, KE, u, KE, wcat, F3, qkv, F3, b_layout=B_KN, bias=bqkv)
+            gemm(M, F3, KE, u, KE, wcat, F3, qkv, F3, b_layout=B_KN, bias=bqkv, bf16=plan.bf16)
             cx = _empty(M, D, like=h)
             aspec = plan.spec(site_attn(i), 1)
             ops.attention_fwd(qkv, cx, B, T, N, GPT_HEADS, D, aspec)
             h2 = _empty(M, D, like=h)
             gemm(M, D, D, cx, D, Wo, D, h2, D, b_layout=B_KN, bias=bo, out_drop=plan.spec(site_res1(i), D),
-                 residual=(h, D))
+                 residual=(h, D), bf16=plan.bf16)
             u2 = _empty(M, D, like=h)
             st2 = _empty(M, 2, like=h)
             ops.layernorm_fwd(h2, D, ln2w, ln2b, u2, D, st2, M, D)
             a = _empty(M, F4, like=h)
             f = _empty(M, F4, like=h)
-            gemm(M, F4, D, u2, D, Wfc, F4, f, F4, b_layout=B_KN, bias=bfc, preact=(a, F4), act=ACT_GELU_TANH)
+            gemm(M, F4, D, u2, D, Wfc, F4, f, F4, b_layout=B_KN, bias=bfc, preact=(a, F4), act=ACT_GELU_TANH, bf16=plan.bf16)
             h3 = _empty(M, D, like=h)
             gemm(M, D, F4, f, F4, Wpr, D, h3, D, b_layout=B_KN, bias=bpr, out_drop=plan.spec(site_res2(i), D),
-                 residual=(h2, D))
+                 residual=(h2, D), bf16=plan.bf16)
             saved += [h, u, st1, wcat, qkv, cx, h2, st2, u2, a]
             h = h3
         lnfw, lnfb = params[n_layers * GPT2StackFn.PER_LAYER:]
@@ -338,9 +341,9 @@ class GPT2StackFn(torch.autograd.Function):
             F3, F4 = Wqkv.shape[1], Wfc.shape[1]
             # MLP:  h3 = h2 + drop(gelu(u2 Wfc + b) Wpr + b)
             da = _empty(M, F4, like=dh)
-            gemm(M, F4, D, dhm, D, Wpr, D, da, F4, act=ACT_GELU_TANH, dact_src=(a, F4))
+            gemm(M, F4, D, dhm, D, Wpr, D, da, F4, act=ACT_GELU_TANH, dact_src=(a, F4), bf16=plan.bf16)
             du2 = _empty(M, D, like=dh)
-            gemm(M, D, F4, da, F4, Wfc, F4, du2, D)
+            gemm(M, D, F4, da, F4, Wfc, F4, du2, D, bf16=plan.bf16)
             del da
             dh2 = _empty(M, D, like=dh)
             sp = plan.spec(site_res1(i), D)
@@ -349,20 +352,20 @@ class GPT2StackFn(torch.autograd.Function):
                                          dx_masked=dh2m if sp is not None else None, mask_drop=sp)
             # attention: h2 = h + drop(ctx Wo + b)
             dcx = du2                                         # reuse buffer
-            gemm(M, D, D, dh2m, D, Wo, D, dcx, D)
+            gemm(M, D, D, dh2m, D, Wo, D, dcx, D, bf16=plan.bf16)
             dqkv = _empty(M, F3, like=dh)
             ops.attention_bwd(qkv, dcx, dqkv, B, T, N, GPT_HEADS, D, plan.spec(site_attn(i), 1))
             du = _empty(M, KE, like=dh)                       # [ d LN1-out (base path) | dz ]
-            gemm(M, KE, F3, dqkv, F3, wcat, F3, du, KE)
+            gemm(M, KE, F3, dqkv, F3, wcat, F3, du, KE, bf16=plan.bf16)
             lspec = plan.spec(site_lora(i), KE)
             dlB = _empty(F3, LORA_R, like=dh)
             gemm(F3, LORA_R, M, dqkv, F3, u, KE, dlB, LORA_R, a_layout=A_KM, b_layout=B_KN, b_off=D,
-                 alpha=LORA_SCALE, split_k=pick_split_k(F3, LORA_R, M))
+                 alpha=LORA_SCALE, split_k=pick_split_k(F3, LORA_R, M), bf16=plan.bf16)
             dlA = _empty(LORA_R, D, like=dh)
             gemm(LORA_R, D, M, du, KE, u, KE, dlA, D, a_layout=A_KM, b_layout=B_KN, a_off=D, b_drop=lspec,
-                 split_k=pick_split_k(LORA_R, D, M))
+                 split_k=pick_split_k(LORA_R, D, M), bf16=plan.bf16)
             # LoRA path back to LN1's output: du[:, :D] += mask * (dz A)
-            gemm(M, D, LORA_R, du, KE, lA, D, du, KE, b_layout=B_KN, a_off=D, out_drop=lspec, accumulate=True)
+            gemm(M, D, LORA_R, du, KE, lA, D, du, KE, b_layout=B_KN, a_off=D, out_drop=lspec, accumulate=True, bf16=plan.bf16)
             dhn = _empty(M, D, like=dh)
             sp = plan.spec(site_res2(i - 1), D) if i > 0 else None
             dhm = _empty(M, D, like=dh) if sp is not None else dhn
@@ -394,31 +397,33 @@ class HeadFn(torch.autograd.Function):
         pre = _empty(S, Hd, like=hid)
         h1 = _empty(S, Hd, like=hid)
         gemm(S, Hd, K1, hid, D, W1, K1, h1, Hd, a_win=w, a_drop=pspec, bias=b1, preact=(pre, Hd), act=ACT_GELU_ERF,
-             out_drop=hspec)
+             out_drop=hspec, bf16=plan.bf16)
         pred = _empty(B, N, Lo, like=hid)
-        gemm(S, Lo, Hd, h1, Hd, W2, Hd, pred, Lo, bias=b2)
+        gemm(S, Lo, Hd, h1, Hd, W2, Hd, pred, Lo, bias=b2, bf16=plan.bf16)
         ctx.save_for_backward(hid, W1, W2, pre, h1)
         ctx.meta = (B, T, N, D, Hd, K1, Lo, w, pspec, hspec)
+        ctx.plan = plan
         return pred
 
     @staticmethod
     def backward(ctx, dpred):
         hid, W1, W2, pre, h1 = ctx.saved_tensors
         B, T, N, D, Hd, K1, Lo, w, pspec, hspec = ctx.meta
+        plan = ctx.plan
         S = B * N
         dpred = dpred.contiguous()
         db2 = colsum(dpred, Lo, S, 1, 1, Lo)[0]
         dW2 = _empty(Lo, Hd, like=hid)
-        gemm(Lo, Hd, S, dpred, Lo, h1, Hd, dW2, Hd, a_layout=A_KM, b_layout=B_KN, split_k=pick_split_k(Lo, Hd, S))
+        gemm(Lo, Hd, S, dpred, Lo, h1, Hd, dW2, Hd, a_layout=A_KM, b_layout=B_KN, split_k=pick_split_k(Lo, Hd, S), bf16=plan.bf16)
         dpre = _empty(S, Hd, like=hid)
         gemm(S, Hd, Lo, dpred, Lo, W2, Hd, dpre, Hd, b_layout=B_KN, act=ACT_GELU_ERF, dact_src=(pre, Hd),
-             out_drop=hspec)
+             out_drop=hspec, bf16=plan.bf16)
         db1 = colsum(dpre, Hd, S, 1, 1, Hd)[0]
         dW1 = _empty(Hd, K1, like=hid)
         gemm(Hd, K1, S, dpre, Hd, hid, D, dW1, K1, a_layout=A_KM, b_layout=B_KN, b_win=w, b_drop=pspec,
-             split_k=pick_split_k(Hd, K1, S))
+             split_k=pick_split_k(Hd, K1, S), bf16=plan.bf16)
         dhid = _empty(B, T, N, D, like=hid)
-        gemm(S, K1, Hd, dpre, Hd, W1, K1, dhid, D, b_layout=B_KN, c_win=w, out_drop=pspec)
+        gemm(S, K1, Hd, dpre, Hd, W1, K1, dhid, D, b_layout=B_KN, c_win=w, out_drop=pspec, bf16=plan.bf16)
         return dhid, dW1, db1, dW2, db2, None
 
 

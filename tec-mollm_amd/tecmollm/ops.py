@@ -50,9 +50,14 @@ def gemm(M: int, N: int, K: int, A: torch.Tensor, lda: int, B: torch.Tensor, ldb
          alpha: float = 1.0, act: int = ACT_NONE, bias: Optional[torch.Tensor] = None,
          rowbias: Optional[Tuple[torch.Tensor, int, int, int]] = None,
          preact: Optional[Tuple[torch.Tensor, int]] = None, dact_src: Optional[Tuple[torch.Tensor, int]] = None,
-         residual: Optional[Tuple[torch.Tensor, int]] = None, accumulate: bool = False, split_k: int = 1) -> None:
+         residual: Optional[Tuple[torch.Tensor, int]] = None, accumulate: bool = False, split_k: int = 1,
+         bf16: bool = False) -> None:
     """C[M,N] = epilogue(alpha * A_view[M,K] . B_view[K,N]); see TecmGemm in include/tecmollm.h.
-    *_off are element offsets added to the base pointers (column slices of wider buffers)."""
+    *_off are element offsets added to the base pointers (column slices of wider buffers).
+    bf16=True asks for the bf16 matrix cores (operands rounded to bf16, fp32 accumulate); calls the bf16
+    kernel cannot serve (N < 64 output columns or operands that are not 16-byte friendly) run on the exact
+    fp32 kernel instead -- the choice is a pure function of shapes/alignment (`uses_bf16`), never silent
+    with respect to the tests, which mirror it."""
     g = TecmGemm()
     g.M, g.N, g.K = M, N, K
     g.A, g.lda, g.a_layout = _off(A, a_off), lda, a_layout
@@ -82,14 +87,36 @@ def gemm(M: int, N: int, K: int, A: torch.Tensor, lda: int, B: torch.Tensor, ldb
         g.split_k, g.workspace = split_k, ws.data_ptr()
     else:
         g.split_k = 1
+    use16 = bf16 and _bf16_ok(g)
+    fn = lib().tecm_gemm_bf16 if use16 else lib().tecm_gemm_f32
     if _timing is None:
-        check(lib().tecm_gemm_f32(C.byref(g), stream_ptr()), "tecm_gemm_f32")
+        check(fn(C.byref(g), stream_ptr()), "tecm_gemm_bf16" if use16 else "tecm_gemm_f32")
         return
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    check(lib().tecm_gemm_f32(C.byref(g), stream_ptr()), "tecm_gemm_f32")
+    check(fn(C.byref(g), stream_ptr()), "tecm_gemm_bf16" if use16 else "tecm_gemm_f32")
     e1.record()
-    _timing.append((_kernel_name(g), 2.0 * M * N * K, e0, e1))
+    _timing.append((_kernel_name(g, use16), 2.0 * M * N * K, e0, e1))
+
+
+BF16_MIN_N = 64
+
+
+def uses_bf16(N: int, K: int, lda: int, ldb: int, a_layout: int = A_MK, b_layout: int = B_NK, cw_a: int = 4,
+              cw_b: int = 4) -> bool:
+    """Which GEMMs run on the bf16 matrix cores when bf16 is requested (mirrored by the oracle's emulation)."""
+    if N < BF16_MIN_N or lda % 4 or ldb % 4 or cw_a % 4 or cw_b % 4:
+        return False
+    if a_layout == A_MK and K % 4:
+        return False
+    return True
+
+
+def _bf16_ok(g: TecmGemm) -> bool:
+    if not uses_bf16(g.N, g.K, g.lda, g.ldb, g.a_layout, g.b_layout, g.a_win.Cw if g.a_win.enabled else 4,
+                     g.b_win.Cw if g.b_win.enabled else 4):
+        return False
+    return g.A % 16 == 0 and g.B % 16 == 0
 
 
 # ------------------------------------------------------------------ per-launch timing (bench.py roofline)
@@ -110,8 +137,10 @@ def _vec(p: int, ld: int, w: TecmWin, inner_is_k: bool, K: int) -> int:
     return v
 
 
-def _kernel_name(g: TecmGemm) -> str:
+def _kernel_name(g: TecmGemm, use16: bool = False) -> str:
     """Name of the template instance csrc/gemm.hip dispatches to (mirrors pick_vec / dispatch_vec)."""
+    if use16:
+        return f"gemm_bf16_kernel<{g.a_layout},{g.b_layout}>"
     av = _vec(g.A, g.lda, g.a_win, g.a_layout == A_MK, g.K)
     bv = _vec(g.B, g.ldb, g.b_win, g.b_layout == B_NK, g.K)
     if av == 4 and bv == 4:

@@ -1,0 +1,117 @@
+"""GPU parity tests of the bf16 MFMA GEMM (tecm_gemm_bf16): operands rounded to bf16 (RNE), fp32 accumulate.
+Reference = fp64 matmul of the bf16-ROUNDED operands, so the only difference left is summation order:
+tolerance 2e-4 relative to the reference's max magnitude, the same as for the fp32 kernel."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-4
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def _q(t):
+    return t.bfloat16().double()
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda")
+
+
+def _rand(*shape, dev, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dev)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 200, 96), (513, 768, 800), (1000, 3072, 768), (77, 64, 52), (256, 128, 64)])
+def test_bf16_mk_nk_and_kn(dev, M, N, K):
+    from tecmollm import ops
+    A = _rand(M, K, dev=dev, seed=1)
+    Bn, Bk = _rand(N, K, dev=dev, seed=2), _rand(K, N, dev=dev, seed=3)
+    bias = _rand(N, dev=dev, seed=4)
+    C = torch.full((M, N), float("nan"), device=dev)
+    ops.gemm(M, N, K, A, K, Bn, K, C, N, bias=bias, bf16=True)
+    assert _rel(C, _q(A) @ _q(Bn).t() + bias.double()) < TOL
+    ops.gemm(M, N, K, A, K, Bk, N, C, N, b_layout=ops.B_KN, alpha=0.5, bf16=True)
+    assert _rel(C, 0.5 * (_q(A) @ _q(Bk))) < TOL
+    # and it really is the bf16 kernel: an fp32-exact result would differ from the rounded-operand reference
+    ops.gemm(M, N, K, A, K, Bk, N, C, N, b_layout=ops.B_KN, alpha=0.5)
+    assert _rel(C, 0.5 * (_q(A) @ _q(Bk))) > 1e-4
+
+
+@pytest.mark.parametrize("Mo,No,K,split", [(64, 168, 5000, 7), (768, 512, 3001, 4), (576, 2304, 999, 1),
+                                           (128, 64, 130, 1)])
+def test_bf16_km_kn_splitk(dev, Mo, No, K, split):
+    from tecmollm import ops
+    A, B = _rand(K, Mo, dev=dev, seed=1), _rand(K, No, dev=dev, seed=2)
+    C = torch.full((Mo, No), float("nan"), device=dev)
+    ops.gemm(Mo, No, K, A, Mo, B, No, C, No, a_layout=ops.A_KM, b_layout=ops.B_KN, split_k=split, bf16=True)
+    assert _rel(C, _q(A).t() @ _q(B)) < TOL
+
+
+def test_bf16_small_n_falls_back_to_fp32_kernel(dev):
+    """N < 64 (LoRA down-projection, head output): the exact fp32 kernel runs -- mirrored by ops.uses_bf16."""
+    from tecmollm import ops
+    A, B = _rand(200, 768, dev=dev, seed=1), _rand(32, 768, dev=dev, seed=2)
+    C = torch.empty(200, 32, device=dev)
+    assert not ops.uses_bf16(32, 768, 768, 768)
+    ops.gemm(200, 32, 768, A, 768, B, 768, C, 32, bf16=True)
+    assert _rel(C, A.double() @ B.double().t()) < TOL
+
+
+@pytest.mark.parametrize("Bn,L,N,Cin,Cout,k", [(2, 48, 5, 24, 64, 3), (2, 24, 3, 64, 128, 7)])
+def test_bf16_window_conv_fwd_dx_dw(dev, Bn, L, N, Cin, Cout, k):
+    from tecmollm import ops
+    x = _rand(Bn, L, N, Cin, dev=dev, seed=1)
+    w = _rand(Cout, Cin, k, dev=dev, seed=2, scale=0.2)
+    fp, bp = ops.conv_weight_pack(w)
+    y = torch.empty(Bn, L, N, Cout, device=dev)
+    ops.gemm(Bn * L * N, Cout, k * Cin, x, Cin, fp, k * Cin, y, Cout, a_win=ops.win(N, L, L, 1, k, Cin, (k - 1) // 2),
+             bf16=True)
+    xs = _q(x).permute(0, 2, 3, 1).reshape(Bn * N, Cin, L)
+    ref = torch.nn.functional.conv1d(xs, _q(w), None, padding=(k - 1) // 2).view(Bn, N, Cout, L).permute(0, 3, 1, 2)
+    assert _rel(y, ref) < TOL
+    dy = _rand(Bn, L, N, Cout, dev=dev, seed=4)
+    dx = torch.empty(Bn, L, N, Cin, device=dev)
+    ops.gemm(Bn * L * N, Cin, k * Cout, dy, Cout, bp, Cin, dx, Cin, b_layout=ops.B_KN,
+             a_win=ops.win(N, L, L, 1, k, Cout, (k - 1) // 2), bf16=True)
+    dpack = torch.empty(Cout, k * Cin, device=dev)
+    ops.gemm(Cout, k * Cin, Bn * L * N, dy, Cout, x, Cin, dpack, k * Cin, a_layout=ops.A_KM, b_layout=ops.B_KN,
+             b_win=ops.win(N, L, L, 1, k, Cin, (k - 1) // 2), split_k=3, bf16=True)
+    dw = ops.conv_weight_unpack(dpack, Cout, Cin, k)
+    gy = _q(dy).permute(0, 2, 3, 1).reshape(Bn * N, Cout, L)
+    gx = torch.nn.grad.conv1d_input(xs.shape, _q(w), gy, padding=(k - 1) // 2)
+    gw = torch.nn.grad.conv1d_weight(xs, w.shape, gy, padding=(k - 1) // 2)
+    if ops.uses_bf16(Cin, k * Cout, Cout, Cin, ops.A_MK, ops.B_KN, Cout, 4):
+        assert _rel(dx, gx.view(Bn, N, Cin, L).permute(0, 3, 1, 2)) < TOL
+    assert _rel(dw, gw) < TOL
+
+
+def test_bf16_dropout_epilogue_window_scatter(dev):
+    from tecmollm import ops, rng
+    M, K, N = 300, 128, 192
+    A, B = _rand(M, K, dev=dev, seed=1), _rand(N, K, dev=dev, seed=2)
+    p, seedA, seedO = 0.1, 1234567, 7654321
+    res = _rand(M, N, dev=dev, seed=3)
+    C = torch.empty(M, N, device=dev)
+    ops.gemm(M, N, K, A, K, B, K, C, N, a_drop=ops.drop(p, seedA, 800), out_drop=ops.drop(p, seedO, N),
+             residual=(res, N), act=ops.ACT_GELU_TANH, bf16=True)
+    ia = (np.arange(M)[:, None] * 800 + np.arange(K)[None, :]).astype(np.uint64)
+    io = (np.arange(M)[:, None] * N + np.arange(N)[None, :]).astype(np.uint64)
+    ma = torch.from_numpy(rng.keep_mult(seedA, ia, p)).to(dev)
+    mo = torch.from_numpy(rng.keep_mult(seedO, io, p)).double().to(dev)
+    z = _q(A * ma) @ _q(B).t()                       # the mask is applied in fp32 BEFORE the bf16 rounding
+    ref = torch.nn.functional.gelu(z, approximate="tanh") * mo + res.double()
+    assert _rel(C, ref) < TOL
+    # transposed operand with dropout (LoRA dA form): dA = dz^T . drop(u)
+    dz, u = _rand(M, 64, dev=dev, seed=5), _rand(M, K, dev=dev, seed=6)
+    dA = torch.empty(64, K, device=dev)
+    ops.gemm(64, K, M, dz, 64, u, K, dA, K, a_layout=ops.A_KM, b_layout=ops.B_KN, b_drop=ops.drop(p, seedA, 800),
+             bf16=True)
+    assert _rel(dA, _q(dz).t() @ _q(u * ma)) < TOL

@@ -11,6 +11,7 @@ if os.environ.get('TECM_LIB'):
 from tecmollm import ops
 
 dev = torch.device("cuda")
+BF16 = os.environ.get('BF16', '0') == '1'
 M = int(os.environ.get("M", 69864))
 shapes = [("fc   KN", 3072, 768, ops.B_KN), ("proj KN", 768, 3072, ops.B_KN), ("qkv  KN", 2304, 800, ops.B_KN),
           ("cprj KN", 768, 768, ops.B_KN), ("da   NK", 3072, 768, ops.B_NK), ("du2  NK", 768, 3072, ops.B_NK),
@@ -21,13 +22,13 @@ for name, N, K, bl in shapes:
     C = torch.empty(M, N, device=dev)
     ldb = N if bl == ops.B_KN else K
     for _ in range(2):
-        ops.gemm(M, N, K, A, K, B, ldb, C, N, b_layout=bl)
+        ops.gemm(M, N, K, A, K, B, ldb, C, N, b_layout=bl, bf16=BF16)
     torch.cuda.synchronize()
     reps = 8
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        ops.gemm(M, N, K, A, K, B, ldb, C, N, b_layout=bl)
+        ops.gemm(M, N, K, A, K, B, ldb, C, N, b_layout=bl, bf16=BF16)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps

@@ -142,8 +142,9 @@ int tecm_groupnorm_gelu_fwd(const float* y, const float* gamma, const float* bet
                             float* stats, int32_t B, int32_t L, int32_t N, int32_t Cout, float eps,
                             void* stream);
 /* dact is (B, L/dstride, N, CT): the gradient exists only at t % dstride == 0 (stride-s 1x1 conv).
- * dgb_partials: (num_blocks, 2*CT) per-block [dgamma | dbeta]; returns num_blocks via *num_blocks
- * when dy == NULL (query mode, nothing launched). */
+ * dgb_partials: (num_blocks, 3*CT) per-block [dgamma | dbeta | column sums of dy] -- the last third is the
+ * gradient of the Conv1d biases in front of the norm (modules.py:27), free here since dy is being written;
+ * returns num_blocks via *num_blocks when dy == NULL (query mode, nothing launched). */
 int tecm_groupnorm_gelu_bwd(const float* dact, int32_t dstride, const float* y, const float* gamma,
                             const float* beta, const float* stats, float* dy, float* dgb_partials,
                             int32_t* num_blocks, int32_t B, int32_t L, int32_t N, int32_t Cout,

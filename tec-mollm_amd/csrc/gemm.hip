@@ -8,8 +8,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const TecmGemm g, in
   const int64_t total = g.M * g.N;
   const tecm_gemm::DropCtx odc = tecm_gemm::make_drop(g.out_drop);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    float v = 0.f;
-    for (int s = 0; s < splits; ++s) v += g.workspace[(int64_t)s * total + i];
+    float v4[4] = {0.f, 0.f, 0.f, 0.f};        // four slabs in flight: a serial chain of `splits` loads is latency-bound
+    for (int s = 0; s < splits; s += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (s + u < splits) v4[u] += g.workspace[(int64_t)(s + u) * total + i];
+    }
+    const float v = (v4[0] + v4[1]) + (v4[2] + v4[3]);
     const int64_t m = i / g.N;
     tecm_gemm::epilogue_store(g, odc, m, (int32_t)(i - m * g.N), v);
   }

@@ -232,17 +232,18 @@ __global__ __launch_bounds__(256) void gn_gelu_bwd_kernel(const float* __restric
                                                           float* __restrict__ partials, int B, int L, int N) {
   constexpr int NCHK = 3 * CPB;
   constexpr int CT = NCHK * 64;
-  __shared__ float red[4][2 * CT];
+  __shared__ float red[4][3 * CT];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float inv_cnt = 1.0f / (float)(L * CPB * 64);
   const int64_t tstride = (int64_t)N * CT;
-  float gm[NCHK], bt[NCHK], dgm[NCHK], dbt[NCHK];
+  float gm[NCHK], bt[NCHK], dgm[NCHK], dbt[NCHK], dys[NCHK];
 #pragma unroll
   for (int i = 0; i < NCHK; ++i) {
     gm[i] = gamma[lane + 64 * i];
     bt[i] = beta[lane + 64 * i];
     dgm[i] = 0.f;
     dbt[i] = 0.f;
+    dys[i] = 0.f;
   }
   for (int64_t sidx = (int64_t)blockIdx.x * 4 + wave; sidx < (int64_t)B * N; sidx += (int64_t)gridDim.x * 4) {
     const int b = (int)(sidx / N), n = (int)(sidx - (int64_t)b * N);
@@ -294,7 +295,9 @@ __global__ __launch_bounds__(256) void gn_gelu_bwd_kernel(const float* __restric
           const float yh = (p[64 * i] - mean[br]) * rstd[br];
           float dyh = 0.f;
           if (has) dyh = dp[64 * i] * dgelu_erf(yh * gm[i] + bt[i]) * gm[i];
-          o[64 * i] = rstd[br] * (dyh - s1[br] - yh * s2[br]);
+          const float dyv = rstd[br] * (dyh - s1[br] - yh * s2[br]);
+          o[64 * i] = dyv;
+          dys[i] += dyv;                    // column sum of dy = gradient of the Conv1d bias in front of this norm
         }
     }
   }
@@ -302,10 +305,11 @@ __global__ __launch_bounds__(256) void gn_gelu_bwd_kernel(const float* __restric
   for (int i = 0; i < NCHK; ++i) {
     red[wave][lane + 64 * i] = dgm[i];
     red[wave][CT + lane + 64 * i] = dbt[i];
+    red[wave][2 * CT + lane + 64 * i] = dys[i];
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < 2 * CT; c += 256)
-    partials[(int64_t)blockIdx.x * 2 * CT + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+  for (int c = threadIdx.x; c < 3 * CT; c += 256)
+    partials[(int64_t)blockIdx.x * 3 * CT + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
 // ------------------------------------------------------------------------------ column sums
@@ -322,13 +326,21 @@ __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ i
   const int64_t end = beg + chunk < total ? beg + chunk : total;
   float acc = 0.f;
   if (c < C) {
-    for (int64_t ri = beg + wave; ri < end; ri += 4) {
-      const int64_t o = ri / inner, j = ri - o * inner;
-      const int64_t row = (o * nseg + s) * inner + j;
-      float v = in[row * ld + c];
-      if (idc.thresh) v *= tecm_drop_mult(idc.seed, (uint64_t)(row * idc.ld + c), idc.thresh, idc.inv);
-      acc += v;
+    float a4[4] = {0.f, 0.f, 0.f, 0.f};          // four rows in flight per wave: the loop is latency-bound otherwise
+    for (int64_t r0 = beg + wave; r0 < end; r0 += 16) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t ri = r0 + 4 * u;
+        if (ri < end) {
+          const int64_t o = ri / inner, j = ri - o * inner;
+          const int64_t row = (o * nseg + s) * inner + j;
+          float v = in[row * ld + c];
+          if (idc.thresh) v *= tecm_drop_mult(idc.seed, (uint64_t)(row * idc.ld + c), idc.thresh, idc.inv);
+          a4[u] += v;
+        }
+      }
     }
+    acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
   }
   red[wave][lane] = acc;
   __syncthreads();

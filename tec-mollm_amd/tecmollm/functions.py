@@ -197,12 +197,12 @@ class ConvBlockFn(torch.autograd.Function):
         gemm(Mo, CT, Cout, dout, Cout, wf2, CT, dact, CT, b_layout=B_KN, bf16=bf16)
         # GroupNorm + GELU
         dy = _empty(B, Lc, N, CT, like=inp)
-        dgamma, dbeta = ops.groupnorm_gelu_bwd(dact, stride, y, gamma, beta, stats, dy, B, Lc, N, Cout)
+        dgamma, dbeta, dbconv = ops.groupnorm_gelu_bwd(dact, stride, y, gamma, beta, stats, dy, B, Lc, N, Cout)
         dinp = _empty(B, Lc, N, ld_in, like=inp) if need_dinp else None
         grads = []
         for j, (k, bp) in enumerate(((3, bp3), (5, bp5), (7, bp7))):
             K = k * ld_in
-            db = colsum(dy, CT, M, 1, 1, Cout, in_off=j * Cout)[0]
+            db = dbconv[j * Cout:(j + 1) * Cout]
             dpack = _empty(Cout, K, like=inp)
             gemm(Cout, K, M, dy, CT, inp, ld_in, dpack, K, a_layout=A_KM, b_layout=B_KN, a_off=j * Cout,
                  b_win=win(N, Lc, Lc, 1, k, ld_in, (k - 1) // 2), split_k=pick_split_k(Cout, K, M), bf16=bf16)

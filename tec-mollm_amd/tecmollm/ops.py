@@ -176,11 +176,13 @@ def summarize_gemm_timing(records: list) -> dict:
     return agg
 
 
-def pick_split_k(Mo: int, No: int, K: int, target_blocks: int = 768, min_chunk: int = 512) -> int:
-    """Split the (huge) reduction dim of a weight-gradient GEMM so the grid fills 256 CUs."""
+def pick_split_k(Mo: int, No: int, K: int, target_blocks: int = 512, min_chunk: int = 512,
+                 max_splits: int = 256) -> int:
+    """Split the (huge) reduction dim of a weight-gradient GEMM so the grid fills 256 CUs; capped because every
+    split costs one slab of partial sums that the reducer has to read back."""
     tiles = ((Mo + 127) // 128) * ((No + 127) // 128 if No > 32 else 1)
     s = max(1, target_blocks // max(tiles, 1))
-    s = min(s, max(1, K // min_chunk))
+    s = min(s, max(1, K // min_chunk), max_splits)
     return int(s)
 
 
@@ -222,18 +224,18 @@ def groupnorm_gelu_fwd(y: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
 
 def groupnorm_gelu_bwd(dact: torch.Tensor, dstride: int, y: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
                        stats: torch.Tensor, dy: torch.Tensor, B: int, L: int, N: int,
-                       Cout: int) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Returns (dgamma, dbeta), each (3*Cout,)."""
+                       Cout: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Returns (dgamma, dbeta, colsum(dy)), each (3*Cout,); the last is the conv-bias gradient."""
     nb = C.c_int32(0)
     check(lib().tecm_groupnorm_gelu_bwd(None, dstride, None, None, None, None, None, None, C.byref(nb), B, L, N, Cout,
                                         None), "tecm_groupnorm_gelu_bwd(query)")
     CT = 3 * Cout
-    partials = torch.empty(nb.value, 2 * CT, device=dy.device, dtype=torch.float32)
+    partials = torch.empty(nb.value, 3 * CT, device=dy.device, dtype=torch.float32)
     check(lib().tecm_groupnorm_gelu_bwd(dact.data_ptr(), dstride, y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                         stats.data_ptr(), dy.data_ptr(), partials.data_ptr(), C.byref(nb), B, L, N,
                                         Cout, stream_ptr()), "tecm_groupnorm_gelu_bwd")
-    dgb = colsum(partials, 2 * CT, nb.value, 1, 1, 2 * CT)
-    return dgb[0, :CT], dgb[0, CT:]
+    dgb = colsum(partials, 3 * CT, nb.value, 1, 1, 3 * CT)
+    return dgb[0, :CT], dgb[0, CT:2 * CT], dgb[0, 2 * CT:]
 
 
 def attention_fwd(qkv: torch.Tensor, ctx: torch.Tensor, B: int, T: int, N: int, heads: int, D: int,

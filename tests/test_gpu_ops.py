@@ -247,11 +247,12 @@ def test_groupnorm_gelu_fwd_bwd(dev, Bn, L, N, Cout, stride):
     Lo = (L - 1) // stride + 1
     dact = _rand(Bn, Lo, N, CT, dev=dev, seed=4)
     dy = torch.empty_like(y)
-    dg, db = ops.groupnorm_gelu_bwd(dact, stride, y, g, b, st, dy, Bn, L, N, Cout)
+    dg, db, dysum = ops.groupnorm_gelu_bwd(dact, stride, y, g, b, st, dy, Bn, L, N, Cout)
     full = torch.zeros(Bn, L, N, CT, dtype=torch.float64, device=dev)
     full[:, ::stride] = dact.double()
     gy, gg, gb = torch.autograd.grad(ref, (yd, gd, bd), full)
     assert _rel(dy, gy) < TOL and _rel(dg, gg) < TOL and _rel(db, gb) < TOL
+    assert _rel(dysum, gy.sum((0, 1, 2))) < TOL
 
 
 def test_colsum_segments_and_dropout(dev):

@@ -69,55 +69,72 @@ __device__ __forceinline__ void build_h(const TecmSpatial& d, const float* xrow,
   }
 }
 
-// Weights staged once per block.  W*_s rows are padded to CP floats (cols 22,23 = 0) so a row is six
-// broadcast ds_read_b128.
-struct WeightsLds {
-  float* Wl;    // [C][CP]
-  float* Wr;    // [C][CP]
-  float* bl;    // [CP]
-  float* br;    // [CP]
-  float* bias;  // [CP]
-};
-constexpr int WEIGHT_FLOATS = 2 * C * CP + 3 * CP;
+// ------------------------------------------------------------------------------------------ dense math
+// All 22x22 products run on the f32 matrix cores (v_mfma_f32_32x32x2_f32) over LDS-resident operands:
+//   rows x [h | 1 | 0] (24 cols)  times  a 24 x 32 matrix stored k-major  ->  32-row x 32-col accumulator.
+// The constant-1 column 22 of `h` folds the bias in (row 22 of the k-major matrix holds it).
+// A-operand reads have an 8-way bank conflict (row pitch 24 words) -- 16 LDS cycles against a 64-cycle MFMA.
+constexpr int KM_FLOATS = CP * 32;          // one k-major 24 x 32 matrix
 
-__device__ __forceinline__ WeightsLds stage_weights(const TecmSpatial& d, float* base) {
-  WeightsLds w;
-  w.Wl = base;
-  w.Wr = w.Wl + C * CP;
-  w.bl = w.Wr + C * CP;
-  w.br = w.bl + CP;
-  w.bias = w.br + CP;
-  for (int i = threadIdx.x; i < C * CP; i += blockDim.x) {
-    const int r = i / CP, k = i - r * CP;
-    w.Wl[i] = k < C ? d.Wl[r * C + k] : 0.f;
-    w.Wr[i] = k < C ? d.Wr[r * C + k] : 0.f;
+struct MatsLds {
+  float* WlT;     // [k][c]: Wl[c][k], row 22 = bl              (x_l = [h|1] . WlT)
+  float* WrT;     // [k][c]: Wr[c][k], row 22 = br
+  float* WlE;     // [a][e]: Wl[a][Cin+e]                        (d emb += dxl . WlE)      backward only
+  float* WrE;     // [a][e]: Wr[a][Cin+e]
+  float* Sel;     // [k][e]: k == Cin+e                          (d emb += dout . Sel)
+};
+
+__device__ __forceinline__ void stage_mats(const TecmSpatial& d, float* base, MatsLds& m, bool bwd) {
+  m.WlT = base;
+  m.WrT = base + KM_FLOATS;
+  m.WlE = base + 2 * KM_FLOATS;
+  m.WrE = base + 3 * KM_FLOATS;
+  m.Sel = base + 4 * KM_FLOATS;
+  for (int i = threadIdx.x; i < KM_FLOATS; i += blockDim.x) {
+    const int k = i >> 5, c = i & 31;
+    float wl = 0.f, wr = 0.f;
+    if (c < C) {
+      if (k < C) { wl = d.Wl[c * C + k]; wr = d.Wr[c * C + k]; }
+      else if (k == C) { wl = d.bl[c]; wr = d.br[c]; }
+    }
+    m.WlT[i] = wl;
+    m.WrT[i] = wr;
+    if (bwd) {
+      const bool ok = k < C && c < d.Demb;
+      m.WlE[i] = ok ? d.Wl[k * C + d.Cin + c] : 0.f;
+      m.WrE[i] = ok ? d.Wr[k * C + d.Cin + c] : 0.f;
+      m.Sel[i] = (c < d.Demb && k == d.Cin + c) ? 1.f : 0.f;
+    }
   }
-  if (threadIdx.x < CP) {
-    const int k = threadIdx.x;
-    w.bl[k] = k < C ? d.bl[k] : 0.f;
-    w.br[k] = k < C ? d.br[k] : 0.f;
-    w.bias[k] = k < C ? d.bias[k] : 0.f;
-  }
-  return w;
 }
 
-// out = W h + b, W rows in LDS (wave-uniform addresses -> broadcast reads)
-__device__ __forceinline__ void dense_lds(const float* Ws, const float* bs, const float (&h)[C], float (&out)[C]) {
+// acc(32 rows x 32 cols) += A[row0 .. row0+31][0..23] . KM   (rows clamped to [0, nrows): duplicates are discarded)
+__device__ __forceinline__ void mfma_rows(f32x16& acc, const float* A, int row0, int nrows, const float* KM, int lane) {
+  const int i = lane & 31, kq = lane >> 5;
+  int row = row0 + i;
+  row = row < nrows ? row : nrows - 1;
+  const float* ar = A + row * CP + kq;
+  const float* br = KM + kq * 32 + i;
 #pragma unroll
-  for (int c = 0; c < C; ++c) {
-    const float4* wr = reinterpret_cast<const float4*>(Ws + c * CP);
-    float a = bs[c];
+  for (int s = 0; s < CP / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[2 * s], br[2 * s * 32], acc, 0, 0, 0);
+}
+
+// OUT[rows][0..23] = A[rows][0..23] . KM for rows [beg, end) of an LDS array; the 4 waves take 32-row blocks in turn.
+__device__ __forceinline__ void dense_rows(float* OUT, const float* A, int beg, int end, const float* KM, int wave,
+                                           int lane) {
+  const int j = lane & 31, kq = lane >> 5;
+  for (int r0 = beg + 32 * wave; r0 < end; r0 += 128) {
+    f32x16 acc;
 #pragma unroll
-    for (int q = 0; q < CP / 4; ++q) {
-      const float4 w4 = wr[q];
-      a = fmaf(w4.x, h[4 * q], a);
-      a = fmaf(w4.y, h[4 * q + 1], a);
-      if (4 * q + 2 < C) a = fmaf(w4.z, h[4 * q + 2], a);
-      if (4 * q + 3 < C) a = fmaf(w4.w, h[4 * q + 3], a);
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    mfma_rows(acc, A, r0, end, KM, lane);
+    if (j < CP) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = r0 + (e & 3) + 8 * (e >> 2) + 4 * kq;
+        if (row < end) OUT[row * CP + j] = acc[e];
+      }
     }
-    out[c] = a;
-    // keep the scheduler from hoisting all 132 broadcast loads of the 22 rows at once (register blow-up)
-    if (c & 1) __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -158,10 +175,20 @@ __device__ __forceinline__ void logits(const float (&xlj)[C], const float (&xr)[
   }
 }
 
+// h rows of the window -> LDS ([h | 1 | 0]); a thread per row
+__device__ __forceinline__ void build_window(const TecmSpatial& d, float* hw, int wa, int wb, int lo, int64_t grow,
+                                             const float* temb_p, int b, int t) {
+  for (int w = wa + threadIdx.x; w < wb; w += blockDim.x) {
+    float h[C];
+    build_h(d, d.x + (grow + lo + w) * d.Cin, lo + w, temb_p, b, t, h);
+    store_row(hw + w * CP, h, 1.0f, 0.f);
+  }
+}
+
 // ------------------------------------------------------------------------------------------ forward
 __global__ __launch_bounds__(256) void spatial_fwd_kernel(const TecmSpatial d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tile = blockIdx.x;
   const int b = blockIdx.y / d.L, t = blockIdx.y - b * d.L;
   const bool use_edges = (t * d.B + b) < d.graphs_with_edges;
@@ -171,47 +198,34 @@ __global__ __launch_bounds__(256) void spatial_fwd_kernel(const TecmSpatial d) {
   const int hi = use_edges ? d.tile_hi[tile] : n1;
   const int W = hi - lo;
   const int wm4 = (d.win_max + 3) & ~3;
-  float* xin = smem;                                   // [wm4][Cin]
-  float* xlw = xin + ((wm4 * d.Cin + 3) & ~3);         // [wm4][CP]
-  float* outt = xlw + wm4 * CP;                        // [tile_nodes][CP]
-  float* temb = outt + d.tile_nodes * CP;              // [32]
-  const WeightsLds ws = stage_weights(d, temb + 32);
+  float* hw = smem;                                    // [wm4][CP]  [h | 1 | 0]
+  float* xlw = hw + wm4 * CP;                          // [wm4][CP]  x_l of the window
+  float* xrw = xlw + wm4 * CP;                         // [tile_nodes][CP]  x_r of the tile, later the output tile
+  float* temb = xrw + d.tile_nodes * CP;               // [32]
+  MatsLds mats;
+  stage_mats(d, temb + 32, mats, false);
   const bool tf_uniform = d.tf_sn == 0;
-
   const int64_t grow = ((int64_t)b * d.L + t) * d.N;   // first row of this graph
-  {
-    const float* src = d.x + (grow + lo) * d.Cin;
-    for (int i = tid; i < W * d.Cin; i += 256) xin[i] = src[i];
-  }
   if (tf_uniform && tid < d.Demb) {
     const TimeIdx ti = load_time_idx(d, b, t, 0);
     temb[tid] = temporal_emb(d, ti, tid);
   }
-  float att[C];
+  float att[C], bias[C];
 #pragma unroll
-  for (int c = 0; c < C; ++c) att[c] = d.att[c];
+  for (int c = 0; c < C; ++c) { att[c] = d.att[c]; bias[c] = d.bias[c]; }
   __syncthreads();
-  const float* temb_p = tf_uniform ? temb : nullptr;
-
-  if (use_edges) {
-    for (int w = tid; w < W; w += 256) {
-      float h[C], xl[C];
-      build_h(d, xin + w * d.Cin, lo + w, temb_p, b, t, h);
-      dense_lds(ws.Wl, ws.bl, h, xl);
-      store_row(xlw + w * CP, xl, 0.f, 0.f);
-    }
-    __syncthreads();
-  }
+  build_window(d, hw, 0, W, lo, grow, tf_uniform ? temb : nullptr, b, t);
+  __syncthreads();
+  dense_rows(xlw, hw, 0, W, mats.WlT, wave, lane);                          // x_l for the whole window
+  dense_rows(xrw - (n0 - lo) * CP, hw, n0 - lo, n1 - lo, mats.WrT, wave, lane);   // x_r for the tile
+  __syncthreads();
 
   const int i = n0 + tid;
   if (i < n1) {
-    float h[C], xr[C], xls[C];
-    build_h(d, xin + (i - lo) * d.Cin, i, temb_p, b, t, h);
-    dense_lds(ws.Wr, ws.br, h, xr);
-    if (use_edges)
-      load_row(xlw + (i - lo) * CP, xls);
-    else
-      dense_lds(ws.Wl, ws.bl, h, xls);
+    const int wi = i - lo;
+    float xr[C], xls[C];
+    load_row(xrw + tid * CP, xr);
+    load_row(xlw + wi * CP, xls);
     float m[H], z[H], acc[C];
 #pragma unroll
     for (int hh = 0; hh < H; ++hh) { m[hh] = -INFINITY; z[hh] = 0.f; }
@@ -245,23 +259,24 @@ __global__ __launch_bounds__(256) void spatial_fwd_kernel(const TecmSpatial d) {
         for (int c = 0; c < CH; ++c) acc[hh * CH + c] = acc[hh * CH + c] * corr + pm * xlj[hh * CH + c];
       }
     }
-    float o[C];
+    float h[C], o[C];
+    load_row(hw + wi * CP, h);
 #pragma unroll
     for (int hh = 0; hh < H; ++hh) {
       const float inv = 1.0f / (z[hh] + 1e-16f);
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
         const int k = hh * CH + c;
-        o[k] = h[k] + (acc[k] * inv + ws.bias[k]);
+        o[k] = h[k] + (acc[k] * inv + bias[k]);
       }
     }
-    store_row(outt + tid * CP, o, 0.f, 0.f);
+    store_row(xrw + tid * CP, o, 0.f, 0.f);           // this thread's x_r row is dead: reuse it for the output
   }
   __syncthreads();
   {
     const int nf4 = (n1 - n0) * CP / 4;
     float4* dst = reinterpret_cast<float4*>(d.out + (grow + n0) * CP);
-    const float4* src = reinterpret_cast<const float4*>(outt);
+    const float4* src = reinterpret_cast<const float4*>(xrw);
     for (int q = tid; q < nf4; q += 256) dst[q] = src[q];
   }
 }
@@ -295,25 +310,19 @@ __global__ __launch_bounds__(256) void spatial_bwd_kernel(const TecmSpatial d, c
   const int W = hi - lo;
   const int wm4 = (d.win_max + 3) & ~3;
   const int Demb = d.Demb, Cin = d.Cin;
-  float* hw = smem;                        // [wm4][CP]   h, column 22 = 1 (bias trick), column 23 = 0
+  float* hw = smem;                        // [wm4][CP]   [h | 1 | 0]
   float* xlw = hw + wm4 * CP;              // [wm4][CP]
   float* dxlw = xlw + wm4 * CP;            // [wm4][CP]
-  float* dxr = dxlw + wm4 * CP;            // [tile_nodes][CP]
-  float* dnode = dxr + d.tile_nodes * CP;  // [wm4][Demb]
+  float* dxr = dxlw + wm4 * CP;            // [tile_nodes][CP]  x_r of the tile first, then d x_r
+  float* gt = dxr + d.tile_nodes * CP;     // [tile_nodes][CP]  dout rows of the tile
+  float* dnode = gt + d.tile_nodes * CP;   // [wm4][Demb]
   float* temb = dnode + wm4 * Demb;        // [32]
   float* tsum = temb + 32;                 // [32]
   float* vec = tsum + 32;                  // [CP]      datt block reduction
-  float* WlE = vec + CP;                   // [Demb<=32][CP]  WlE[e][a] = Wl[a][Cin+e]
-  float* WrE = WlE + 32 * CP;              // [32][CP]
-  const WeightsLds ws = stage_weights(d, WrE + 32 * CP);
+  MatsLds mats;
+  stage_mats(d, vec + CP, mats, true);
   const bool tf_uniform = d.tf_sn == 0;
 
-  for (int q = tid; q < 32 * CP; q += 256) {
-    const int e = q / CP, a = q - e * CP;
-    const bool ok = e < Demb && a < C;
-    WlE[q] = ok ? d.Wl[a * C + Cin + e] : 0.f;
-    WrE[q] = ok ? d.Wr[a * C + Cin + e] : 0.f;
-  }
   for (int q = tid; q < W * Demb; q += 256) dnode[q] = 0.f;
   if (tid < CP) vec[tid] = 0.f;
   float att[C], datt_acc[C];
@@ -332,6 +341,7 @@ __global__ __launch_bounds__(256) void spatial_bwd_kernel(const TecmSpatial d, c
     const bool use_edges = (t * d.B + b) < d.graphs_with_edges;
     const int wa = use_edges ? 0 : n0 - lo;
     const int wb = use_edges ? W : n1 - lo;
+    const int ta = n0 - lo, tb = n1 - lo;             // tile rows inside the window
     const int64_t grow = ((int64_t)b * d.L + t) * d.N;
     __syncthreads();                                  // previous timestep fully consumed
     TimeIdx tiu;
@@ -339,19 +349,13 @@ __global__ __launch_bounds__(256) void spatial_bwd_kernel(const TecmSpatial d, c
     if (tf_uniform && tid < Demb) temb[tid] = temporal_emb(d, tiu, tid);
     if (tid < 32) tsum[tid] = 0.f;
     __syncthreads();
-    const float* temb_p = tf_uniform ? temb : nullptr;
 
-    // ---- A: recompute h and x_l for the window, clear d x_l
-    for (int w = wa + tid; w < wb; w += 256) {
-      float h[C], xl[C];
-      build_h(d, d.x + (grow + lo + w) * Cin, lo + w, temb_p, b, t, h);
-      dense_lds(ws.Wl, ws.bl, h, xl);
-      store_row(hw + w * CP, h, 1.0f, 0.f);
-      store_row(xlw + w * CP, xl, 0.f, 0.f);
-      float4* z4 = reinterpret_cast<float4*>(dxlw + w * CP);
-#pragma unroll
-      for (int q = 0; q < CP / 4; ++q) z4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    // ---- A: h for the window, then x_l (window) and x_r (tile) on the matrix cores; clear d x_l
+    build_window(d, hw, wa, wb, lo, grow, tf_uniform ? temb : nullptr, b, t);
+    for (int q = wa * CP + tid; q < wb * CP; q += 256) dxlw[q] = 0.f;
+    __syncthreads();
+    dense_rows(xlw, hw, wa, wb, mats.WlT, wave, lane);
+    dense_rows(dxr - ta * CP, hw, ta, tb, mats.WrT, wave, lane);
     __syncthreads();
 
     // ---- B: per target node, two passes over its edges
@@ -359,12 +363,9 @@ __global__ __launch_bounds__(256) void spatial_bwd_kernel(const TecmSpatial d, c
     if (i < n1) {
       const int wi = i - lo;
       float xr[C], g[C], dxr_acc[C];
-      {
-        float h[C];
-        load_row(hw + wi * CP, h);
-        dense_lds(ws.Wr, ws.br, h, xr);
-      }
+      load_row(dxr + tid * CP, xr);
       load_row(gr.dout + (grow + i) * CP, g);
+      store_row(gt + tid * CP, g, 0.f, 0.f);
 #pragma unroll
       for (int c = 0; c < C; ++c) dxr_acc[c] = 0.f;
       const int64_t rowi = (int64_t)(t * d.B + b) * d.N + i;
@@ -431,47 +432,55 @@ __global__ __launch_bounds__(256) void spatial_bwd_kernel(const TecmSpatial d, c
 
     // ---- C1: [dWl | dbl] += dxl^T [h, 1] over the window, [dWr | dbr] += dxr^T [h, 1] over the tile
     outer_accumulate(accL, dxlw, hw, wa, wb, wave, lane);
-    outer_accumulate(accR, dxr - (n0 - lo) * CP, hw, n0 - lo, n1 - lo, wave, lane);
+    outer_accumulate(accR, dxr - ta * CP, hw, ta, tb, wave, lane);
 
-    // ---- C2: embedding part of dh -> node-table accumulators and temporal tables
-    for (int w0 = wa; w0 < wb; w0 += 256) {
-      const int w = w0 + tid;
-      const bool act = w < wb;
-      const int node = lo + w;
-      const bool intile = act && node >= n0 && node < n1;
-      float dl[C], dr[C];
+    // ---- C2: embedding part of dh = dxl.WlE (+ tile rows: dxr.WrE + dout.Sel) -> node-table accumulators and
+    //          the temporal tables, all three products chained into one MFMA accumulator per 32-row block
+    {
+      const int j = lane & 31, kq = lane >> 5;
+      float colsum = 0.f;
+      for (int r0 = wa + 32 * wave; r0 < wb; r0 += 128) {
+        f32x16 acc;
 #pragma unroll
-      for (int c = 0; c < C; ++c) { dl[c] = 0.f; dr[c] = 0.f; }
-      if (act) load_row(dxlw + w * CP, dl);
-      if (intile) load_row(dxr + (node - n0) * CP, dr);
-      TimeIdx ti;
-      if (act && !tf_uniform) ti = load_time_idx(d, b, t, node);
-      for (int e = 0; e < Demb; ++e) {
-        float v = 0.f;
-        if (act) {
-          float wl[C], wr[C];
-          load_row(WlE + e * CP, wl);
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        mfma_rows(acc, dxlw, r0, wb, mats.WlE, lane);
+        const bool overlaps = r0 + 32 > ta && r0 < tb;                       // wave-uniform
+        if (overlaps) {
+          // tile operands are indexed relative to the tile; rows of this block outside the tile contribute 0
+          const int i = lane & 31;
+          const int row = r0 + i;
+          const bool in = row >= ta && row < tb;
+          const float* ar = dxr + (in ? row - ta : 0) * CP + kq;
+          const float* gg = gt + (in ? row - ta : 0) * CP + kq;
+          const float* b1 = mats.WrE + kq * 32 + i;
+          const float* b2 = mats.Sel + kq * 32 + i;
 #pragma unroll
-          for (int a = 0; a < C; ++a) v = fmaf(wl[a], dl[a], v);
-          if (intile) {
-            load_row(WrE + e * CP, wr);
-#pragma unroll
-            for (int a = 0; a < C; ++a) v = fmaf(wr[a], dr[a], v);
-            v += gr.dout[(grow + node) * CP + Cin + e];
-          }
-          dnode[w * Demb + e] += v;
-          if (!tf_uniform) {
-            atomicAdd(&gr.d_tod_tab[ti.tod * Demb + e], v);
-            atomicAdd(&gr.d_doy_tab[ti.doy * Demb + e], v);
-            atomicAdd(&gr.d_year_tab[ti.year * Demb + e], v);
-            atomicAdd(&gr.d_season_tab[ti.season * Demb + e], v);
+          for (int s = 0; s < CP / 2; ++s) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(in ? ar[2 * s] : 0.f, b1[2 * s * 32], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(in ? gg[2 * s] : 0.f, b2[2 * s * 32], acc, 0, 0, 0);
           }
         }
-        if (tf_uniform) {
-          const float sv = wave_sum(v);
-          if (lane == 0) atomicAdd(&tsum[e], sv);
+        if (j < Demb) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int row = r0 + (e & 3) + 8 * (e >> 2) + 4 * kq;
+            if (row < wb) {
+              const float v = acc[e];
+              dnode[row * Demb + j] += v;                                     // (row, j) has exactly one owner
+              if (tf_uniform) {
+                colsum += v;
+              } else {
+                const TimeIdx ti = load_time_idx(d, b, t, lo + row);
+                atomicAdd(&gr.d_tod_tab[ti.tod * Demb + j], v);
+                atomicAdd(&gr.d_doy_tab[ti.doy * Demb + j], v);
+                atomicAdd(&gr.d_year_tab[ti.year * Demb + j], v);
+                atomicAdd(&gr.d_season_tab[ti.season * Demb + j], v);
+              }
+            }
+          }
         }
       }
+      if (tf_uniform && j < Demb) atomicAdd(&tsum[j], colsum);
     }
     __syncthreads();
     if (tf_uniform && tid < Demb) {
@@ -548,8 +557,7 @@ extern "C" int tecm_spatial_fwd(const TecmSpatial* dp, void* stream) {
   if (rc) return rc;
   TECM_REQUIRE(d.out != nullptr && tecm_aligned(d.out, 16), TECM_E_ALIGN, "tecm_spatial_fwd: out must be 16-byte aligned");
   const int wm4 = (d.win_max + 3) & ~3;
-  const size_t lds = sizeof(float) * ((size_t)((wm4 * d.Cin + 3) & ~3) + (size_t)wm4 * CP + (size_t)d.tile_nodes * CP +
-                                      32 + WEIGHT_FLOATS);
+  const size_t lds = sizeof(float) * ((size_t)2 * wm4 * CP + (size_t)d.tile_nodes * CP + 32 + 2 * KM_FLOATS);
   TECM_REQUIRE(lds <= (size_t)kLdsBudget, TECM_E_LDS,
                "tecm_spatial_fwd: neighbour window of %d rows needs %zu B of LDS (> 160 KiB); renumber the graph "
                "(e.g. RCM) or shrink tile_nodes", d.win_max, lds);
@@ -581,8 +589,7 @@ extern "C" int tecm_spatial_bwd(const TecmSpatial* dp, const TecmSpatialGrads* g
   TECM_REQUIRE(g.partial_ld >= 2 * C * C + 4 * C, TECM_E_ARG, "tecm_spatial_bwd: partial_ld must be >= %d",
                2 * C * C + 4 * C);
   const int wm4 = (d.win_max + 3) & ~3;
-  size_t floats = (size_t)3 * wm4 * CP + (size_t)d.tile_nodes * CP + (size_t)wm4 * d.Demb + 64 + CP + 64 * CP +
-                  WEIGHT_FLOATS;
+  size_t floats = (size_t)3 * wm4 * CP + (size_t)2 * d.tile_nodes * CP + (size_t)wm4 * d.Demb + 64 + CP + 5 * KM_FLOATS;
   if (floats < 8192 + 64) floats = 8192 + 64;          // the final 4-wave MFMA reduction needs 2*4*32*32 floats
   const size_t lds = sizeof(float) * floats;
   TECM_REQUIRE(lds <= (size_t)kLdsBudget, TECM_E_LDS,

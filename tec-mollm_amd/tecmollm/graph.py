@@ -60,13 +60,13 @@ def tile_windows(rowptr: np.ndarray, colidx: np.ndarray, num_nodes: int, tile_no
 
 
 CP = 24
-WEIGHT_FLOATS = 2 * C_FEAT * CP + 3 * CP
+KM_FLOATS = CP * 32
 
 
 def lds_bytes_bwd(win: int, tile_nodes: int, demb: int = 16) -> int:
     """Dynamic LDS of spatial_bwd_kernel (must match csrc/spatial.hip:tecm_spatial_bwd)."""
     wm4 = (win + 3) & ~3
-    floats = 3 * wm4 * CP + tile_nodes * CP + wm4 * demb + 64 + CP + 64 * CP + WEIGHT_FLOATS
+    floats = 3 * wm4 * CP + 2 * tile_nodes * CP + wm4 * demb + 64 + CP + 5 * KM_FLOATS
     return 4 * max(floats, 8192 + 64)
 
 

@@ -112,7 +112,8 @@ typedef struct TecmSpatial {
   const float* tf; int64_t tf_sb, tf_sl, tf_sn, tf_sf;   /* (B,L,N,4) with element strides; sn may be 0 */
   const float* node_tab; const float* tod_tab; const float* doy_tab; const float* year_tab;
   const float* season_tab;                /* (rows, Demb) each */
-  int32_t year_rows, _pad;
+  int32_t year_rows;
+  int32_t tile_edges_max;                 /* max over tiles of rowptr[n1] - rowptr[n0] (CSR slice staged in LDS) */
   const float* Wl; const float* bl; const float* Wr; const float* br;   /* (C,C),(C) */
   const float* att;                       /* (H, Ch) */
   const float* bias;                      /* (C) */

@@ -204,6 +204,15 @@ __global__ __launch_bounds__(256) void spatial_fwd_kernel(const TecmSpatial d) {
   float* temb = xrw + d.tile_nodes * CP;               // [32]
   MatsLds mats;
   stage_mats(d, temb + 32, mats, false);
+  // CSR slice of this tile, window-relative, in LDS: the edge loop must not chase global memory per edge
+  int* eptr = reinterpret_cast<int*>(temb + 32 + 2 * KM_FLOATS);   // [tile_nodes + 1]
+  int* ecol = eptr + d.tile_nodes + 1;                             // [tile_edges_max]
+  if (use_edges) {
+    const int ebase = d.rowptr[n0];
+    for (int q = tid; q <= n1 - n0; q += 256) eptr[q] = d.rowptr[n0 + q] - ebase;
+    const int ne = d.rowptr[n1] - ebase;
+    for (int q = tid; q < ne; q += 256) ecol[q] = d.colidx[ebase + q] - lo;
+  }
   const bool tf_uniform = d.tf_sn == 0;
   const int64_t grow = ((int64_t)b * d.L + t) * d.N;   // first row of this graph
   if (tf_uniform && tid < d.Demb) {
@@ -234,15 +243,15 @@ __global__ __launch_bounds__(256) void spatial_fwd_kernel(const TecmSpatial d) {
     const uint32_t dth = d.alpha_drop.p > 0.f ? tecm_drop_thresh(d.alpha_drop.p) : 0u;
     const float dinv = d.alpha_drop.p > 0.f ? 1.0f / (1.0f - d.alpha_drop.p) : 1.0f;
     const int64_t rowi = (int64_t)(t * d.B + b) * d.N + i;     // row in the reference's (L*B*N) flattening
-    const int e0 = use_edges ? d.rowptr[i] : 0;
-    const int deg = use_edges ? d.rowptr[i + 1] - e0 : 0;
+    const int e0 = use_edges ? eptr[tid] : 0;
+    const int deg = use_edges ? eptr[tid + 1] - e0 : 0;
     for (int s = 0; s <= deg; ++s) {
       float xlj[C];
       if (s == deg) {
 #pragma unroll
         for (int c = 0; c < C; ++c) xlj[c] = xls[c];
       } else {
-        load_row(xlw + (d.colidx[e0 + s] - lo) * CP, xlj);
+        load_row(xlw + ecol[e0 + s] * CP, xlj);
       }
       float e[H];
       logits(xlj, xr, att, e);
@@ -321,6 +330,14 @@ __global__ __launch_bounds__(256) void spatial_bwd_kernel(const TecmSpatial d, c
   float* vec = tsum + 32;                  // [CP]      datt block reduction
   MatsLds mats;
   stage_mats(d, vec + CP, mats, true);
+  int* eptr = reinterpret_cast<int*>(vec + CP + 5 * KM_FLOATS);    // [tile_nodes + 1]  CSR slice of the tile
+  int* ecol = eptr + d.tile_nodes + 1;                             // [tile_edges_max]  window-relative sources
+  {
+    const int ebase = d.rowptr[n0];
+    for (int q = tid; q <= n1 - n0; q += 256) eptr[q] = d.rowptr[n0 + q] - ebase;
+    const int ne = d.rowptr[n1] - ebase;
+    for (int q = tid; q < ne; q += 256) ecol[q] = d.colidx[ebase + q] - lo;
+  }
   const bool tf_uniform = d.tf_sn == 0;
 
   for (int q = tid; q < W * Demb; q += 256) dnode[q] = 0.f;
@@ -369,14 +386,14 @@ __global__ __launch_bounds__(256) void spatial_bwd_kernel(const TecmSpatial d, c
 #pragma unroll
       for (int c = 0; c < C; ++c) dxr_acc[c] = 0.f;
       const int64_t rowi = (int64_t)(t * d.B + b) * d.N + i;
-      const int e0 = use_edges ? d.rowptr[i] : 0;
-      const int deg = use_edges ? d.rowptr[i + 1] - e0 : 0;
+      const int e0 = use_edges ? eptr[tid] : 0;
+      const int deg = use_edges ? eptr[tid + 1] - e0 : 0;
       // pass 1: online softmax statistics and the numerator of dot_h = sum_j alpha_ij dalpha_ij
       float m[H], z[H], num[H];
 #pragma unroll
       for (int hh = 0; hh < H; ++hh) { m[hh] = -INFINITY; z[hh] = 0.f; num[hh] = 0.f; }
       for (int s = 0; s <= deg; ++s) {
-        const int j = s == deg ? wi : d.colidx[e0 + s] - lo;
+        const int j = s == deg ? wi : ecol[e0 + s];
         float xlj[C], e[H];
         load_row(xlw + j * CP, xlj);
         logits(xlj, xr, att, e);
@@ -401,7 +418,7 @@ __global__ __launch_bounds__(256) void spatial_bwd_kernel(const TecmSpatial d, c
       }
       // pass 2: gradients
       for (int s = 0; s <= deg; ++s) {
-        const int j = s == deg ? wi : d.colidx[e0 + s] - lo;
+        const int j = s == deg ? wi : ecol[e0 + s];
         float xlj[C], e[H];
         load_row(xlw + j * CP, xlj);
         logits(xlj, xr, att, e);
@@ -543,6 +560,7 @@ int check_common(const char* who, const TecmSpatial& d) {
                    (int64_t)d.num_tiles * d.tile_nodes >= d.N && d.win_max >= 1,
                TECM_E_ARG, "%s: bad node tiling", who);
   TECM_REQUIRE(d.year_rows > 0, TECM_E_ARG, "%s: year_rows must be positive", who);
+  TECM_REQUIRE(d.tile_edges_max >= 0, TECM_E_ARG, "%s: tile_edges_max must be the max edge count of a tile", who);
   return TECM_OK;
 }
 
@@ -557,7 +575,8 @@ extern "C" int tecm_spatial_fwd(const TecmSpatial* dp, void* stream) {
   if (rc) return rc;
   TECM_REQUIRE(d.out != nullptr && tecm_aligned(d.out, 16), TECM_E_ALIGN, "tecm_spatial_fwd: out must be 16-byte aligned");
   const int wm4 = (d.win_max + 3) & ~3;
-  const size_t lds = sizeof(float) * ((size_t)2 * wm4 * CP + (size_t)d.tile_nodes * CP + 32 + 2 * KM_FLOATS);
+  const size_t lds = sizeof(float) * ((size_t)2 * wm4 * CP + (size_t)d.tile_nodes * CP + 32 + 2 * KM_FLOATS +
+                                      d.tile_nodes + 1 + d.tile_edges_max);
   TECM_REQUIRE(lds <= (size_t)kLdsBudget, TECM_E_LDS,
                "tecm_spatial_fwd: neighbour window of %d rows needs %zu B of LDS (> 160 KiB); renumber the graph "
                "(e.g. RCM) or shrink tile_nodes", d.win_max, lds);
@@ -589,7 +608,8 @@ extern "C" int tecm_spatial_bwd(const TecmSpatial* dp, const TecmSpatialGrads* g
   TECM_REQUIRE(g.partial_ld >= 2 * C * C + 4 * C, TECM_E_ARG, "tecm_spatial_bwd: partial_ld must be >= %d",
                2 * C * C + 4 * C);
   const int wm4 = (d.win_max + 3) & ~3;
-  size_t floats = (size_t)3 * wm4 * CP + (size_t)2 * d.tile_nodes * CP + (size_t)wm4 * d.Demb + 64 + CP + 5 * KM_FLOATS;
+  size_t floats = (size_t)3 * wm4 * CP + (size_t)2 * d.tile_nodes * CP + (size_t)wm4 * d.Demb + 64 + CP + 5 * KM_FLOATS +
+                  d.tile_nodes + 1 + d.tile_edges_max;
   if (floats < 8192 + 64) floats = 8192 + 64;          // the final 4-wave MFMA reduction needs 2*4*32*32 floats
   const size_t lds = sizeof(float) * floats;
   TECM_REQUIRE(lds <= (size_t)kLdsBudget, TECM_E_LDS,

@@ -55,7 +55,7 @@ class TecmSpatial(C.Structure):
         ("tf", c_f32p), ("tf_sb", C.c_int64), ("tf_sl", C.c_int64), ("tf_sn", C.c_int64), ("tf_sf", C.c_int64),
         ("node_tab", c_f32p), ("tod_tab", c_f32p), ("doy_tab", c_f32p), ("year_tab", c_f32p),
         ("season_tab", c_f32p),
-        ("year_rows", C.c_int32), ("_pad", C.c_int32),
+        ("year_rows", C.c_int32), ("tile_edges_max", C.c_int32),
         ("Wl", c_f32p), ("bl", c_f32p), ("Wr", c_f32p), ("br", c_f32p),
         ("att", c_f32p), ("bias", c_f32p),
         ("rowptr", C.c_void_p), ("colidx", C.c_void_p), ("tile_lo", C.c_void_p), ("tile_hi", C.c_void_p),

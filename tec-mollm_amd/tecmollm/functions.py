@@ -91,6 +91,7 @@ class SpatialFn(torch.autograd.Function):
         d.B, d.L, d.N, d.Cin, d.Demb, d.H = B, L, N, Cin, Demb, heads
         d.graphs_with_edges = min(int(R), B * L)
         d.num_tiles, d.tile_nodes, d.win_max = meta.num_tiles, meta.tile_nodes, meta.win_max
+        d.tile_edges_max = meta.tile_edges_max
         d.x = x.data_ptr()
         d.tf = tf.data_ptr()
         d.tf_sb, d.tf_sl, d.tf_sn, d.tf_sf = tf.stride()

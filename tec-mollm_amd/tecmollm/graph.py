@@ -27,6 +27,7 @@ class GraphMeta:
     tile_nodes: int
     num_tiles: int
     win_max: int
+    tile_edges_max: int
     rowptr: torch.Tensor   # int32 (N+1) device
     colidx: torch.Tensor   # int32 (E') device
     tile_lo: torch.Tensor  # int32 (num_tiles) device
@@ -63,10 +64,10 @@ CP = 24
 KM_FLOATS = CP * 32
 
 
-def lds_bytes_bwd(win: int, tile_nodes: int, demb: int = 16) -> int:
+def lds_bytes_bwd(win: int, tile_nodes: int, demb: int = 16, tile_edges: int = 0) -> int:
     """Dynamic LDS of spatial_bwd_kernel (must match csrc/spatial.hip:tecm_spatial_bwd)."""
     wm4 = (win + 3) & ~3
-    floats = 3 * wm4 * CP + 2 * tile_nodes * CP + wm4 * demb + 64 + CP + 5 * KM_FLOATS
+    floats = 3 * wm4 * CP + 2 * tile_nodes * CP + wm4 * demb + 64 + CP + 5 * KM_FLOATS + tile_nodes + 1 + tile_edges
     return 4 * max(floats, 8192 + 64)
 
 
@@ -79,17 +80,20 @@ def build(edge_index: torch.Tensor, num_nodes: int, device: torch.device, demb: 
         tn = min(tn, 256)
         lo, hi = tile_windows(rowptr, colidx, num_nodes, tn)
         wmax = int((hi - lo).max())
-        if lds_bytes_bwd(wmax, tn, demb) <= LDS_BYTES - 4096:
-            chosen = (tn, lo, hi, wmax)
+        bounds = np.minimum(np.arange(lo.size + 1) * tn, num_nodes)
+        emax = int(np.diff(rowptr[bounds]).max())
+        if lds_bytes_bwd(wmax, tn, demb, emax) <= LDS_BYTES - 4096:
+            chosen = (tn, lo, hi, wmax, emax)
             break
     if chosen is None:
         raise ValueError(
             "graph bandwidth too large for the 160 KiB LDS neighbour window even with 1-node tiles; "
             "renumber the nodes (e.g. reverse Cuthill-McKee) so that neighbours have nearby ids")
-    tn, lo, hi, wmax = chosen
+    tn, lo, hi, wmax, emax = chosen
     to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)   # noqa: E731
     return GraphMeta(num_nodes=num_nodes, num_edges=int(colidx.size), max_deg=int(deg.max()) if deg.size else 0,
-                     tile_nodes=tn, num_tiles=int(lo.size), win_max=wmax, rowptr=to(rowptr),
+                     tile_nodes=tn, num_tiles=int(lo.size), win_max=wmax, tile_edges_max=emax,
+                     rowptr=to(rowptr),
                      colidx=to(colidx if colidx.size else np.zeros(1, np.int32)), tile_lo=to(lo), tile_hi=to(hi))
 
 

@@ -108,10 +108,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs MI355X GPUs (the HIP path has no CPU fallback)")
+    local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # backend "nccl" IS RCCL on ROCm; TECM_DIST_BACKEND=gloo only exists to rehearse the multi-rank code path
+        # on a single-GPU box (two ranks cannot share one device under RCCL)
+        backend = os.environ.get("TECM_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from src.model.tec_mollm import TEC_MoLLM
     from tecmollm import ops
@@ -138,7 +145,10 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier(device_ids=[local])
+            if dist.get_backend() == "nccl":
+                dist.barrier(device_ids=[local])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):

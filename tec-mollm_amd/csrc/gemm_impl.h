@@ -420,7 +420,7 @@ __global__ __launch_bounds__(threads_for(BN), (AVEC == 4 && BVEC == 4) ? (thread
                                                                                            int k_chunk) {
   constexpr int NTHREADS = threads_for(BN);
   constexpr int NWAVES = NTHREADS / 64;
-  constexpr int WN = BN >= 128 ? (NWAVES == 8 ? 4 : 2) : 1;
+  constexpr int WN = BN >= 128 ? (NWAVES == 8 ? 4 : 2) : (BN == 64 ? 2 : 1);
   constexpr int WM = NWAVES / WN;
   constexpr int WTM = BM / WM;
   constexpr int WTN = BN / WN;

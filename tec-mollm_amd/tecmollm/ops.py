@@ -149,7 +149,7 @@ def _kernel_name(g: TecmGemm, use16: bool = False) -> str:
         pair = (2, 1) if av >= 2 else (1, 1)
     else:
         pair = (4, 2) if (av == 4 and bv >= 2) else (1, 1)
-    bn = 32 if g.N <= 32 else 128
+    bn = 32 if g.N <= 32 else (64 if g.N <= 64 else 128)
     return f"gemm_kernel<{g.a_layout},{g.b_layout},{pair[0]},{pair[1]},{bn}>"
 
 
@@ -180,7 +180,7 @@ def pick_split_k(Mo: int, No: int, K: int, target_blocks: int = 512, min_chunk: 
                  max_splits: int = 256) -> int:
     """Split the (huge) reduction dim of a weight-gradient GEMM so the grid fills 256 CUs; capped because every
     split costs one slab of partial sums that the reducer has to read back."""
-    tiles = ((Mo + 127) // 128) * ((No + 127) // 128 if No > 32 else 1)
+    tiles = ((Mo + 127) // 128) * ((No + 127) // 128 if No > 64 else 1)
     s = max(1, target_blocks // max(tiles, 1))
     s = min(s, max(1, K // min_chunk), max_splits)
     return int(s)

@@ -66,6 +66,23 @@ def make_config(args):
     }
 
 
+def pmc_traffic(kernel: str, args):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
+    separate runs of this same command, gfx950 corrections applied by tools/pmc_traffic.py); None when the
+    committed passes do not cover this configuration."""
+    if args.batch != 8 or args.L_in != 48 or args.precision != "fp32" or args.gat != "per_timestep":
+        return None
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_fp32_B8.json")
+    try:
+        with open(path) as f:
+            k = json.load(f)["kernels"].get(kernel)
+        return None if k is None else {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"],
+                                       "fetch": k["fetch_bytes_per_launch"], "write": k["write_bytes_per_launch"],
+                                       "source": "profiles/r01_pmc_traffic_fp32_B8.json"}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(cfg, args):
     """The CPU oracle's full train step (fwd + Huber + bwd + clip + AdamW), fp32, on the host cores this
     process may use, one timed step at B = --cpu-batch after a forward-only warm-up of allocator/threads."""
@@ -176,7 +193,7 @@ def main():
                 achieved = a["flops"] / (a["ms"] * 1e-3) / 1e12
                 peak = BF16_MFMA_PEAK_TFLOPS if "bf16" in name else F32_MFMA_PEAK_TFLOPS
                 roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak,
-                        "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                        "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": pmc_traffic(name, args),
                         "launches": a["n"], "avg_launch_ms": round(a["ms"] / a["n"], 4),
                         "share_of_step": round(a["ms"] / (dt * 1e3), 4),
                         "all_gemm_share_of_step": round(sum(v["ms"] for v in agg.values()) / (dt * 1e3), 4)}

@@ -169,6 +169,14 @@ def test_full_step_L96_stress_shape(dev):
     assert res["fwd_rel"] < TOL and res["grad_rel_max"] < TOL, (res["fwd_rel"], res["grad_worst"], res["grad_rel_max"])
 
 
+def test_full_step_L336_six_layers_T21(dev):
+    """The reference's 4-GPU script shape (scripts/train_with_dynamic_naming.sh:4-11): L_in=336, 6 GPT-2 layers
+    -> 21 tokens per sequence (generic-T attention path), head 16128 -> 4032 -> 12."""
+    cfg = R.default_config(L_in=336, L_out=12, num_nodes=6, llm_layers=6)
+    res = compare_forward_backward(cfg, B=1, grid=(2, 3), threshold_km=170.0, gat_graphs="per_timestep", seed=8)
+    assert res["fwd_rel"] < TOL and res["grad_rel_max"] < TOL, (res["fwd_rel"], res["grad_worst"], res["grad_rel_max"])
+
+
 def test_full_size_graph_B1_against_oracle(dev):
     """BASELINE config shape (L_in=48, N=2911, E=20924) at B=1: forward + every trainable gradient."""
     cfg = R.default_config(L_in=48, L_out=12, num_nodes=2911)

@@ -201,6 +201,69 @@ int tecm_conv_weight_unpack(const float* dpack, float* dw, int32_t Cout, int32_t
 int tecm_transpose_scale(const float* src, int64_t lds, float* dst, int64_t ldd, int32_t rows,
                          int32_t cols, float scale, void* stream);
 
+/* ------------------------------------------------------------------ the shell around the step
+ * (2) optimizer step of train.py:92-109 + :358-366 on FLAT buffers: global-norm clip + AdamW in two
+ * launches, no host sync.  Semantics of torch.nn.utils.clip_grad_norm_(max_norm) followed by
+ * torch.optim.AdamW(betas, eps, weight_decay).step() (decoupled decay, bias-corrected):
+ *   g      = grad * grad_scale                          (grad_scale folds the data-parallel 1/world mean)
+ *   norm   = ||g||_2 over all n values ; coef = min(1, max_norm / (norm + 1e-6))   (max_norm <= 0: coef = 1)
+ *   g     *= coef ; p *= 1 - lr*wd ; m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g
+ *   p     -= (lr / (1-b1^step)) * m / (sqrt(v)/sqrt(1-b2^step) + eps)
+ * total_norm_out[0] = norm (device scalar, optional).  zero_grad != 0 clears grad in the same pass
+ * (optimizer.zero_grad(), train.py:105).  partials: >= TECM_NORM_BLOCKS doubles of workspace. */
+#define TECM_NORM_BLOCKS 512
+typedef struct {
+  int64_t n;
+  float* param; float* grad; float* exp_avg; float* exp_avg_sq;
+  double* partials;
+  float* total_norm_out;
+  float lr, beta1, beta2, eps, weight_decay, max_norm, grad_scale;
+  int32_t step;        /* 1-based count of this update (bias correction) */
+  int32_t zero_grad;
+  int32_t _pad;
+} TecmAdamW;
+int tecm_adamw_clip_step(const TecmAdamW* a, void* stream);
+
+/* (3) evaluation metrics on device (src/evaluation/metrics.py:10-89, :119-183): per prediction horizon h
+ * accumulate, over all (sample, node) pairs of one batch, the sufficient statistics of
+ * evaluate_metrics(): after the non-finite guard on scaled predictions (:139-145, -> 0), the
+ * StandardScaler inverse transform t = y*scale + mean (:36-37, rounded to f32 twice as sklearn does
+ * on f32 input), nan_to_num(nan 0, +inf 100, -inf 0) (:40-46) and the clip of predictions to
+ * [clip_lo, clip_hi] = [0, 200] TECU (:50-51).  pred/target are addressed as
+ * base[s*stride_s + h*stride_h + i*stride_i] (element strides), so the model's permuted output view
+ * (tec_mollm.py:123) is read in place.  stats: (H, 8) doubles, ACCUMULATED across calls:
+ *   [count, sum t, sum p, sum t^2, sum p^2, sum t*p, sum |t-p|, sum (t-p)^2]. */
+#define TECM_METRIC_STATS 8
+typedef struct {
+  const float* pred; int64_t p_stride_s, p_stride_h, p_stride_i;
+  const float* target; int64_t t_stride_s, t_stride_h, t_stride_i;
+  int64_t S; int32_t H; int32_t _pad; int64_t I;      /* samples, horizons, values per (sample, horizon) */
+  double mean, scale;                                   /* scaler.mean_[0], scaler.scale_[0]; (0,1) = already unscaled */
+  float clip_lo, clip_hi; int32_t clip;                /* clip != 0: clamp predictions */
+  int32_t _pad2;
+  double* stats;
+} TecmMetrics;
+int tecm_metrics_accumulate(const TecmMetrics* m, void* stream);
+
+/* (4) sliding-window batch assembly from device-resident series (SlidingWindowSamplerDataset.__getitem__
+ * src/data/dataset.py:65-99 + the harness reshapes train.py:62-65, :76): for sample b with window
+ * start a = starts[b] (already multiplied by the dataset stride):
+ *   x_out[b, t, :, :]   = X[a + t, :, :]                       t < L_in     (B, L_in, N*C) contiguous
+ *   tf_out[b, t, :]     = TF[a + t, :]                                       (B, L_in, F_t)
+ *   y_out[b, h, i]      = Y[a + L_in - 1, i, h]                h < L_out    (B, L_out, N): the target
+ *                         already in the (B, L_out, N, 1) order of train.py:76
+ * X (T, N*C), TF (T, F_t), Y (T, N, L_out), starts (B) int64 on the device.  Out-of-range windows are
+ * rejected on the host only when starts_host_check is given (same values, host memory); the kernel
+ * clamps nothing. */
+typedef struct {
+  const float* X; const float* TF; const float* Y; const int64_t* starts;
+  const int64_t* starts_host_check;
+  int64_t T; int64_t row; /* N*C floats per time step */
+  int32_t N, L_in, L_out, F_t, B, _pad;
+  float* x_out; float* tf_out; float* y_out;
+} TecmWindowBatch;
+int tecm_window_batch(const TecmWindowBatch* w, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -73,6 +73,41 @@ class TecmSpatialGrads(C.Structure):
     ]
 
 
+class TecmAdamW(C.Structure):
+    _fields_ = [
+        ("n", C.c_int64),
+        ("param", c_f32p), ("grad", c_f32p), ("exp_avg", c_f32p), ("exp_avg_sq", c_f32p),
+        ("partials", C.c_void_p), ("total_norm_out", c_f32p),
+        ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+        ("weight_decay", C.c_float), ("max_norm", C.c_float), ("grad_scale", C.c_float),
+        ("step", C.c_int32), ("zero_grad", C.c_int32), ("_pad", C.c_int32),
+    ]
+
+
+class TecmMetrics(C.Structure):
+    _fields_ = [
+        ("pred", c_f32p), ("p_stride_s", C.c_int64), ("p_stride_h", C.c_int64), ("p_stride_i", C.c_int64),
+        ("target", c_f32p), ("t_stride_s", C.c_int64), ("t_stride_h", C.c_int64), ("t_stride_i", C.c_int64),
+        ("S", C.c_int64), ("H", C.c_int32), ("_pad", C.c_int32), ("I", C.c_int64),
+        ("mean", C.c_double), ("scale", C.c_double),
+        ("clip_lo", C.c_float), ("clip_hi", C.c_float), ("clip", C.c_int32), ("_pad2", C.c_int32),
+        ("stats", C.c_void_p),
+    ]
+
+
+class TecmWindowBatch(C.Structure):
+    _fields_ = [
+        ("X", c_f32p), ("TF", c_f32p), ("Y", c_f32p), ("starts", C.c_void_p), ("starts_host_check", C.c_void_p),
+        ("T", C.c_int64), ("row", C.c_int64),
+        ("N", C.c_int32), ("L_in", C.c_int32), ("L_out", C.c_int32), ("F_t", C.c_int32), ("B", C.c_int32),
+        ("_pad", C.c_int32),
+        ("x_out", c_f32p), ("tf_out", c_f32p), ("y_out", c_f32p),
+    ]
+
+TECM_NORM_BLOCKS = 512
+TECM_METRIC_STATS = 8
+
+
 EXPORTS = {
     "tecm_abi_version": (C.c_int, []),
     "tecm_last_error": (C.c_char_p, []),
@@ -102,6 +137,9 @@ EXPORTS = {
     "tecm_conv_weight_unpack": (C.c_int, [c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "tecm_transpose_scale": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_float,
                                        C.c_void_p]),
+    "tecm_adamw_clip_step": (C.c_int, [C.POINTER(TecmAdamW), C.c_void_p]),
+    "tecm_metrics_accumulate": (C.c_int, [C.POINTER(TecmMetrics), C.c_void_p]),
+    "tecm_window_batch": (C.c_int, [C.POINTER(TecmWindowBatch), C.c_void_p]),
 }
 
 _lib: Optional[C.CDLL] = None

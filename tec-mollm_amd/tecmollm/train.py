@@ -7,8 +7,9 @@ MI355X-first differences from the reference's DDP wrapper (train.py:353-354):
     config); `p.grad` are views into it, so autograd accumulates in place and the data-parallel exchange
     is a single RCCL all-reduce over xGMI per optimizer step -- not one per micro-batch (the reference
     has no `no_sync()` around its accumulation loop);
-  * gradient clipping is one fused norm over the flat buffer, without a host sync.
-PyTorch owns the optimizer state; `torch.optim.AdamW(fused=True)` runs on the flat views.
+  * the 1/world mean, clip_grad_norm_(1.0), AdamW and zero_grad are ONE fused pass (two launches) over the
+    flat parameter/gradient/moment buffers (tecmollm/optim.py -> tecm_adamw_clip_step), without a host sync;
+    the cosine-warm-restart learning rate is a closed-form host float.
 """
 from __future__ import annotations
 
@@ -48,27 +49,45 @@ def clip_flat_(flat: torch.Tensor, max_norm: float) -> torch.Tensor:
 
 
 class TrainStep:
+    """One optimizer step of train.py:57-112.  optimizer="native" (default): FlatAdamW + CosineWarmRestarts --
+    the mean over ranks, clip, AdamW and zero_grad are one fused pass over the flat buffers (HIP only, raises
+    for CPU parameters).  optimizer="torch": torch.optim.AdamW + torch's scheduler on the same flat gradient
+    views -- kept for the world_size-2 gloo plumbing tests, which run host logic on CPU stand-in modules."""
+
     def __init__(self, model: torch.nn.Module, lr: float = 1e-4, weight_decay: float = 1e-2, max_norm: float = 1.0,
-                 accumulation_steps: int = 1, world_size: int = 1, group=None, fused_huber: bool = True):
+                 accumulation_steps: int = 1, world_size: int = 1, group=None, fused_huber: bool = True,
+                 optimizer: str = "native"):
+        if optimizer not in ("native", "torch"):
+            raise ValueError("optimizer must be 'native' or 'torch'")
         self.model = model
         self.params: List[torch.nn.Parameter] = [p for p in model.parameters() if p.requires_grad]
-        self.flat_grad = flatten_grads(self.params)
         self.max_norm = max_norm
         self.accumulation_steps = accumulation_steps
         self.world_size = world_size
         self.group = group
         self.fused_huber = fused_huber
-        fused = self.params[0].is_cuda
-        self.optimizer = torch.optim.AdamW(self.params, lr=lr, weight_decay=weight_decay, fused=fused)
-        self.scheduler = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(self.optimizer, T_0=10, T_mult=2,
-                                                                             eta_min=1e-7)
+        self.native = optimizer == "native"
+        if self.native:
+            from .optim import CosineWarmRestarts, FlatAdamW
+            self.optimizer = FlatAdamW(self.params, lr=lr, weight_decay=weight_decay)
+            self.flat_grad = self.optimizer.flat_grad
+            self.scheduler = CosineWarmRestarts(lr, T_0=10, T_mult=2, eta_min=1e-7)
+        else:
+            self.flat_grad = flatten_grads(self.params)
+            self.optimizer = torch.optim.AdamW(self.params, lr=lr, weight_decay=weight_decay,
+                                               fused=self.params[0].is_cuda)
+            self.scheduler = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(self.optimizer, T_0=10, T_mult=2,
+                                                                                 eta_min=1e-7)
         self._micro = 0
 
     def _loss(self, out: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
-        if self.fused_huber and out.is_cuda:
+        if self.fused_huber:
             from .functions import HuberFn
             return HuberFn.apply(out, y, 1.0)
         return torch.nn.functional.huber_loss(out, y, delta=1.0)
+
+    def current_lr(self) -> float:
+        return self.scheduler.lr if self.native else self.optimizer.param_groups[0]["lr"]
 
     def step(self, x, time_features, edge_index, edge_weight, y) -> torch.Tensor:
         """One micro-batch; the optimizer fires every `accumulation_steps` calls.  Returns the (device) loss."""
@@ -77,9 +96,20 @@ class TrainStep:
         (loss / self.accumulation_steps).backward()
         self._micro += 1
         if self._micro % self.accumulation_steps == 0:
+            self.finish_accumulation()
+        return loss.detach()
+
+    def finish_accumulation(self) -> None:
+        """The boundary of an accumulation cycle (also train.py:117-126 for a trailing partial cycle):
+        all-reduce, clip, AdamW, zero_grad, scheduler."""
+        if self.native:
+            if self.world_size > 1:
+                dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            self.optimizer.step(lr=self.scheduler.lr, max_norm=self.max_norm, grad_scale=1.0 / self.world_size,
+                                zero_grad=True)
+        else:
             allreduce_mean_(self.flat_grad, self.world_size, self.group)
             clip_flat_(self.flat_grad, self.max_norm)
             self.optimizer.step()
             self.flat_grad.zero_()
-            self.scheduler.step()
-        return loss.detach()
+        self.scheduler.step()

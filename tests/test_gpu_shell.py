@@ -1,0 +1,271 @@
+"""GPU parity of the shell around the step through the C ABI:
+fused clip + AdamW vs torch's clip_grad_norm_/AdamW/CosineAnnealingWarmRestarts, device metrics vs the
+reference's metrics.py (golden vectors + numpy oracle), window batches vs the reference Dataset."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import shell_cpu as S
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("mae_avg", "rmse_avg", "r2_score_avg", "pearson_r_avg", "mae_by_horizon", "rmse_by_horizon", "r2_by_horizon",
+        "pearson_by_horizon")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda")
+
+
+def _model(cfg, seed, dev, gat="per_timestep"):
+    from tests.parity import build_model
+    from oracle import ref_cpu as R
+    return build_model(cfg, R.init_params(cfg, seed=seed), dev, gat)
+
+
+def _inputs(cfg, B, grid, seed, dev):
+    from oracle import ref_cpu as R
+    N = grid[0] * grid[1]
+    x, tf, y = R.synthetic_batch(B, cfg["temporal_seq_len"], N, cfg["spatial_in_channels_base"],
+                                 cfg["prediction_horizon"], seed=seed)
+    tfd = tf[:, :, 0, :].contiguous().to(dev).unsqueeze(-2).expand(B, cfg["temporal_seq_len"], N, 4)
+    return x.to(dev), tfd, R.grid_graph(*grid)[0].to(dev), y.to(dev)
+
+
+# ------------------------------------------------------------------------------------ optimizer
+@pytest.mark.parametrize("shapes,scale", [([(7, 5), (5,), (3, 4, 2), (1,)], 5.0),      # 65 values: scalar tail path
+                                          ([(257, 33), (33,), (1024,)], 0.01),          # below max_norm: no clipping
+                                          ([(768, 96), (2304, 32), (13, 16)], 3.0)])
+def test_fused_clip_adamw_matches_torch(dev, shapes, scale):
+    from tecmollm.optim import CosineWarmRestarts, FlatAdamW
+    g = torch.Generator().manual_seed(3)
+    params0 = [torch.randn(*s, generator=g) for s in shapes]
+    steps = 25                                             # crosses the first warm restart (T_0 = 10) and the second
+    grads = [[torch.randn(*s, generator=g) * scale / (1 + 0.1 * k) for s in shapes] for k in range(steps)]
+    want, norms, lrs = S.reference_optimizer_steps(params0, grads, lr=1e-3, weight_decay=1e-2, max_norm=1.0)
+
+    ps = [torch.nn.Parameter(p.clone().to(dev)) for p in params0]
+    opt = FlatAdamW(ps, lr=1e-3, weight_decay=1e-2)
+    sched = CosineWarmRestarts(1e-3)
+    for k in range(steps):
+        for p, gk in zip(ps, grads[k]):
+            p.grad.copy_(gk)                               # writes into the flat buffer through the view
+        assert abs(sched.lr - lrs[k]) <= 1e-12 + 1e-9 * lrs[k]
+        tn = opt.step(lr=sched.lr, max_norm=1.0)
+        assert abs(float(tn) - norms[k]) <= 2e-6 * norms[k]
+        assert float(opt.flat_grad.abs().sum()) == 0.0     # zero_grad fused
+        sched.step()
+    for p, w in zip(ps, want):
+        torch.testing.assert_close(p.detach().cpu(), w, rtol=2e-5, atol=2e-7)
+
+
+def test_fused_adamw_grad_scale_is_the_data_parallel_mean(dev):
+    """grad_scale = 1/world on the SUM-reduced buffer equals clipping/updating the mean gradient."""
+    from tecmollm.optim import FlatAdamW
+    g = torch.Generator().manual_seed(5)
+    p0 = torch.randn(1000, generator=g)
+    g1, g2 = torch.randn(1000, generator=g), torch.randn(1000, generator=g)
+    want, norms, _ = S.reference_optimizer_steps([p0], [[(g1 + g2) / 2]], lr=1e-4)
+    p = torch.nn.Parameter(p0.clone().to(dev))
+    opt = FlatAdamW([p])
+    p.grad.copy_(g1 + g2)
+    tn = opt.step(max_norm=1.0, grad_scale=0.5)
+    assert abs(float(tn) - norms[0]) <= 2e-6 * norms[0]
+    torch.testing.assert_close(p.detach().cpu(), want[0], rtol=1e-6, atol=1e-8)
+
+
+def test_flat_adamw_state_dict_round_trips_through_torch_adamw(dev):
+    from tecmollm.optim import FlatAdamW
+    g = torch.Generator().manual_seed(9)
+    shapes = [(6, 4), (4,)]
+    ps = [torch.nn.Parameter(torch.randn(*s, generator=g).to(dev)) for s in shapes]
+    opt = FlatAdamW(ps, lr=1e-3)
+    for _ in range(3):
+        for p in ps:
+            p.grad.copy_(torch.randn(*p.shape, generator=g))
+        opt.step(max_norm=0.0)
+    sd = opt.state_dict()
+    tps = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    topt = torch.optim.AdamW(tps, lr=1e-3, weight_decay=1e-2)
+    topt.load_state_dict(sd)                                # torch accepts the exported state
+    ps2 = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt2 = FlatAdamW(ps2, lr=1e-3)
+    opt2.load_state_dict(topt.state_dict())                 # and the flat optimizer accepts torch's
+    gk = [torch.randn(*s, generator=g) for s in shapes]
+    for p, p2, tp, gg in zip(ps, ps2, tps, gk):
+        p.grad.copy_(gg)
+        p2.grad.copy_(gg)
+        tp.grad = gg.to(dev)
+    opt.step(max_norm=0.0)
+    opt2.step(max_norm=0.0)
+    topt.step()
+    for p, p2, tp in zip(ps, ps2, tps):
+        assert torch.equal(p, p2)
+        torch.testing.assert_close(p.detach(), tp.detach(), rtol=2e-6, atol=1e-8)
+
+
+def test_optimizer_rejects_cpu_parameters_and_replaced_grads(dev):
+    from tecmollm import TecmError
+    from tecmollm.optim import FlatAdamW
+    with pytest.raises(TecmError):
+        FlatAdamW([torch.nn.Parameter(torch.zeros(4))])
+    p = torch.nn.Parameter(torch.zeros(8, device=dev))
+    opt = FlatAdamW([p])
+    p.grad = torch.ones(8, device=dev)
+    with pytest.raises(TecmError):
+        opt.step()
+
+
+def test_train_step_native_equals_torch_optimizer_path(dev):
+    """Whole step on the model: native fused optimizer vs torch AdamW on identical gradients."""
+    from oracle import ref_cpu as R
+    from tecmollm.train import TrainStep
+    cfg = R.default_config(L_in=48, L_out=12, num_nodes=12, llm_layers=1)
+    outs = []
+    for kind in ("native", "torch"):
+        model = _model(cfg, 2, dev).eval()                  # dropout off: both runs see identical gradients
+        x, tf, ei, y = _inputs(cfg, 2, (3, 4), 4, dev)
+        ts = TrainStep(model, lr=1e-3, optimizer=kind, accumulation_steps=2)
+        losses = [float(ts.step(x, tf, ei, None, y)) for _ in range(6)]
+        outs.append((losses, torch.cat([q.detach().flatten() for q in ts.params]).cpu()))
+    assert outs[0][0][0] == outs[1][0][0]
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=2e-4)
+    torch.testing.assert_close(outs[0][1], outs[1][1], rtol=1e-3, atol=2e-5)
+    assert outs[0][0][2] != outs[0][0][0]                   # parameters moved after the first boundary
+
+
+# ------------------------------------------------------------------------------------ metrics
+def _check(out, want, rtol=2e-5, atol=2e-6):
+    for k in KEYS:
+        np.testing.assert_allclose(np.asarray(out[k]), np.asarray(want[k]), rtol=rtol, atol=atol, err_msg=k)
+
+
+def test_device_metrics_match_reference_golden(dev, golden_dir):
+    from src.evaluation.metrics import HorizonMetrics
+    g = np.load(os.path.join(golden_dir, "shell_metrics_scaled.npz"))
+    hm = HorizonMetrics(g["y_true"].shape[1], (float(g["mean"]), float(g["scale"])), device=dev)
+    yt, yp = torch.from_numpy(g["y_true"]).to(dev), torch.from_numpy(g["y_pred"]).to(dev)
+    for a in range(0, yt.shape[0], 2):                      # streamed in batches of 2 like validate()
+        hm.update(yp[a:a + 2], yt[a:a + 2])
+    _check(hm.compute(), {k: g[f"out_{k}"] for k in KEYS})
+
+
+def test_device_metrics_fallback_and_degenerate_horizons(dev, golden_dir):
+    from src.evaluation.metrics import evaluate_horizons
+    g = np.load(os.path.join(golden_dir, "shell_metrics_unscaled.npz"))
+    out = evaluate_horizons(g["y_true"], g["y_pred"], None, device=dev)
+    _check(out, {k: g[f"out_{k}"] for k in KEYS})
+    assert out["pearson_by_horizon"][1] == 0.0 and out["pearson_by_horizon"][2] == 0.0 and out["r2_by_horizon"][3] == 1.0
+
+
+def test_device_metrics_read_the_permuted_model_output_view(dev):
+    from src.evaluation.metrics import HorizonMetrics
+    g = torch.Generator().manual_seed(1)
+    B, N, H = 3, 2911, 12
+    pred_bnl = torch.randn(B, N, H, generator=g).to(dev)
+    out_view = pred_bnl.permute(0, 2, 1).unsqueeze(-1)      # what TEC_MoLLM.forward returns
+    y = torch.randn(B, H, N, 1, generator=g).to(dev)
+    assert not out_view.is_contiguous()
+    hm = HorizonMetrics(H, (21.5, 9.25), device=dev)
+    hm.update(out_view, y)
+    want = S.evaluate_horizons(y.cpu().numpy(), out_view.cpu().numpy(), 21.5, 9.25)
+    _check(hm.compute(), want, rtol=1e-9, atol=1e-10)       # oracle and kernel both sum in float64
+
+
+# ------------------------------------------------------------------------------------ sliding windows
+def test_window_batches_match_reference_dataset_items(dev, golden_dir):
+    from src.data.dataset import SlidingWindowSamplerDataset
+    g = np.load(os.path.join(golden_dir, "shell_windows.npz"))
+    ds = SlidingWindowSamplerDataset.from_tensors(torch.from_numpy(g["X"]), torch.from_numpy(g["Y"]),
+                                                  torch.from_numpy(g["TF"]), int(g["L_in"]), int(g["L_out"]),
+                                                  int(g["stride"]), device=dev)
+    assert len(ds) == int(g["length"])
+    pick = [int(i) for i in g["pick"]]
+    x, tf, y = ds.batch(pick)
+    T, Hh, Ww, Cc = g["X"].shape
+    N = Hh * Ww
+    assert x.shape == (len(pick), int(g["L_in"]), N, Cc) and y.shape == (len(pick), int(g["L_out"]), N, 1)
+    assert tf.shape == (len(pick), int(g["L_in"]), N, 4) and tf.stride(2) == 0
+    assert np.array_equal(x.cpu().numpy(), g["x"].reshape(len(pick), -1, N, Cc))                     # bit-exact copies
+    assert np.array_equal(y.cpu().numpy(), np.transpose(g["y"], (0, 3, 1, 2)).reshape(len(pick), -1, N, 1))
+    assert np.array_equal(tf[:, :, 0, :].cpu().numpy(), g["tf"])
+    for j, i in enumerate(pick):                                                                     # per-item API
+        it = ds[i]
+        assert np.array_equal(it["x"].cpu().numpy(), g["x"][j]) and np.array_equal(it["y"].cpu().numpy(), g["y"][j])
+    with pytest.raises(IndexError):
+        ds[len(ds)]
+    with pytest.raises(IndexError):
+        ds.batch([0, len(ds)])
+    short = SlidingWindowSamplerDataset.from_tensors(torch.from_numpy(g["X"]), torch.from_numpy(g["Y"]),
+                                                     torch.from_numpy(g["TF"]), 38, 4, 1, device=dev)
+    assert len(short) == int(g["length_when_too_short"]) == 0
+
+
+def test_window_batch_full_grid_and_odd_row_width(dev):
+    """41x71 grid at C=10 (float4 path) and a row width that is not a multiple of 4 (scalar path) vs the oracle."""
+    from src.data.dataset import SlidingWindowSamplerDataset
+    rng = np.random.default_rng(0)
+    for (Hh, Ww, Cc, L_in, L_out) in [(41, 71, 10, 48, 12), (3, 3, 3, 5, 2)]:
+        T = L_in + L_out + 9
+        X = rng.standard_normal((T, Hh, Ww, Cc)).astype(np.float32)
+        Y = rng.standard_normal((T, Hh, Ww, L_out)).astype(np.float32)
+        TF = rng.integers(0, 12, (T, 4)).astype(np.float32)
+        ref = S.SlidingWindows(X, Y, TF, L_in, L_out, 2)
+        ds = SlidingWindowSamplerDataset.from_tensors(torch.from_numpy(X), torch.from_numpy(Y), torch.from_numpy(TF),
+                                                      L_in, L_out, 2, device=dev)
+        assert len(ds) == len(ref)
+        idx = [len(ref) - 1, 0, 2]
+        x, tf, y = ds.batch(idx)
+        wx, wtf, wy = ref.batch(idx)
+        assert np.array_equal(x.cpu().numpy(), wx) and np.array_equal(y.cpu().numpy(), wy)
+        assert np.array_equal(tf.cpu().numpy(), wtf)
+
+
+def test_window_batch_feeds_the_model(dev):
+    """dataset -> batch -> TEC_MoLLM forward/backward: the expanded time-feature view and the (B,L_out,N,1)
+    target are consumed as they come."""
+    from src.data.dataset import SlidingWindowSamplerDataset
+    from oracle import ref_cpu as R
+    from tecmollm.train import TrainStep
+    cfg = R.default_config(L_in=48, L_out=12, num_nodes=12, llm_layers=1)
+    rng = np.random.default_rng(2)
+    T = 80
+    X = torch.from_numpy(rng.standard_normal((T, 3, 4, cfg["spatial_in_channels_base"])).astype(np.float32))
+    Y = torch.from_numpy(rng.standard_normal((T, 3, 4, 12)).astype(np.float32))
+    TF = torch.from_numpy(np.stack([rng.integers(0, 12, T), rng.integers(0, 366, T), rng.integers(0, 13, T),
+                                    rng.integers(0, 4, T)], 1).astype(np.float32))
+    ds = SlidingWindowSamplerDataset.from_tensors(X, Y, TF, 48, 12, device=dev)
+    model = _model(cfg, 1, dev)
+    ei = R.grid_graph(3, 4)[0].to(dev)
+    ts = TrainStep(model)
+    x, tf, y = ds.batch([0, 5, 11])
+    l0 = float(ts.step(x, tf, ei, None, y))
+    assert np.isfinite(l0)
+
+
+# ------------------------------------------------------------------------------------ checkpoints
+def test_checkpoint_round_trip_with_wrapper_prefixes(dev, tmp_path):
+    from oracle import ref_cpu as R
+    from tecmollm import checkpoint as ck
+    from tecmollm.optim import FlatAdamW
+    cfg = R.default_config(L_in=48, L_out=12, num_nodes=12, llm_layers=1)
+    model = _model(cfg, 1, dev)
+    path = str(tmp_path / "best_model.pth")
+    ck.save_model(model, path)
+    saved = torch.load(path, map_location="cpu")
+    assert set(saved) == set(model.state_dict())
+    # a DDP + torch.compile style file, as test.py:178-187 expects to meet
+    torch.save({"module._orig_mod." + k: v + 1.0 if v.dtype.is_floating_point else v for k, v in saved.items()}, path)
+    model2 = _model(cfg, 3, dev)
+    opt = FlatAdamW([p for p in model2.parameters() if p.requires_grad])
+    before = opt.flat_param.data_ptr()
+    res = ck.load_model(model2, path, map_location="cpu")
+    assert not res.missing_keys and not res.unexpected_keys
+    for k, v in model2.state_dict().items():
+        if v.dtype.is_floating_point:
+            torch.testing.assert_close(v.cpu(), saved[k] + 1.0)
+    assert opt.flat_param.data_ptr() == before and opt.params[0].data_ptr() == before      # flat views survive a load

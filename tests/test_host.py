@@ -165,7 +165,7 @@ def _dp_worker(rank, world, port, out):
         from tecmollm.train import TrainStep
         torch.manual_seed(0)
         model = _Toy()
-        ts = TrainStep(model, world_size=world, fused_huber=False)
+        ts = TrainStep(model, world_size=world, fused_huber=False, optimizer="torch")
         g = torch.Generator().manual_seed(100)
         X = torch.randn(4, 5, 9, 6, generator=g)
         Y = torch.randn(4, 12, 9, 1, generator=g)
@@ -188,7 +188,7 @@ def test_data_parallel_step_two_ranks_equals_single_rank_on_global_batch():
     assert torch.allclose(out[0], out[1], rtol=0, atol=0)          # ranks stay bit-identical
     torch.manual_seed(0)
     model = _Toy()
-    ts = TrainStep(model, world_size=1, fused_huber=False)
+    ts = TrainStep(model, world_size=1, fused_huber=False, optimizer="torch")
     g = torch.Generator().manual_seed(100)
     X = torch.randn(4, 5, 9, 6, generator=g)
     Y = torch.randn(4, 12, 9, 1, generator=g)
@@ -202,7 +202,7 @@ def test_accumulation_fires_optimizer_on_boundary_only():
     from tecmollm.train import TrainStep
     torch.manual_seed(0)
     model = _Toy()
-    ts = TrainStep(model, accumulation_steps=3, fused_huber=False)
+    ts = TrainStep(model, accumulation_steps=3, fused_huber=False, optimizer="torch")
     before = model.a.weight.detach().clone()
     g = torch.Generator().manual_seed(1)
     X, Y = torch.randn(2, 5, 9, 6, generator=g), torch.randn(2, 12, 9, 1, generator=g)
@@ -211,3 +211,34 @@ def test_accumulation_fires_optimizer_on_boundary_only():
     assert torch.equal(model.a.weight, before) and float(ts.flat_grad.abs().sum()) > 0
     ts.step(X, None, None, None, Y)
     assert not torch.equal(model.a.weight, before) and float(ts.flat_grad.abs().sum()) == 0
+
+
+def test_cosine_warm_restarts_closed_form_equals_torch_scheduler():
+    """CosineAnnealingWarmRestarts(T_0=10, T_mult=2, eta_min=1e-7) stepped once per update (train.py:366, :108)."""
+    from tecmollm.optim import CosineWarmRestarts
+    for base, T0, Tm in [(1e-4, 10, 2), (3e-3, 4, 1), (1e-4, 7, 3)]:
+        opt = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=base)
+        ref = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(opt, T_0=T0, T_mult=Tm, eta_min=1e-7)
+        mine = CosineWarmRestarts(base, T0, Tm, 1e-7)
+        for _ in range(200):
+            assert abs(mine.lr - opt.param_groups[0]["lr"]) <= 1e-18 + 1e-12 * base
+            opt.step()
+            ref.step()
+            mine.step()
+        st = mine.state_dict()
+        again = CosineWarmRestarts(base, T0, Tm, 1e-7)
+        again.load_state_dict(st)
+        assert again.lr == mine.lr and again.step() == mine.step()
+
+
+def test_checkpoint_prefix_stripping_follows_test_py():
+    from tecmollm.checkpoint import strip_wrapper_prefixes
+    sd = {"module._orig_mod.a.weight": 1, "module.b.bias": 2, "_orig_mod.c": 3, "d.module.e": 4}
+    assert strip_wrapper_prefixes(sd) == {"a.weight": 1, "b.bias": 2, "c": 3, "d.module.e": 4}
+
+
+def test_native_train_step_refuses_cpu_parameters():
+    from tecmollm import TecmError
+    from tecmollm.train import TrainStep
+    with pytest.raises(TecmError):
+        TrainStep(_Toy())                      # optimizer="native" is the default and is HIP-only

@@ -111,9 +111,35 @@ def cpu_baseline(cfg, args):
     torch.nn.utils.clip_grad_norm_(train, 1.0)
     opt.step()
     dt = time.perf_counter() - t0
-    return {"value": B / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+    base = {"value": B / dt, "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": f"1 full train step (fwd+Huber+bwd+clip+AdamW) of the fp32 PyTorch-CPU oracle at B={B}, "
                       f"L_in={cfg['temporal_seq_len']}, N=2911, gat={args.gat}, eval-mode dropout; {dt:.1f} s"}
+    return base, (params, x, tf, ei, out.detach())
+
+
+def rmse_vs_ref(cfg, args, dev, ref):
+    """BASELINE's "test RMSE vs ref": the HIP model (eval mode, same parameters, same batch) against the
+    predictions the CPU oracle produced inside its timed step; RMSE/MAE/R^2/Pearson per metrics.py:53-78
+    from the device metrics kernel, plus the max relative error of the 1e-3 parity bar."""
+    from src.evaluation.metrics import HorizonMetrics
+    from src.model.tec_mollm import TEC_MoLLM
+    params, x, tf, ei, out_ref = ref
+    mc = dict(cfg, gat_graphs=args.gat, include_wte=False, load_pretrained_gpt2=False, precision=args.precision)
+    model = TEC_MoLLM(mc)
+    model.load_state_dict(params, strict=True)
+    model = model.to(dev).eval()
+    B = x.shape[0]
+    tfd = tf[:, :, 0, :].contiguous().to(dev).unsqueeze(-2).expand(B, x.shape[1], x.shape[2], 4)
+    with torch.no_grad():
+        out = model(x.to(dev), tfd, ei.to(dev))
+    want = out_ref.to(dev)
+    hm = HorizonMetrics(out.shape[1], None, device=dev)
+    hm.update(out, want)
+    m = hm.compute()
+    rel = float((out - want).abs().max() / want.abs().max())
+    return {"rmse_vs_ref": m["rmse_avg"], "mae_vs_ref": m["mae_avg"], "r2_vs_ref": m["r2_score_avg"],
+            "pearson_vs_ref": m["pearson_r_avg"], "max_rel_err": rel, "ref_rms": float(want.pow(2).mean().sqrt()),
+            "sample": f"eval forward at B={B} on the cpu_baseline batch, scaled units, {out.shape[1]} horizons"}
 
 
 def main():
@@ -211,7 +237,8 @@ def main():
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg, args)
+            line["cpu_baseline"], ref = cpu_baseline(cfg, args)
+            line["parity"] = rmse_vs_ref(cfg, args, dev, ref)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

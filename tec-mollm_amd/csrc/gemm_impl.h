@@ -540,26 +540,36 @@ __global__ __launch_bounds__(threads_for(BN), (AVEC == 4 && BVEC == 4) ? (thread
       constexpr int q = decltype(qc)::value;
       if constexpr (q < 3) read_frags(Ac, Bc, std::integral_constant<int, q + 1>{}, fa[(q + 1) & 1], fb[(q + 1) & 1]);
       do_mfma(fa[q & 1], fb[q & 1]);
-      constexpr int AB = (ANV * q) / 4, AE = (ANV * (q + 1)) / 4;
-      constexpr int BB = (BNV * q) / 4, BE = (BNV * (q + 1)) / 4;
-      if (FULL || k0 + BK < kend) {
-        sa.template store_part<AB, AE>(An, adc);
-        sb.template store_part<BB, BE>(An + A_FLOATS, bdc);
-      }
-      if (FULL || k0 + 2 * BK < kend) {
-        sa.template load_part<AB, AE>(g.A, g.a_win, g.lda, k0 + 2 * BK, kend, adc);
-        sb.template load_part<BB, BE>(g.B, g.b_win, g.ldb, k0 + 2 * BK, kend, bdc);
+      // Staging lives in the LAST q-step: park tile t+1 (loaded one whole tile ago) in the idle LDS buffer, then
+      // refill the same registers with tile t+2 straight away -- every global load gets a full K-tile of MFMAs
+      // (32-64 per wave, x the waves sharing the SIMD) to land before its ds_write.  Spreading the staging over
+      // the q-steps halves that distance for the vectors staged early, which is what stalls under L2-miss latency.
+      if constexpr (q == 3) {
+        if (FULL || k0 + BK < kend) {
+          sa.store(An, adc);
+          sb.store(An + A_FLOATS, bdc);
+        }
+        if (FULL || k0 + 2 * BK < kend) {
+          sa.load(g.A, g.a_win, g.lda, k0 + 2 * BK, kend, adc);
+          sb.load(g.B, g.b_win, g.ldb, k0 + 2 * BK, kend, bdc);
+        }
       }
       if constexpr (FULL && !WIN && !DROP && AVEC == 4 && BVEC == 4) {
-        // 16 (or MT*NT*4) MFMAs; between them: next-step fragment reads first, then LDS writes, then global loads
+        // pin "1 MFMA, then memory instructions" so every LDS / global instruction issues in the shadow of a
+        // 64-cycle MFMA: q < 3 -> the next q-step's fragment reads; q == 3 -> first the LDS writes, then the loads
         constexpr int NMFMA = MT * NT * 4;
-        constexpr int NREAD = q < 3 ? 12 : 0;            // upper bound on ds_read instructions of one read_frags
+        constexpr int NREAD = MT * (ALAY == TECM_A_MK ? 1 : 4) + NT * (BLAY == TECM_B_NK ? 1 : 4);
+        constexpr int HALF = NMFMA / 2;
+        constexpr int SPS = (ANV + BNV + HALF - 1) / HALF;
 #pragma unroll
         for (int m = 0; m < NMFMA; ++m) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // 1 MFMA
-          if (m < NREAD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // 1 DS read
-          else if (m < NREAD + 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // 1 DS write
-          else if (m < NREAD + 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
+          if constexpr (q < 3) {
+            if (m < NREAD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
+          } else {
+            if (m < HALF) __builtin_amdgcn_sched_group_barrier(0x200, SPS, 0);     // DS writes
+            else __builtin_amdgcn_sched_group_barrier(0x020, SPS, 0);              // VMEM reads
+          }
         }
       }
     });

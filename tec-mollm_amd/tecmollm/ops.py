@@ -96,7 +96,12 @@ def gemm(M: int, N: int, K: int, A: torch.Tensor, lda: int, B: torch.Tensor, ldb
     e0.record()
     check(fn(C.byref(g), stream_ptr()), "tecm_gemm_bf16" if use16 else "tecm_gemm_f32")
     e1.record()
-    _timing.append((_kernel_name(g, use16), 2.0 * M * N * K, e0, e1))
+    name = _kernel_name(g, use16)
+    if _timing_detail:
+        name += (f" M={M} N={N} K={K} win={g.a_win.enabled}{g.b_win.enabled}{g.c_win.enabled}"
+                 f" drop={int(g.a_drop.p > 0)}{int(g.b_drop.p > 0)}{int(g.out_drop.p > 0)} split={g.split_k}"
+                 f" act={g.act} acc={g.accumulate}")
+    _timing.append((name, 2.0 * M * N * K, e0, e1))
 
 
 BF16_MIN_N = 64
@@ -121,6 +126,7 @@ def _bf16_ok(g: TecmGemm) -> bool:
 
 # ------------------------------------------------------------------ per-launch timing (bench.py roofline)
 _timing = None
+_timing_detail = False
 
 
 def _vec(p: int, ld: int, w: TecmWin, inner_is_k: bool, K: int) -> int:
@@ -153,10 +159,12 @@ def _kernel_name(g: TecmGemm, use16: bool = False) -> str:
     return f"gemm_kernel<{g.a_layout},{g.b_layout},{pair[0]},{pair[1]},{bn}>"
 
 
-def enable_gemm_timing() -> list:
-    """Bracket every GEMM launch with events on the launch stream (torch's current stream)."""
-    global _timing
+def enable_gemm_timing(detail: bool = False) -> list:
+    """Bracket every GEMM launch with events on the launch stream (torch's current stream).
+    detail=True keys the records by shape / view / epilogue flags as well (tools/gemm_breakdown.py)."""
+    global _timing, _timing_detail
     _timing = []
+    _timing_detail = detail
     return _timing
 
 

@@ -27,6 +27,12 @@
 #define TECM_BIG_THREADS 512
 #endif
 #include <utility>
+#ifndef TECM_ABLATE
+#define TECM_ABLATE 0      // experiments only: 1 no staging, 2 no LDS reads either, 3 loads only, 4 stores only
+#endif
+#ifndef TECM_STAGE_Q
+#define TECM_STAGE_Q 0
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -173,18 +179,20 @@ struct Stager {
       if constexpr (!ROWK) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-          const int64_t row = row0 + r0 + i * RSTEP;
+          int64_t row = row0 + r0 + i * RSTEP;
           if (row < rows_total) rowok |= 1u << i;
+          else row = rows_total - 1;          // clamped: always a valid address, the tile row it feeds is never stored
           ptr[i] = P + row * ld + kbeg + cv;
           if constexpr (DROP) didx[i] = row * dc.ld + kbeg + cv;
         }
       } else {
         inner_ok = (fixed0 + cv) < fixed_lim;
+        const int64_t inner = inner_ok ? fixed0 + cv : 0;      // clamped likewise (columns beyond the limit)
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
           const int64_t row = (int64_t)kbeg + r0 + i * RSTEP;
-          ptr[i] = P + row * ld + fixed0 + cv;
-          if constexpr (DROP) didx[i] = row * dc.ld + fixed0 + cv;
+          ptr[i] = P + row * ld + inner;
+          if constexpr (DROP) didx[i] = row * dc.ld + inner;
         }
       }
     } else if constexpr (WIN) {
@@ -266,6 +274,41 @@ struct Stager {
           okbits = (okbits & ~(1u << i)) | ((ok ? 1u : 0u) << i);
           if constexpr (DROP) dsave[i] = row * dc.ld + c;
         }
+      }
+    }
+  }
+
+  // Steady state of the plain view (every k of the tile in range, rows/columns pre-clamped in init): no masks,
+  // no selects -- one global load and one 64-bit pointer bump per vector.  Out-of-range rows/columns carry
+  // clamped (finite or not, irrelevant) data into accumulator rows/columns that the epilogue never stores.
+  __device__ __forceinline__ void load_steady(int64_t ld, const DropCtx& dc) {
+    okbits = ~0u;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      gload<VEC>(ptr[i], ptr[i], true, regs[i]);
+      if constexpr (!ROWK) {
+        if constexpr (DROP) { dsave[i] = didx[i]; didx[i] += BK; }
+        ptr[i] += BK;
+      } else {
+        if constexpr (DROP) { dsave[i] = didx[i]; didx[i] += (int64_t)BK * dc.ld; }
+        ptr[i] += (int64_t)BK * ld;
+      }
+    }
+    if constexpr (!ROWK) kk += BK;
+  }
+  __device__ __forceinline__ void store_steady(float* lds, const DropCtx& dc) {
+    const int cv = (threadIdx.x % VPR) * VEC;
+    const int r0 = threadIdx.x / VPR;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if constexpr (DROP) {
+        float v[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] = regs[i][e];
+        apply_drop<VEC>(dc, dsave[i], v);
+        lds_store<VEC>(lds + (r0 + i * RSTEP) * LD + cv, v);
+      } else {
+        lds_store<VEC>(lds + (r0 + i * RSTEP) * LD + cv, regs[i]);
       }
     }
   }
@@ -414,6 +457,73 @@ __device__ __forceinline__ void epi_vec4(const TecmGemm& g, const DropCtx& odc, 
   *reinterpret_cast<float4*>(g.C + off) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
+// ---------------------------------------------------------------------------------------- block epilogue
+// C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
+// Each wave parks its WTM x WTN accumulator block in LDS (the operand buffers are dead by now) and walks it
+// row by row in ONE rolled loop (small code: the epilogue is executed once per block and must not thrash the
+// instruction cache): row state is resolved once per row, a lane keeps its columns, and the global stores are
+// whole contiguous row segments (float4 per lane when the host found every pointer / leading dimension
+// 16-byte friendly: g._p0 == 1).
+template <int MT, int NT, int WTM, int WTN, int STG_LD>
+__device__ __forceinline__ void block_epilogue(const TecmGemm& g, f32x16 (&acc)[MT][NT], float* smem, int wave, int lane,
+                                               int wm, int wn, int64_t m0, int64_t n0) {
+  const int r = lane & 31, h = lane >> 5;
+  const DropCtx odc = make_drop(g.out_drop);
+  const bool split = gridDim.z > 1;
+  float* stg = smem + wave * (WTM * STG_LD);
+  static_for<MT>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    static_for<16>([&](auto ec) {
+      constexpr int e = decltype(ec)::value;
+      static_for<NT>([&](auto jc) {
+        constexpr int jn = decltype(jc)::value;
+        stg[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * STG_LD + jn * 32 + r] = acc[i][jn][e];
+      });
+    });
+  });
+  __syncthreads();
+  if (g._p0 != 0) {
+    constexpr int LPR = WTN / 4;                       // lanes per row
+    constexpr int RPI = 64 / LPR;                      // rows per iteration
+    const int lcol = (lane % LPR) * 4, lrow = lane / LPR;
+    const EpiCol ecol = epi_col(g, n0 + wn * WTN + lcol);
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.bias && ecol.ok) bias4 = *reinterpret_cast<const float4*>(g.bias + ecol.n);
+#pragma unroll 1
+    for (int it = 0; it < WTM / RPI; ++it) {
+      const int rl = it * RPI + lrow;
+      const int64_t m = m0 + wm * WTM + rl;
+      if (m < g.M && ecol.ok) {
+        const float4 v = *reinterpret_cast<const float4*>(&stg[rl * STG_LD + lcol]);
+        if (split) {
+          *reinterpret_cast<float4*>(g.workspace + ((int64_t)blockIdx.z * g.M + m) * g.N + ecol.n) = v;
+        } else {
+          const EpiRow er = epi_row(g, odc, m);
+          epi_vec4(g, odc, er, ecol, bias4, v);
+        }
+      }
+    }
+  } else {
+    constexpr int RPI = 64 / WTN;                      // 1 (WTN = 64) or 2 (WTN = 32)
+    const int lcol = lane % WTN, lrow = lane / WTN;
+    const EpiCol ecol = epi_col(g, n0 + wn * WTN + lcol);
+#pragma unroll 1
+    for (int it = 0; it < WTM / RPI; ++it) {
+      const int rl = it * RPI + lrow;
+      const int64_t m = m0 + wm * WTM + rl;
+      if (m < g.M && ecol.ok) {
+        const float v = stg[rl * STG_LD + lcol];
+        if (split) {
+          g.workspace[((int64_t)blockIdx.z * g.M + m) * g.N + ecol.n] = v;
+        } else {
+          const EpiRow er = epi_row(g, odc, m);
+          epi_elem(g, odc, er, ecol, v);
+        }
+      }
+    }
+  }
+}
+
 template <int ALAY, int BLAY, int AVEC, int BVEC, int BN, bool WIN, bool DROP>
 __global__ __launch_bounds__(threads_for(BN), (AVEC == 4 && BVEC == 4) ? (threads_for(BN) == 512 ? 4 : 2) : 1) void gemm_kernel(const TecmGemm g,
                                                                                            int tiles_m, int tiles_n,
@@ -538,18 +648,31 @@ __global__ __launch_bounds__(threads_for(BN), (AVEC == 4 && BVEC == 4) ? (thread
     read_frags(Ac, Bc, std::integral_constant<int, 0>{}, fa[0], fb[0]);
     static_for<4>([&](auto qc) {
       constexpr int q = decltype(qc)::value;
-      if constexpr (q < 3) read_frags(Ac, Bc, std::integral_constant<int, q + 1>{}, fa[(q + 1) & 1], fb[(q + 1) & 1]);
+      if constexpr (q < 3 && !(TECM_ABLATE >= 2 && FULL)) read_frags(Ac, Bc, std::integral_constant<int, q + 1>{}, fa[(q + 1) & 1], fb[(q + 1) & 1]);
       do_mfma(fa[q & 1], fb[q & 1]);
       // Staging lives in the LAST q-step: park tile t+1 (loaded one whole tile ago) in the idle LDS buffer, then
       // refill the same registers with tile t+2 straight away -- every global load gets a full K-tile of MFMAs
       // (32-64 per wave, x the waves sharing the SIMD) to land before its ds_write.  Spreading the staging over
       // the q-steps halves that distance for the vectors staged early, which is what stalls under L2-miss latency.
-      if constexpr (q == 3) {
+      if constexpr (q == TECM_STAGE_Q && !((TECM_ABLATE == 1 || TECM_ABLATE == 2) && FULL)) {
         if (FULL || k0 + BK < kend) {
-          sa.store(An, adc);
-          sb.store(An + A_FLOATS, bdc);
+          if constexpr (TECM_ABLATE == 3 && FULL) {
+#pragma unroll
+            for (int i = 0; i < ANV; ++i) asm volatile("" ::"v"(sa.regs[i][0]), "v"(sa.regs[i][1]), "v"(sa.regs[i][2]), "v"(sa.regs[i][3]));
+#pragma unroll
+            for (int i = 0; i < BNV; ++i) asm volatile("" ::"v"(sb.regs[i][0]), "v"(sb.regs[i][1]), "v"(sb.regs[i][2]), "v"(sb.regs[i][3]));
+          } else if constexpr (FULL && !WIN) {
+            sa.store_steady(An, adc);
+            sb.store_steady(An + A_FLOATS, bdc);
+          } else {
+            sa.store(An, adc);
+            sb.store(An + A_FLOATS, bdc);
+          }
         }
-        if (FULL || k0 + 2 * BK < kend) {
+        if constexpr (FULL && !WIN && TECM_ABLATE != 4) {
+          sa.load_steady(g.lda, adc);
+          sb.load_steady(g.ldb, bdc);
+        } else if ((FULL && TECM_ABLATE != 4) || (!FULL && k0 + 2 * BK < kend)) {
           sa.load(g.A, g.a_win, g.lda, k0 + 2 * BK, kend, adc);
           sb.load(g.B, g.b_win, g.ldb, k0 + 2 * BK, kend, bdc);
         }
@@ -566,7 +689,8 @@ __global__ __launch_bounds__(threads_for(BN), (AVEC == 4 && BVEC == 4) ? (thread
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // 1 MFMA
           if constexpr (q < 3) {
             if (m < NREAD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
-          } else {
+          }
+          if constexpr (q == TECM_STAGE_Q) {
             if (m < HALF) __builtin_amdgcn_sched_group_barrier(0x200, SPS, 0);     // DS writes
             else __builtin_amdgcn_sched_group_barrier(0x020, SPS, 0);              // VMEM reads
           }
@@ -577,79 +701,20 @@ __global__ __launch_bounds__(threads_for(BN), (AVEC == 4 && BVEC == 4) ? (thread
 
   int cur = 0;
   int32_t k0 = kbeg;
-  for (; k0 + 2 * BK < kend; k0 += BK) {                 // steady state
+  for (; k0 + 3 * BK <= kend; k0 += BK) {                // steady state: tiles t+1 and t+2 lie entirely inside [kbeg, kend)
     tile_body(smem + cur * TILE_FLOATS, smem + cur * TILE_FLOATS + A_FLOATS, smem + (cur ^ 1) * TILE_FLOATS, k0,
               std::true_type{});
     __syncthreads();
     cur ^= 1;
   }
-  for (; k0 < kend; k0 += BK) {                          // last two tiles
+  for (; k0 < kend; k0 += BK) {                          // last (up to three) tiles, masked loads
     tile_body(smem + cur * TILE_FLOATS, smem + cur * TILE_FLOATS + A_FLOATS, smem + (cur ^ 1) * TILE_FLOATS, k0,
               std::false_type{});
     __syncthreads();
     cur ^= 1;
   }
 
-  // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
-  // Each wave parks its WTM x WTN accumulator block in LDS (the operand buffers are dead by now) and walks it
-  // row by row in ONE rolled loop (small code: the epilogue is executed once per block and must not thrash the
-  // instruction cache): row state is resolved once per row, a lane keeps its columns, and the global stores are
-  // whole contiguous row segments (float4 per lane when the host found every pointer / leading dimension
-  // 16-byte friendly: g._p0 == 1).
-  const DropCtx odc = make_drop(g.out_drop);
-  const bool split = gridDim.z > 1;
-  float* stg = smem + wave * (WTM * STG_LD);
-  static_for<MT>([&](auto ic) {
-    constexpr int i = decltype(ic)::value;
-    static_for<16>([&](auto ec) {
-      constexpr int e = decltype(ec)::value;
-      static_for<NT>([&](auto jc) {
-        constexpr int jn = decltype(jc)::value;
-        stg[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * STG_LD + jn * 32 + r] = acc[i][jn][e];
-      });
-    });
-  });
-  __syncthreads();
-  if (g._p0 != 0) {
-    constexpr int LPR = WTN / 4;                       // lanes per row
-    constexpr int RPI = 64 / LPR;                      // rows per iteration
-    const int lcol = (lane % LPR) * 4, lrow = lane / LPR;
-    const EpiCol ecol = epi_col(g, n0 + wn * WTN + lcol);
-    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (g.bias && ecol.ok) bias4 = *reinterpret_cast<const float4*>(g.bias + ecol.n);
-#pragma unroll 1
-    for (int it = 0; it < WTM / RPI; ++it) {
-      const int rl = it * RPI + lrow;
-      const int64_t m = m0 + wm * WTM + rl;
-      if (m < g.M && ecol.ok) {
-        const float4 v = *reinterpret_cast<const float4*>(&stg[rl * STG_LD + lcol]);
-        if (split) {
-          *reinterpret_cast<float4*>(g.workspace + ((int64_t)blockIdx.z * g.M + m) * g.N + ecol.n) = v;
-        } else {
-          const EpiRow er = epi_row(g, odc, m);
-          epi_vec4(g, odc, er, ecol, bias4, v);
-        }
-      }
-    }
-  } else {
-    constexpr int RPI = 64 / WTN;                      // 1 (WTN = 64) or 2 (WTN = 32)
-    const int lcol = lane % WTN, lrow = lane / WTN;
-    const EpiCol ecol = epi_col(g, n0 + wn * WTN + lcol);
-#pragma unroll 1
-    for (int it = 0; it < WTM / RPI; ++it) {
-      const int rl = it * RPI + lrow;
-      const int64_t m = m0 + wm * WTM + rl;
-      if (m < g.M && ecol.ok) {
-        const float v = stg[rl * STG_LD + lcol];
-        if (split) {
-          g.workspace[((int64_t)blockIdx.z * g.M + m) * g.N + ecol.n] = v;
-        } else {
-          const EpiRow er = epi_row(g, odc, m);
-          epi_elem(g, odc, er, ecol, v);
-        }
-      }
-    }
-  }
+  block_epilogue<MT, NT, WTM, WTN, STG_LD>(g, acc, smem, wave, lane, wm, wn, m0, n0);
 }
 
 template <int ALAY, int BLAY, int AVEC, int BVEC, int BN, bool WIN, bool DROP>

@@ -312,6 +312,294 @@ __global__ __launch_bounds__(256) void gn_gelu_bwd_kernel(const float* __restric
     partials[(int64_t)blockIdx.x * 3 * CT + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
+
+// ------------------------------------------------------------------------------ GroupNorm(1) + GELU, register-resident
+// Fast path for sequences that fit in registers: WPS waves (LPS = 64*WPS lanes) own one sequence, a lane holds
+// NP <= NPMAX float4 "pairs" (t, channel quad) of it, so y (and dact) are read from HBM exactly once with
+// 16-byte loads and every statistic is a register pass.  Pair j = l2 + LPS*i of lane l2 (i = 0..NP-1) is row
+// t = j / QPR, quad = j % QPR (QPR = CT/4 quads per row).  3*LPS is a multiple of QPR for CT in {192, 384, 768},
+// so a lane only ever meets three different channel quads (slot = i % 3): three gamma/beta quads and three
+// parameter-gradient accumulators per lane.  Requires L*QPR % LPS == 0 and L*QPR/LPS <= NPMAX.
+//   <WPS 4, NPMAX 9>: the default shapes (L 48 x 192 ch, L 24 x 384 ch): 9 pairs, ~150 VGPRs in the backward
+//   <WPS 8, NPMAX 9>: twice the sequence length (L_in = 96), one 512-thread block per sequence
+//   <WPS 2, NPMAX 18>: forward only, short sequences whose quad count is not a multiple of 256
+
+template <int CPB, int WPS>
+struct GnGeom {
+  static constexpr int CT = 192 * CPB;
+  static constexpr int QPR = CT / 4;        // quads per row
+  static constexpr int QPB = QPR / 3;       // quads per branch
+  static constexpr int LPS = 64 * WPS;      // lanes per sequence
+  static constexpr int NTHR = WPS > 4 ? 64 * WPS : 256;   // threads per block
+  static constexpr int SPB = NTHR / LPS;    // sequences per block
+  static constexpr int DT = LPS / QPR, DQ = LPS % QPR;
+  static_assert((3 * LPS) % QPR == 0, "slot period");
+};
+
+__device__ __forceinline__ float sel3(int k, float a, float b, float c) { return k == 0 ? a : (k == 1 ? b : c); }
+__device__ __forceinline__ float sum4(const float4& v) { return (v.x + v.y) + (v.z + v.w); }
+
+// sums over the WPS waves of a sequence: xch[wave][3], waves of one sequence are consecutive
+template <int WPS>
+__device__ __forceinline__ void seq_reduce3(float (&v)[3], float (*xch)[3], int wave, int lane) {
+#pragma unroll
+  for (int b = 0; b < 3; ++b) v[b] = wave_sum(v[b]);
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int b = 0; b < 3; ++b) xch[wave][b] = v[b];
+  }
+  __syncthreads();
+  const int w0 = wave / WPS * WPS;
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    float t = xch[w0][b];
+#pragma unroll
+    for (int w = 1; w < WPS; ++w) t += xch[w0 + w][b];
+    v[b] = t;
+  }
+}
+
+template <int CPB, int WPS, int GN_NPMAX>
+__global__ __launch_bounds__((GnGeom<CPB, WPS>::NTHR)) void gn_gelu_fwd_reg(const float* __restrict__ y, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* __restrict__ act,
+                                                       float* __restrict__ stats, int B, int L, int N, float eps, int NP) {
+  using G = GnGeom<CPB, WPS>;
+  __shared__ float xch[G::NTHR / 64][3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sp = wave / WPS, half = wave % WPS, l2 = half * 64 + lane;
+  int64_t sidx = (int64_t)blockIdx.x * G::SPB + sp;
+  const bool live = sidx < (int64_t)B * N;
+  if (!live) sidx = (int64_t)B * N - 1;                  // keep the wave in the barriers; it stores nothing
+  const int b = (int)(sidx / N), n = (int)(sidx - (int64_t)b * N);
+  const int64_t tstride = (int64_t)N * G::CT;
+  const int64_t base = ((int64_t)b * L * N + n) * G::CT;
+  const float inv_cnt = 1.0f / (float)(L * CPB * 64);
+
+  // the lane's three channel quads
+  int qs[3], brs[3];
+  {
+    int q = l2 % G::QPR;
+#pragma unroll
+    for (int s_ = 0; s_ < 3; ++s_) {
+      qs[s_] = q;
+      brs[s_] = q / G::QPB;
+      q += G::DQ;
+      if (q >= G::QPR) q -= G::QPR;
+    }
+  }
+  float4 v[GN_NPMAX];
+  int32_t off[GN_NPMAX];                                 // relative to the sequence base (host checks L*N*CT < 2^31)
+  const float* yb = y + base;
+  float* ab = act + base;
+  {
+    int t = l2 / G::QPR, q = l2 % G::QPR;
+#pragma unroll
+    for (int i = 0; i < GN_NPMAX; ++i) {
+      off[i] = t * (int32_t)tstride + q * 4;
+      if (i < NP) v[i] = *reinterpret_cast<const float4*>(yb + off[i]);
+      t += G::DT;
+      q += G::DQ;
+      if (q >= G::QPR) { q -= G::QPR; ++t; }
+    }
+  }
+  float4 gm[3], bt[3];
+#pragma unroll
+  for (int s_ = 0; s_ < 3; ++s_) {
+    gm[s_] = *reinterpret_cast<const float4*>(gamma + qs[s_] * 4);
+    bt[s_] = *reinterpret_cast<const float4*>(beta + qs[s_] * 4);
+  }
+  // mean
+  float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < GN_NPMAX; ++i)
+    if (i < NP) acc[i % 3] += sum4(v[i]);
+  float mean[3];
+#pragma unroll
+  for (int bb = 0; bb < 3; ++bb)
+    mean[bb] = (brs[0] == bb ? acc[0] : 0.f) + (brs[1] == bb ? acc[1] : 0.f) + (brs[2] == bb ? acc[2] : 0.f);
+  seq_reduce3<WPS>(mean, xch, wave, lane);
+#pragma unroll
+  for (int bb = 0; bb < 3; ++bb) mean[bb] *= inv_cnt;
+  float ms[3];
+#pragma unroll
+  for (int s_ = 0; s_ < 3; ++s_) ms[s_] = sel3(brs[s_], mean[0], mean[1], mean[2]);
+  // variance (two-pass form, like nn.GroupNorm)
+  acc[0] = acc[1] = acc[2] = 0.f;
+#pragma unroll
+  for (int i = 0; i < GN_NPMAX; ++i)
+    if (i < NP) {
+      const float m = ms[i % 3];
+      const float dx = v[i].x - m, dy_ = v[i].y - m, dz = v[i].z - m, dw = v[i].w - m;
+      acc[i % 3] += (dx * dx + dy_ * dy_) + (dz * dz + dw * dw);
+    }
+  float rstd[3];
+#pragma unroll
+  for (int bb = 0; bb < 3; ++bb)
+    rstd[bb] = (brs[0] == bb ? acc[0] : 0.f) + (brs[1] == bb ? acc[1] : 0.f) + (brs[2] == bb ? acc[2] : 0.f);
+  seq_reduce3<WPS>(rstd, xch, wave, lane);
+#pragma unroll
+  for (int bb = 0; bb < 3; ++bb) rstd[bb] = 1.0f / sqrtf(rstd[bb] * inv_cnt + eps);
+  float rs[3];
+#pragma unroll
+  for (int s_ = 0; s_ < 3; ++s_) rs[s_] = sel3(brs[s_], rstd[0], rstd[1], rstd[2]);
+  if (live) {
+#pragma unroll
+    for (int i = 0; i < GN_NPMAX; ++i)
+      if (i < NP) {
+        const int s_ = i % 3;
+        float4 o;
+        o.x = gelu_erf_fast((v[i].x - ms[s_]) * rs[s_] * gm[s_].x + bt[s_].x);
+        o.y = gelu_erf_fast((v[i].y - ms[s_]) * rs[s_] * gm[s_].y + bt[s_].y);
+        o.z = gelu_erf_fast((v[i].z - ms[s_]) * rs[s_] * gm[s_].z + bt[s_].z);
+        o.w = gelu_erf_fast((v[i].w - ms[s_]) * rs[s_] * gm[s_].w + bt[s_].w);
+        *reinterpret_cast<float4*>(ab + off[i]) = o;
+      }
+    if (half == 0 && lane < 3) {
+      stats[(sidx * 3 + lane) * 2] = sel3(lane, mean[0], mean[1], mean[2]);
+      stats[(sidx * 3 + lane) * 2 + 1] = sel3(lane, rstd[0], rstd[1], rstd[2]);
+    }
+  }
+}
+
+template <int CPB, int WPS, int GN_NPMAX>
+__global__ __launch_bounds__((GnGeom<CPB, WPS>::NTHR)) void gn_gelu_bwd_reg(const float* __restrict__ dact, int dstride, int L2,
+                                                       const float* __restrict__ y, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ stats,
+                                                       float* __restrict__ dy, float* __restrict__ partials, int B,
+                                                       int L, int N, int NP) {
+  using G = GnGeom<CPB, WPS>;
+  __shared__ float xch[G::NTHR / 64][3];
+  __shared__ float red[3 * G::CT];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sp = wave / WPS, half = wave % WPS, l2 = half * 64 + lane;
+  const int64_t tstride = (int64_t)N * G::CT;
+  const float inv_cnt = 1.0f / (float)(L * CPB * 64);
+  for (int c = threadIdx.x; c < 3 * G::CT; c += G::NTHR) red[c] = 0.f;
+
+  int qs[3], brs[3];
+  {
+    int q = l2 % G::QPR;
+#pragma unroll
+    for (int s_ = 0; s_ < 3; ++s_) {
+      qs[s_] = q;
+      brs[s_] = q / G::QPB;
+      q += G::DQ;
+      if (q >= G::QPR) q -= G::QPR;
+    }
+  }
+  float4 gm[3], bt[3], dgm[3], dbt[3], dys[3];
+#pragma unroll
+  for (int s_ = 0; s_ < 3; ++s_) {
+    gm[s_] = *reinterpret_cast<const float4*>(gamma + qs[s_] * 4);
+    bt[s_] = *reinterpret_cast<const float4*>(beta + qs[s_] * 4);
+    dgm[s_] = dbt[s_] = dys[s_] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int64_t S = (int64_t)B * N;
+  for (int64_t s0 = (int64_t)blockIdx.x * G::SPB; s0 < S; s0 += (int64_t)gridDim.x * G::SPB) {
+    int64_t sidx = s0 + sp;
+    const bool live = sidx < S;
+    if (!live) sidx = S - 1;
+    const int b = (int)(sidx / N), n = (int)(sidx - (int64_t)b * N);
+    const int64_t ybase = ((int64_t)b * L * N + n) * G::CT;
+    const int64_t dbase = ((int64_t)b * L2 * N + n) * G::CT;
+    float mean[3], rstd[3];
+#pragma unroll
+    for (int bb = 0; bb < 3; ++bb) {
+      mean[bb] = stats[(sidx * 3 + bb) * 2];
+      rstd[bb] = stats[(sidx * 3 + bb) * 2 + 1];
+    }
+    float ms[3], rs[3];
+#pragma unroll
+    for (int s_ = 0; s_ < 3; ++s_) {
+      ms[s_] = sel3(brs[s_], mean[0], mean[1], mean[2]);
+      rs[s_] = sel3(brs[s_], rstd[0], rstd[1], rstd[2]);
+    }
+    float4 yh[GN_NPMAX], gd[GN_NPMAX];                    // y (then y_hat) and dact (then d y_hat)
+    int32_t off[GN_NPMAX];
+    const float* yb = y + ybase;
+    const float* db = dact + dbase;
+    float* ob = dy + ybase;
+    {
+      int t = l2 / G::QPR, q = l2 % G::QPR;
+#pragma unroll
+      for (int i = 0; i < GN_NPMAX; ++i) {
+        off[i] = t * (int32_t)tstride + q * 4;
+        if (i < NP) {
+          yh[i] = *reinterpret_cast<const float4*>(yb + off[i]);
+          const bool has = (t % dstride) == 0;
+          gd[i] = has ? *reinterpret_cast<const float4*>(db + (t / dstride) * (int32_t)tstride + q * 4)
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        t += G::DT;
+        q += G::DQ;
+        if (q >= G::QPR) { q -= G::QPR; ++t; }
+      }
+    }
+    float a1[3] = {0.f, 0.f, 0.f}, a2[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < GN_NPMAX; ++i)
+      if (i < NP) {
+        const int s_ = i % 3;
+#define GN_ELEM(c)                                                               \
+  {                                                                              \
+    const float h_ = (yh[i].c - ms[s_]) * rs[s_];                                \
+    const float g_ = gd[i].c * dgelu_erf_fast(h_ * gm[s_].c + bt[s_].c);              \
+    if (live) { dgm[s_].c += g_ * h_; dbt[s_].c += g_; }                         \
+    const float d_ = g_ * gm[s_].c;                                              \
+    a1[s_] += d_;                                                                \
+    a2[s_] += d_ * h_;                                                           \
+    yh[i].c = h_;                                                                \
+    gd[i].c = d_;                                                                \
+  }
+        GN_ELEM(x) GN_ELEM(y) GN_ELEM(z) GN_ELEM(w)
+#undef GN_ELEM
+      }
+    float s1[3], s2[3];
+#pragma unroll
+    for (int bb = 0; bb < 3; ++bb) {
+      s1[bb] = (brs[0] == bb ? a1[0] : 0.f) + (brs[1] == bb ? a1[1] : 0.f) + (brs[2] == bb ? a1[2] : 0.f);
+      s2[bb] = (brs[0] == bb ? a2[0] : 0.f) + (brs[1] == bb ? a2[1] : 0.f) + (brs[2] == bb ? a2[2] : 0.f);
+    }
+    seq_reduce3<WPS>(s1, xch, wave, lane);
+    seq_reduce3<WPS>(s2, xch, wave, lane);
+    float m1[3], m2[3];
+#pragma unroll
+    for (int s_ = 0; s_ < 3; ++s_) {
+      m1[s_] = sel3(brs[s_], s1[0], s1[1], s1[2]) * inv_cnt;
+      m2[s_] = sel3(brs[s_], s2[0], s2[1], s2[2]) * inv_cnt;
+    }
+    if (live) {
+#pragma unroll
+      for (int i = 0; i < GN_NPMAX; ++i)
+        if (i < NP) {
+          const int s_ = i % 3;
+          float4 o;
+          o.x = rs[s_] * (gd[i].x - m1[s_] - yh[i].x * m2[s_]);
+          o.y = rs[s_] * (gd[i].y - m1[s_] - yh[i].y * m2[s_]);
+          o.z = rs[s_] * (gd[i].z - m1[s_] - yh[i].z * m2[s_]);
+          o.w = rs[s_] * (gd[i].w - m1[s_] - yh[i].w * m2[s_]);
+          *reinterpret_cast<float4*>(ob + off[i]) = o;
+          dys[s_].x += o.x; dys[s_].y += o.y; dys[s_].z += o.z; dys[s_].w += o.w;   // conv-bias gradient
+        }
+    }
+  }
+  // block reduction of the per-lane parameter gradients (each channel is held by many lanes) -> one partial row
+  __syncthreads();
+#pragma unroll
+  for (int s_ = 0; s_ < 3; ++s_) {
+    const int c = qs[s_] * 4;
+    atomicAdd(&red[c + 0], dgm[s_].x); atomicAdd(&red[c + 1], dgm[s_].y);
+    atomicAdd(&red[c + 2], dgm[s_].z); atomicAdd(&red[c + 3], dgm[s_].w);
+    atomicAdd(&red[G::CT + c + 0], dbt[s_].x); atomicAdd(&red[G::CT + c + 1], dbt[s_].y);
+    atomicAdd(&red[G::CT + c + 2], dbt[s_].z); atomicAdd(&red[G::CT + c + 3], dbt[s_].w);
+    atomicAdd(&red[2 * G::CT + c + 0], dys[s_].x); atomicAdd(&red[2 * G::CT + c + 1], dys[s_].y);
+    atomicAdd(&red[2 * G::CT + c + 2], dys[s_].z); atomicAdd(&red[2 * G::CT + c + 3], dys[s_].w);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 3 * G::CT; c += G::NTHR) partials[(int64_t)blockIdx.x * 3 * G::CT + c] = red[c];
+}
+
 // ------------------------------------------------------------------------------ column sums
 // stage 1: grid (colblocks, RB, nseg).  Lane = column, the 4 waves stride the block's row chunk.
 __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ in, int64_t ld, int64_t outer,
@@ -369,6 +657,16 @@ __global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ w
 int ln_blocks(int64_t M) {
   const int64_t want = (M + 3) / 4;
   return (int)(want < 1024 ? want : 1024);
+}
+// pairs per lane of the register-resident GroupNorm path with `wps` waves per sequence, 0 when the sequence does
+// not fit / is not 16-byte friendly
+int gn_reg_pairs(int L, int N, int Cout, int wps, int npmax, const void* a, const void* b) {
+  const int64_t quads = (int64_t)L * (3 * Cout / 4);
+  const int lps = 64 * wps;
+  if ((int64_t)L * N * 3 * Cout >= (1ll << 31)) return 0;      // 32-bit offsets inside one sample
+  if (quads % lps != 0 || quads / lps > npmax) return 0;
+  if (!tecm_aligned(a, 16) || !tecm_aligned(b, 16)) return 0;
+  return (int)(quads / lps);
 }
 int gn_blocks(int64_t S) {
   const int64_t want = (S + 3) / 4;
@@ -441,6 +739,38 @@ extern "C" int tecm_groupnorm_gelu_fwd(const float* y, const float* gamma, const
   const int64_t S = (int64_t)B * N;
   const dim3 grid((unsigned)((S + 3) / 4));
   hipStream_t st = (hipStream_t)stream;
+  // register-resident paths: one HBM read of y, float4 accesses
+#define GN_FWD_REG(CPB, WPS, NPM, GRID) \
+  hipLaunchKernelGGL((gn_gelu_fwd_reg<CPB, WPS, NPM>), GRID, dim3(WPS > 4 ? 64 * WPS : 256), 0, st, y, gamma, beta, act, \
+                     stats, B, L, N, eps, np)
+  int np = gn_reg_pairs(L, N, Cout, 4, 9, y, act);
+  if (np > 0) {
+    const dim3 g4((unsigned)S);
+    if (Cout == 64) GN_FWD_REG(1, 4, 9, g4);
+    else if (Cout == 128) GN_FWD_REG(2, 4, 9, g4);
+    else GN_FWD_REG(4, 4, 9, g4);
+    TECM_CHECK_LAUNCH("tecm_groupnorm_gelu_fwd/reg4");
+    return TECM_OK;
+  }
+  np = gn_reg_pairs(L, N, Cout, 8, 9, y, act);
+  if (np > 0) {
+    const dim3 g8((unsigned)S);
+    if (Cout == 64) GN_FWD_REG(1, 8, 9, g8);
+    else if (Cout == 128) GN_FWD_REG(2, 8, 9, g8);
+    else GN_FWD_REG(4, 8, 9, g8);
+    TECM_CHECK_LAUNCH("tecm_groupnorm_gelu_fwd/reg8");
+    return TECM_OK;
+  }
+  np = gn_reg_pairs(L, N, Cout, 2, 18, y, act);
+  if (np > 0) {
+    const dim3 g2((unsigned)((S + 1) / 2));
+    if (Cout == 64) GN_FWD_REG(1, 2, 18, g2);
+    else if (Cout == 128) GN_FWD_REG(2, 2, 18, g2);
+    else GN_FWD_REG(4, 2, 18, g2);
+    TECM_CHECK_LAUNCH("tecm_groupnorm_gelu_fwd/reg2");
+    return TECM_OK;
+  }
+#undef GN_FWD_REG
   if (Cout == 64)
     hipLaunchKernelGGL((gn_gelu_fwd_kernel<1>), grid, dim3(256), 0, st, y, gamma, beta, act, stats, B, L, N, eps);
   else if (Cout == 128)
@@ -464,6 +794,34 @@ extern "C" int tecm_groupnorm_gelu_bwd(const float* dact, int32_t dstride, const
   TECM_REQUIRE(dact && y && gamma && beta && stats && dgb_partials, TECM_E_ARG, "tecm_groupnorm_gelu_bwd: null pointer");
   const int L2 = (L + dstride - 1) / dstride;
   hipStream_t st = (hipStream_t)stream;
+  const int np = tecm_aligned(dact, 16) ? gn_reg_pairs(L, N, Cout, 4, 9, y, dy) : 0;
+  if (np > 0) {
+    if (Cout == 64)
+      hipLaunchKernelGGL((gn_gelu_bwd_reg<1, 4, 9>), dim3(nb), dim3(256), 0, st, dact, dstride, L2, y, gamma, beta, stats,
+                         dy, dgb_partials, B, L, N, np);
+    else if (Cout == 128)
+      hipLaunchKernelGGL((gn_gelu_bwd_reg<2, 4, 9>), dim3(nb), dim3(256), 0, st, dact, dstride, L2, y, gamma, beta, stats,
+                         dy, dgb_partials, B, L, N, np);
+    else
+      hipLaunchKernelGGL((gn_gelu_bwd_reg<4, 4, 9>), dim3(nb), dim3(256), 0, st, dact, dstride, L2, y, gamma, beta, stats,
+                         dy, dgb_partials, B, L, N, np);
+    TECM_CHECK_LAUNCH("tecm_groupnorm_gelu_bwd/reg");
+    return TECM_OK;
+  }
+  const int np8 = tecm_aligned(dact, 16) ? gn_reg_pairs(L, N, Cout, 8, 9, y, dy) : 0;
+  if (np8 > 0) {
+    if (Cout == 64)
+      hipLaunchKernelGGL((gn_gelu_bwd_reg<1, 8, 9>), dim3(nb), dim3(512), 0, st, dact, dstride, L2, y, gamma, beta, stats,
+                         dy, dgb_partials, B, L, N, np8);
+    else if (Cout == 128)
+      hipLaunchKernelGGL((gn_gelu_bwd_reg<2, 8, 9>), dim3(nb), dim3(512), 0, st, dact, dstride, L2, y, gamma, beta, stats,
+                         dy, dgb_partials, B, L, N, np8);
+    else
+      hipLaunchKernelGGL((gn_gelu_bwd_reg<4, 8, 9>), dim3(nb), dim3(512), 0, st, dact, dstride, L2, y, gamma, beta, stats,
+                         dy, dgb_partials, B, L, N, np8);
+    TECM_CHECK_LAUNCH("tecm_groupnorm_gelu_bwd/reg8");
+    return TECM_OK;
+  }
   if (Cout == 64)
     hipLaunchKernelGGL((gn_gelu_bwd_kernel<1>), dim3(nb), dim3(256), 0, st, dact, dstride, L2, y, gamma, beta, stats,
                        dy, dgb_partials, B, L, N);

@@ -226,7 +226,12 @@ def test_layernorm_fwd_bwd(dev, M, D):
     assert torch.equal(dx2, dx) and torch.equal(dxm, dx * mult)
 
 
-@pytest.mark.parametrize("Bn,L,N,Cout,stride", [(2, 48, 5, 64, 2), (1, 24, 9, 128, 2), (2, 6, 3, 64, 1)])
+# register-resident kernels: 4 waves/sequence (2304 quads), 8 waves (4608 quads: L_in = 96), forward-only 2 waves
+# (1152 quads, odd sequence count), Cout = 256; (2, 6, 3, 64, 1) and the backward of the 2-wave case take the
+# generic multi-pass kernels
+@pytest.mark.parametrize("Bn,L,N,Cout,stride", [(2, 48, 5, 64, 2), (1, 24, 9, 128, 2), (2, 6, 3, 64, 1),
+                                                (1, 96, 3, 64, 2), (1, 48, 3, 128, 1), (1, 24, 3, 64, 2),
+                                                (1, 12, 3, 256, 2)])
 def test_groupnorm_gelu_fwd_bwd(dev, Bn, L, N, Cout, stride):
     from tecmollm import ops
     CT = 3 * Cout

@@ -33,7 +33,7 @@ extern "C" {
 #define TECM_E_LAUNCH (-3)     /* hipGetLastError() != hipSuccess after the launch       */
 #define TECM_E_LDS (-4)        /* problem does not fit the 160 KiB LDS budget            */
 
-#define TECM_ABI_VERSION 1
+#define TECM_ABI_VERSION 2
 int tecm_abi_version(void);
 /* Human-readable text for the last error on this thread (host pointer, never NULL). */
 const char* tecm_last_error(void);
@@ -132,6 +132,12 @@ typedef struct TecmSpatialGrads {
   float* partials; int64_t partial_ld;    /* (num_blocks, partial_ld) per-block sums of
                                              [dWl(C*C) dbl(C) dWr(C*C) dbr(C) datt(C) dbias(C)] */
   int32_t t_chunk; int32_t num_blocks;    /* blocks = num_tiles * B * ceil(L / t_chunk) */
+  /* the tile's edges grouped by SOURCE (d x_l is gathered per source row, no atomics): for tile k with window
+   * [lo, hi) and edge segment [rowptr[n0], rowptr[n1]) of the by-target CSR,
+   *   src_ptr[src_ptr_off[k] + w] .. src_ptr[src_ptr_off[k] + w + 1]   (w = j - lo, 0 <= w < hi - lo)
+   * index, relative to rowptr[n0], the entries of src_col that leave source j; an entry is
+   * ((target - n0) << 16) | slot, slot = position of the edge in its target's CSR row. */
+  const int32_t* src_ptr; const int32_t* src_col; const int32_t* src_ptr_off;
 } TecmSpatialGrads;
 int tecm_spatial_bwd(const TecmSpatial* d, const TecmSpatialGrads* g, void* stream);
 

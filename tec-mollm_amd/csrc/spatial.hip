@@ -22,6 +22,9 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifndef SP_SKIP
+#define SP_SKIP 0      // experiments only: bit0 skip dense x_l/x_r, bit1 edge phase, bit2 outer products, bit3 embedding grads
+#endif
 
 namespace {
 
@@ -30,6 +33,9 @@ constexpr int C = 22;      // feature channels (Cin + Demb)
 constexpr int H = 2;       // heads
 constexpr int CH = C / H;
 constexpr int CP = 24;     // padded row: 16-byte aligned, column 22 carries the constant 1 of the bias trick
+constexpr int DXP = 25;    // row pitch of the d x_l accumulators: odd, so the per-edge LDS float atomics of a wave (same
+                           // column, 64 different rows) hit 64 different banks instead of 8 (measured: the edge phase
+                           // of the backward is bound by ds_add_f32 under bank conflicts)
 
 __device__ __forceinline__ int clampi(int v, int hi) { return v < 0 ? 0 : (v >= hi ? hi - 1 : v); }
 
@@ -109,11 +115,12 @@ __device__ __forceinline__ void stage_mats(const TecmSpatial& d, float* base, Ma
 }
 
 // acc(32 rows x 32 cols) += A[row0 .. row0+31][0..23] . KM   (rows clamped to [0, nrows): duplicates are discarded)
+template <int PA = CP>
 __device__ __forceinline__ void mfma_rows(f32x16& acc, const float* A, int row0, int nrows, const float* KM, int lane) {
   const int i = lane & 31, kq = lane >> 5;
   int row = row0 + i;
   row = row < nrows ? row : nrows - 1;
-  const float* ar = A + row * CP + kq;
+  const float* ar = A + row * PA + kq;
   const float* br = KM + kq * 32 + i;
 #pragma unroll
   for (int s = 0; s < CP / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[2 * s], br[2 * s * 32], acc, 0, 0, 0);
@@ -161,6 +168,21 @@ __device__ __forceinline__ void store_row(float* row, const float (&v)[C], float
     t.z = 4 * q + 2 < C ? v[4 * q + 2] : c22;
     t.w = 4 * q + 3 < C ? v[4 * q + 3] : c23;
     p[q] = t;
+  }
+}
+
+// the CH = 11 channels of head hh out of a 24-float row (16-byte aligned): head 0 = floats 0..10, head 1 = 11..21
+__device__ __forceinline__ void load_head(const float* row, int hh, float (&v)[CH]) {
+  static_assert(CH == 11, "head slicing is written for 11 channels per head");
+  const float4* p = reinterpret_cast<const float4*>(row);
+  if (hh == 0) {
+    const float4 a = p[0], b = p[1], c = p[2];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    v[8] = c.x; v[9] = c.y; v[10] = c.z;
+  } else {
+    const float4 a = p[2], b = p[3], c = p[4], e = p[5];
+    v[0] = a.w; v[1] = b.x; v[2] = b.y; v[3] = b.z; v[4] = b.w; v[5] = c.x; v[6] = c.y; v[7] = c.z;
+    v[8] = c.w; v[9] = e.x; v[10] = e.y;
   }
 }
 
@@ -293,6 +315,7 @@ __global__ __launch_bounds__(256) void spatial_fwd_kernel(const TecmSpatial d) {
 // ------------------------------------------------------------------------------------------ backward
 // acc(32x32) += sum over `rows` of  A[row][0..23]^T  (x)  B[row][0..23]   on the f32 matrix core.
 // Rows are dealt to the 4 waves in pairs (one MFMA consumes k = 2 rows).
+template <int PA = CP>
 __device__ __forceinline__ void outer_accumulate(f32x16& acc, const float* A, const float* Bm, int row_beg,
                                                  int row_end, int wave, int lane) {
   const int i = lane & 31, kq = lane >> 5;
@@ -300,7 +323,7 @@ __device__ __forceinline__ void outer_accumulate(f32x16& acc, const float* A, co
   for (int r0 = row_beg + 2 * wave; r0 < row_end; r0 += 8) {
     const int row = r0 + kq;
     const bool ok = col_ok && row < row_end;
-    const float a = ok ? A[row * CP + i] : 0.f;
+    const float a = ok ? A[row * PA + i] : 0.f;
     const float bv = ok ? Bm[row * CP + i] : 0.f;
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
   }
@@ -321,8 +344,8 @@ __global__ __launch_bounds__(256) void spatial_bwd_kernel(const TecmSpatial d, c
   const int Demb = d.Demb, Cin = d.Cin;
   float* hw = smem;                        // [wm4][CP]   [h | 1 | 0]
   float* xlw = hw + wm4 * CP;              // [wm4][CP]
-  float* dxlw = xlw + wm4 * CP;            // [wm4][CP]
-  float* dxr = dxlw + wm4 * CP;            // [tile_nodes][CP]  x_r of the tile first, then d x_r
+  float* dxlw = xlw + wm4 * CP;            // [wm4][DXP]
+  float* dxr = dxlw + wm4 * DXP;           // [tile_nodes][CP]  x_r of the tile first, then d x_r   (wm4 % 4 == 0: aligned)
   float* gt = dxr + d.tile_nodes * CP;     // [tile_nodes][CP]  dout rows of the tile
   float* dnode = gt + d.tile_nodes * CP;   // [wm4][Demb]
   float* temb = dnode + wm4 * Demb;        // [32]
@@ -332,19 +355,29 @@ __global__ __launch_bounds__(256) void spatial_bwd_kernel(const TecmSpatial d, c
   stage_mats(d, vec + CP, mats, true);
   int* eptr = reinterpret_cast<int*>(vec + CP + 5 * KM_FLOATS);    // [tile_nodes + 1]  CSR slice of the tile
   int* ecol = eptr + d.tile_nodes + 1;                             // [tile_edges_max]  window-relative sources
+  int* sptr = ecol + d.tile_edges_max;                             // [wm4 + 1]  the tile's edges grouped by SOURCE row
+  int* scol = sptr + wm4 + 1;                                      // [tile_edges_max]  (tile target << 16) | slot
+  float* tstat = reinterpret_cast<float*>(scol + d.tile_edges_max);   // [tile_nodes][H][3]  softmax m, 1/z, dot
+  float* attl = tstat + d.tile_nodes * H * 3;                      // [CP]  attention vector (both heads)
   {
     const int ebase = d.rowptr[n0];
     for (int q = tid; q <= n1 - n0; q += 256) eptr[q] = d.rowptr[n0 + q] - ebase;
     const int ne = d.rowptr[n1] - ebase;
-    for (int q = tid; q < ne; q += 256) ecol[q] = d.colidx[ebase + q] - lo;
+    for (int q = tid; q < ne; q += 256) {
+      ecol[q] = d.colidx[ebase + q] - lo;
+      scol[q] = gr.src_col[ebase + q];
+    }
+    const int pbase = gr.src_ptr_off[tile];
+    for (int q = tid; q <= W; q += 256) sptr[q] = gr.src_ptr[pbase + q];
+    if (tid < C) attl[tid] = d.att[tid];
   }
   const bool tf_uniform = d.tf_sn == 0;
 
   for (int q = tid; q < W * Demb; q += 256) dnode[q] = 0.f;
   if (tid < CP) vec[tid] = 0.f;
-  float att[C], datt_acc[C];
+  float att[CH], datt_acc[CH];                      // this thread's head (tid >> 7) only
 #pragma unroll
-  for (int c = 0; c < C; ++c) { att[c] = d.att[c]; datt_acc[c] = 0.f; }
+  for (int c = 0; c < CH; ++c) { att[c] = d.att[(tid >> 7) * CH + c]; datt_acc[c] = 0.f; }
   f32x16 accL, accR;
 #pragma unroll
   for (int e = 0; e < 16; ++e) { accL[e] = 0.f; accR[e] = 0.f; }
@@ -369,98 +402,189 @@ __global__ __launch_bounds__(256) void spatial_bwd_kernel(const TecmSpatial d, c
 
     // ---- A: h for the window, then x_l (window) and x_r (tile) on the matrix cores; clear d x_l
     build_window(d, hw, wa, wb, lo, grow, tf_uniform ? temb : nullptr, b, t);
-    for (int q = wa * CP + tid; q < wb * CP; q += 256) dxlw[q] = 0.f;
     __syncthreads();
-    dense_rows(xlw, hw, wa, wb, mats.WlT, wave, lane);
-    dense_rows(dxr - ta * CP, hw, ta, tb, mats.WrT, wave, lane);
-    __syncthreads();
-
-    // ---- B: per target node, two passes over its edges
-    const int i = n0 + tid;
-    if (i < n1) {
-      const int wi = i - lo;
-      float xr[C], g[C], dxr_acc[C];
-      load_row(dxr + tid * CP, xr);
-      load_row(gr.dout + (grow + i) * CP, g);
-      store_row(gt + tid * CP, g, 0.f, 0.f);
-#pragma unroll
-      for (int c = 0; c < C; ++c) dxr_acc[c] = 0.f;
-      const int64_t rowi = (int64_t)(t * d.B + b) * d.N + i;
-      const int e0 = use_edges ? eptr[tid] : 0;
-      const int deg = use_edges ? eptr[tid + 1] - e0 : 0;
-      // pass 1: online softmax statistics and the numerator of dot_h = sum_j alpha_ij dalpha_ij
-      float m[H], z[H], num[H];
-#pragma unroll
-      for (int hh = 0; hh < H; ++hh) { m[hh] = -INFINITY; z[hh] = 0.f; num[hh] = 0.f; }
-      for (int s = 0; s <= deg; ++s) {
-        const int j = s == deg ? wi : ecol[e0 + s];
-        float xlj[C], e[H];
-        load_row(xlw + j * CP, xlj);
-        logits(xlj, xr, att, e);
-#pragma unroll
-        for (int hh = 0; hh < H; ++hh) {
-          float da = 0.f;
-#pragma unroll
-          for (int c = 0; c < CH; ++c) da = fmaf(g[hh * CH + c], xlj[hh * CH + c], da);
-          if (dth) da *= tecm_drop_mult(d.alpha_drop.seed, (uint64_t)((rowi * H + hh) * d.alpha_drop.ld + s), dth, dinv);
-          const float mn = fmaxf(m[hh], e[hh]);
-          const float corr = __expf(m[hh] - mn), p = __expf(e[hh] - mn);
-          z[hh] = z[hh] * corr + p;
-          num[hh] = num[hh] * corr + p * da;
-          m[hh] = mn;
-        }
-      }
-      float zinv[H], dot[H];
-#pragma unroll
-      for (int hh = 0; hh < H; ++hh) {
-        zinv[hh] = 1.0f / (z[hh] + 1e-16f);
-        dot[hh] = num[hh] * zinv[hh];
-      }
-      // pass 2: gradients
-      for (int s = 0; s <= deg; ++s) {
-        const int j = s == deg ? wi : ecol[e0 + s];
-        float xlj[C], e[H];
-        load_row(xlw + j * CP, xlj);
-        logits(xlj, xr, att, e);
-#pragma unroll
-        for (int hh = 0; hh < H; ++hh) {
-          const float alpha = __expf(e[hh] - m[hh]) * zinv[hh];
-          float mult = 1.0f;
-          if (dth) mult = tecm_drop_mult(d.alpha_drop.seed, (uint64_t)((rowi * H + hh) * d.alpha_drop.ld + s), dth, dinv);
-          float da = 0.f;
-#pragma unroll
-          for (int c = 0; c < CH; ++c) da = fmaf(g[hh * CH + c], xlj[hh * CH + c], da);
-          const float de = alpha * (da * mult - dot[hh]);
-          const float am = alpha * mult;
-#pragma unroll
-          for (int c = 0; c < CH; ++c) {
-            const int k = hh * CH + c;
-            const float sv = xlj[k] + xr[k];
-            const float ds = de * att[k] * (sv > 0.f ? 1.0f : NEG_SLOPE);
-            datt_acc[k] += de * lrelu(sv);
-            dxr_acc[k] += ds;
-            atomicAdd(&dxlw[j * CP + k], am * g[k] + ds);
-          }
-        }
-      }
-      store_row(dxr + tid * CP, dxr_acc, 0.f, 0.f);
+    if (!(SP_SKIP & 1)) {
+      dense_rows(xlw, hw, wa, wb, mats.WlT, wave, lane);
+      dense_rows(dxr - ta * CP, hw, ta, tb, mats.WrT, wave, lane);
     }
     __syncthreads();
 
+    // ---- B: per (target node, head), two passes over the node's edges.  Threads 0..127 take head 0 of tile node
+    //         tid, threads 128..255 head 1 of node tid-128: the head is wave-uniform, all four waves work, and the
+    //         two threads of a node only ever touch their own 11 columns of the shared rows.
+    const int tn = tid & 127, hh = tid >> 7;
+    const int i = n0 + tn;
+    const bool tgt = tn < d.tile_nodes && i < n1;
+    float dxr_acc[CH];
+    if (tgt) {
+      const int wi = i - lo;
+      const int c0 = hh * CH;
+      float xr[CH], g[CH];
+      load_head(dxr + tn * CP, hh, xr);
+      load_head(gr.dout + (grow + i) * CP, hh, g);
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        gt[tn * CP + c0 + c] = g[c];
+        dxr_acc[c] = 0.f;
+      }
+      if (hh == 1) { gt[tn * CP + C] = 0.f; gt[tn * CP + C + 1] = 0.f; }
+      const int64_t rowi = (int64_t)(t * d.B + b) * d.N + i;
+      const uint64_t dbase = (uint64_t)((rowi * H + hh) * d.alpha_drop.ld);
+      const int e0 = use_edges ? eptr[tn] : 0;
+      const int deg = use_edges ? eptr[tn + 1] - e0 : 0;
+      // Both passes walk the edge list two edges at a time (even / odd positions): the two chains are
+      // independent, so their LDS round trips and exponentials overlap -- with one wave per SIMD there is no other
+      // wave to hide that latency behind.  Slot s == deg is the implicit self loop.
+      auto edge_terms = [&](int s_, float (&xlj)[CH], float& e, float& da) {
+        const int j = s_ >= deg ? wi : ecol[e0 + s_];
+        load_head(xlw + j * CP, hh, xlj);
+        e = 0.f;
+        da = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          e = fmaf(att[c], lrelu(xlj[c] + xr[c]), e);
+          da = fmaf(g[c], xlj[c], da);
+        }
+        return j;
+      };
+      // pass 1: online softmax statistics and the numerator of dot = sum_j alpha_ij dalpha_ij
+      float m2[2] = {-INFINITY, -INFINITY}, z2[2] = {0.f, 0.f}, num2[2] = {0.f, 0.f};
+      for (int s = 0; s <= deg; s += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          if (s + u <= deg) {
+            float xlj[CH], e, da;
+            edge_terms(s + u, xlj, e, da);
+            if (dth) da *= tecm_drop_mult(d.alpha_drop.seed, dbase + s + u, dth, dinv);
+            const float mn = fmaxf(m2[u], e);
+            const float corr = __expf(m2[u] - mn), pw = __expf(e - mn);
+            z2[u] = z2[u] * corr + pw;
+            num2[u] = num2[u] * corr + pw * da;
+            m2[u] = mn;
+          }
+        }
+      }
+      const float m = fmaxf(m2[0], m2[1]);                 // chain 0 always holds at least slot 0
+      const float k0 = __expf(m2[0] - m), k1 = __expf(m2[1] - m);   // exp(-inf) = 0 for an empty chain 1
+      const float z = z2[0] * k0 + z2[1] * k1;
+      const float num = num2[0] * k0 + num2[1] * k1;
+      const float zinv = 1.0f / (z + 1e-16f);
+      const float dot = num * zinv;
+      tstat[(tn * H + hh) * 3 + 0] = m;                    // the by-source pass recomputes alpha from these
+      tstat[(tn * H + hh) * 3 + 1] = zinv;
+      tstat[(tn * H + hh) * 3 + 2] = dot;
+      // pass 2: gradients that accumulate per TARGET (d x_r, d att); d x_l is gathered per source below
+      for (int s = 0; s <= deg; s += 2) {
+        float xl2[2][CH], e_[2], da_[2];
+        int j2[2];
+        bool on[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          on[u] = s + u <= deg;
+          j2[u] = edge_terms(on[u] ? s + u : deg, xl2[u], e_[u], da_[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          if (on[u]) {
+            const float alpha = __expf(e_[u] - m) * zinv;
+            float mult = 1.0f;
+            if (dth) mult = tecm_drop_mult(d.alpha_drop.seed, dbase + s + u, dth, dinv);
+            const float de = alpha * (da_[u] * mult - dot);
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+              const float sv = xl2[u][c] + xr[c];
+              const float ds = de * att[c] * (sv > 0.f ? 1.0f : NEG_SLOPE);
+              datt_acc[c] += de * lrelu(sv);
+              dxr_acc[c] += ds;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- B': d x_l gathered per SOURCE row of the window (no LDS float atomics: ds_add_f32 runs at about one
+    //          lane per 3.5 cycles on this part and was 40 % of the kernel).  Item = (window row w, head); it walks
+    //          the tile's edges that leave w (host-built by-source lists) plus w's own self loop when w is a tile row,
+    //          recomputes alpha / d e from the per-target statistics and sums into registers.
+    {
+      const int Wn = wb - wa;
+      for (int it = tid; it < 2 * Wn; it += 256) {
+        const int h2 = it >= Wn ? 1 : 0;
+        const int w = wa + it - h2 * Wn;
+        const int c0 = h2 * CH;
+        float xl[CH], acc[CH], at[CH];
+        load_head(xlw + w * CP, h2, xl);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) { acc[c] = 0.f; at[c] = attl[c0 + c]; }
+        const bool self = w >= ta && w < tb;
+        const int q0 = use_edges ? sptr[w] : 0;
+        const int q1 = use_edges ? sptr[w + 1] : 0;
+        for (int q = q0; q < q1 + (self ? 1 : 0); ++q) {
+          int tt, sl;
+          if (q < q1) {
+            const int code = scol[q];
+            tt = code >> 16;
+            sl = code & 0xffff;
+          } else {                                          // the implicit self loop: last slot of its target
+            tt = w - ta;
+            sl = use_edges ? eptr[tt + 1] - eptr[tt] : 0;
+          }
+          float xr[CH], g[CH];
+          load_head(dxr + tt * CP, h2, xr);                 // still x_r: d x_r is written after this pass
+          load_head(gt + tt * CP, h2, g);
+          float e = 0.f, da = 0.f;
+#pragma unroll
+          for (int c = 0; c < CH; ++c) {
+            e = fmaf(at[c], lrelu(xl[c] + xr[c]), e);
+            da = fmaf(g[c], xl[c], da);
+          }
+          const float* st = tstat + (tt * H + h2) * 3;
+          const float alpha = __expf(e - st[0]) * st[1];
+          float mult = 1.0f;
+          if (dth) {
+            const int64_t rowt = (int64_t)(t * d.B + b) * d.N + n0 + tt;
+            mult = tecm_drop_mult(d.alpha_drop.seed, (uint64_t)((rowt * H + h2) * d.alpha_drop.ld) + sl, dth, dinv);
+          }
+          const float de = alpha * (da * mult - st[2]);
+          const float am = alpha * mult;
+#pragma unroll
+          for (int c = 0; c < CH; ++c) {
+            const float sv = xl[c] + xr[c];
+            acc[c] += am * g[c] + de * at[c] * (sv > 0.f ? 1.0f : NEG_SLOPE);
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) dxlw[w * DXP + c0 + c] = acc[c];
+        if (h2 == 1) { dxlw[w * DXP + C] = 0.f; dxlw[w * DXP + C + 1] = 0.f; dxlw[w * DXP + C + 2] = 0.f; }
+      }
+    }
+    __syncthreads();
+    if (tgt) {
+      const int c0 = hh * CH;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) dxr[tn * CP + c0 + c] = dxr_acc[c];
+      if (hh == 1) { dxr[tn * CP + C] = 0.f; dxr[tn * CP + C + 1] = 0.f; }
+    }
+    __syncthreads();
+
+
     // ---- C1: [dWl | dbl] += dxl^T [h, 1] over the window, [dWr | dbr] += dxr^T [h, 1] over the tile
-    outer_accumulate(accL, dxlw, hw, wa, wb, wave, lane);
-    outer_accumulate(accR, dxr - ta * CP, hw, ta, tb, wave, lane);
+    if (!(SP_SKIP & 4)) {
+      outer_accumulate<DXP>(accL, dxlw, hw, wa, wb, wave, lane);
+      outer_accumulate(accR, dxr - ta * CP, hw, ta, tb, wave, lane);
+    }
 
     // ---- C2: embedding part of dh = dxl.WlE (+ tile rows: dxr.WrE + dout.Sel) -> node-table accumulators and
     //          the temporal tables, all three products chained into one MFMA accumulator per 32-row block
-    {
+    if (!(SP_SKIP & 8)) {
       const int j = lane & 31, kq = lane >> 5;
       float colsum = 0.f;
       for (int r0 = wa + 32 * wave; r0 < wb; r0 += 128) {
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-        mfma_rows(acc, dxlw, r0, wb, mats.WlE, lane);
+        mfma_rows<DXP>(acc, dxlw, r0, wb, mats.WlE, lane);
         const bool overlaps = r0 + 32 > ta && r0 < tb;                       // wave-uniform
         if (overlaps) {
           // tile operands are indexed relative to the tile; rows of this block outside the tile contribute 0
@@ -512,9 +636,9 @@ __global__ __launch_bounds__(256) void spatial_bwd_kernel(const TecmSpatial d, c
   // ---- block results.  partial row layout: dWl (C*C) | dbl (C) | dWr (C*C) | dbr (C) | datt (C) | (C unused)
   __syncthreads();
 #pragma unroll
-  for (int c = 0; c < C; ++c) {
+  for (int c = 0; c < CH; ++c) {
     const float a = wave_sum(datt_acc[c]);
-    if (lane == 0) atomicAdd(&vec[c], a);
+    if (lane == 0) atomicAdd(&vec[(tid >> 7) * CH + c], a);
   }
   __syncthreads();
   float* part = gr.partials + (int64_t)blockIdx.x * gr.partial_ld;
@@ -601,6 +725,8 @@ extern "C" int tecm_spatial_bwd(const TecmSpatial* dp, const TecmSpatialGrads* g
                TECM_E_ARG, "tecm_spatial_bwd: null pointer");
   TECM_REQUIRE(tecm_aligned(g.dout, 16), TECM_E_ALIGN, "tecm_spatial_bwd: dout must be 16-byte aligned");
   TECM_REQUIRE(g.t_chunk > 0, TECM_E_ARG, "tecm_spatial_bwd: t_chunk must be positive");
+  TECM_REQUIRE(g.src_ptr && g.src_col && g.src_ptr_off, TECM_E_ARG, "tecm_spatial_bwd: by-source edge lists missing");
+  TECM_REQUIRE(d.tile_nodes <= 128, TECM_E_ARG, "tecm_spatial_bwd: tile_nodes must be <= 128 (two threads per node)");
   const int nchunks = (d.L + g.t_chunk - 1) / g.t_chunk;
   const int nblocks = d.num_tiles * d.B * nchunks;
   TECM_REQUIRE(g.num_blocks == nblocks, TECM_E_ARG, "tecm_spatial_bwd: num_blocks must be %d (got %d)", nblocks,
@@ -608,8 +734,8 @@ extern "C" int tecm_spatial_bwd(const TecmSpatial* dp, const TecmSpatialGrads* g
   TECM_REQUIRE(g.partial_ld >= 2 * C * C + 4 * C, TECM_E_ARG, "tecm_spatial_bwd: partial_ld must be >= %d",
                2 * C * C + 4 * C);
   const int wm4 = (d.win_max + 3) & ~3;
-  size_t floats = (size_t)3 * wm4 * CP + (size_t)2 * d.tile_nodes * CP + (size_t)wm4 * d.Demb + 64 + CP + 5 * KM_FLOATS +
-                  d.tile_nodes + 1 + d.tile_edges_max;
+  size_t floats = (size_t)2 * wm4 * CP + (size_t)wm4 * DXP + (size_t)2 * d.tile_nodes * CP + (size_t)wm4 * d.Demb + 64 + CP + 5 * KM_FLOATS +
+                  d.tile_nodes + 1 + 2 * (size_t)d.tile_edges_max + wm4 + 1 + (size_t)d.tile_nodes * H * 3 + CP;
   if (floats < 8192 + 64) floats = 8192 + 64;          // the final 4-wave MFMA reduction needs 2*4*32*32 floats
   const size_t lds = sizeof(float) * floats;
   TECM_REQUIRE(lds <= (size_t)kLdsBudget, TECM_E_LDS,

@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TECM_LIB", os.path.join(_HERE, "libtecmollm_hip.so"))   # override for experiments
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_f32p = C.c_void_p
 
@@ -70,6 +70,7 @@ class TecmSpatialGrads(C.Structure):
         ("d_year_tab", c_f32p), ("d_season_tab", c_f32p),
         ("partials", c_f32p), ("partial_ld", C.c_int64),
         ("t_chunk", C.c_int32), ("num_blocks", C.c_int32),
+        ("src_ptr", C.c_void_p), ("src_col", C.c_void_p), ("src_ptr_off", C.c_void_p),
     ]
 
 

@@ -130,6 +130,8 @@ class SpatialFn(torch.autograd.Function):
         g.d_year_tab, g.d_season_tab = d_year.data_ptr(), d_season.data_ptr()
         g.partials, g.partial_ld = partials.data_ptr(), pld
         g.t_chunk, g.num_blocks = t_chunk, nblocks
+        g.src_ptr, g.src_col = meta.src_ptr.data_ptr(), meta.src_col.data_ptr()
+        g.src_ptr_off = meta.src_ptr_off.data_ptr()
         check(lib().tecm_spatial_bwd(C.byref(d), C.byref(g), stream_ptr()), "tecm_spatial_bwd")
         s = colsum(partials, pld, nblocks, 1, 1, pld)[0]
         o = 0

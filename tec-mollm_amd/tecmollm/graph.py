@@ -32,6 +32,9 @@ class GraphMeta:
     colidx: torch.Tensor   # int32 (E') device
     tile_lo: torch.Tensor  # int32 (num_tiles) device
     tile_hi: torch.Tensor  # int32 (num_tiles) device
+    src_ptr: torch.Tensor      # int32: per tile, W+1 offsets into the tile's edge segment, grouped by source row
+    src_col: torch.Tensor      # int32 (E'): ((target - n0) << 16) | slot, tile segments aligned with colidx
+    src_ptr_off: torch.Tensor  # int32 (num_tiles): start of each tile's src_ptr run
 
 
 def csr_by_target(edge_index: np.ndarray, num_nodes: int) -> Tuple[np.ndarray, np.ndarray]:
@@ -61,13 +64,41 @@ def tile_windows(rowptr: np.ndarray, colidx: np.ndarray, num_nodes: int, tile_no
 
 
 CP = 24
+DXP = 25            # row pitch of the backward's d x_l accumulators (csrc/spatial.hip)
 KM_FLOATS = CP * 32
+
+
+def by_source_lists(rowptr: np.ndarray, colidx: np.ndarray, num_nodes: int, tile_nodes: int, lo: np.ndarray,
+                    hi: np.ndarray):
+    """Per tile, the tile's by-target edge segment regrouped by SOURCE (the backward gathers d x_l per source
+    row instead of scattering it with atomics).  Returns (src_ptr, src_col, src_ptr_off) as in include/tecmollm.h."""
+    deg = np.diff(rowptr).astype(np.int64)
+    tgt = np.repeat(np.arange(num_nodes, dtype=np.int64), deg)           # target of every CSR entry
+    slot = np.arange(colidx.size, dtype=np.int64) - np.repeat(rowptr[:-1].astype(np.int64), deg)
+    if slot.size and slot.max() >= (1 << 16):
+        raise ValueError("a node has more than 65535 in-edges")
+    src_col = np.zeros(max(colidx.size, 1), dtype=np.int32)
+    ptrs, offs, pos = [], [], 0
+    for k in range(lo.size):
+        n0, n1 = k * tile_nodes, min(num_nodes, (k + 1) * tile_nodes)
+        e0, e1 = int(rowptr[n0]), int(rowptr[n1])
+        w = colidx[e0:e1].astype(np.int64) - int(lo[k])
+        order = np.argsort(w, kind="stable")
+        src_col[e0:e1] = (((tgt[e0:e1][order] - n0) << 16) | slot[e0:e1][order]).astype(np.int32)
+        W = int(hi[k] - lo[k])
+        p = np.zeros(W + 1, dtype=np.int64)
+        np.add.at(p, w + 1, 1)
+        ptrs.append(np.cumsum(p).astype(np.int32))
+        offs.append(pos)
+        pos += W + 1
+    return np.concatenate(ptrs), src_col, np.asarray(offs, dtype=np.int32)
 
 
 def lds_bytes_bwd(win: int, tile_nodes: int, demb: int = 16, tile_edges: int = 0) -> int:
     """Dynamic LDS of spatial_bwd_kernel (must match csrc/spatial.hip:tecm_spatial_bwd)."""
     wm4 = (win + 3) & ~3
-    floats = 3 * wm4 * CP + 2 * tile_nodes * CP + wm4 * demb + 64 + CP + 5 * KM_FLOATS + tile_nodes + 1 + tile_edges
+    floats = (2 * wm4 * CP + wm4 * DXP + 2 * tile_nodes * CP + wm4 * demb + 64 + CP + 5 * KM_FLOATS + tile_nodes + 1 +
+              2 * tile_edges + wm4 + 1 + tile_nodes * 6 + CP)
     return 4 * max(floats, 8192 + 64)
 
 
@@ -91,10 +122,12 @@ def build(edge_index: torch.Tensor, num_nodes: int, device: torch.device, demb: 
             "renumber the nodes (e.g. reverse Cuthill-McKee) so that neighbours have nearby ids")
     tn, lo, hi, wmax, emax = chosen
     to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)   # noqa: E731
+    sp, sc, so = by_source_lists(rowptr, colidx, num_nodes, tn, lo, hi)
     return GraphMeta(num_nodes=num_nodes, num_edges=int(colidx.size), max_deg=int(deg.max()) if deg.size else 0,
                      tile_nodes=tn, num_tiles=int(lo.size), win_max=wmax, tile_edges_max=emax,
                      rowptr=to(rowptr),
-                     colidx=to(colidx if colidx.size else np.zeros(1, np.int32)), tile_lo=to(lo), tile_hi=to(hi))
+                     colidx=to(colidx if colidx.size else np.zeros(1, np.int32)), tile_lo=to(lo), tile_hi=to(hi),
+                     src_ptr=to(sp), src_col=to(sc), src_ptr_off=to(so))
 
 
 _cache: Dict[Tuple[int, int, int, str], Tuple[torch.Tensor, GraphMeta]] = {}

@@ -34,7 +34,8 @@ def test_library_exports_every_declared_symbol(built_lib):
     for name in sorted(declared):
         assert hasattr(handle, name), f"{name} declared in tecmollm.h but not exported"
     handle.tecm_abi_version.restype = ctypes.c_int
-    assert handle.tecm_abi_version() == 1
+    from tecmollm import _lib
+    assert handle.tecm_abi_version() == _lib.ABI_VERSION == 2
     handle.tecm_last_error.restype = ctypes.c_char_p
     assert isinstance(handle.tecm_last_error(), bytes)
 
@@ -242,3 +243,29 @@ def test_native_train_step_refuses_cpu_parameters():
     from tecmollm.train import TrainStep
     with pytest.raises(TecmError):
         TrainStep(_Toy())                      # optimizer="native" is the default and is HIP-only
+
+
+def test_by_source_lists_are_a_permutation_of_each_tile_segment():
+    """Every by-target CSR entry of a tile appears exactly once in the tile's by-source lists, under its source row,
+    carrying its (target, slot) -- what the backward's gather pass relies on."""
+    from tecmollm import graph as G
+    ei, _ = R.grid_graph(7, 9, threshold_km=900.0)
+    rowptr, col = G.csr_by_target(ei.numpy(), 63)
+    for tn in (16, 5):
+        lo, hi = G.tile_windows(rowptr, col, 63, tn)
+        sp, sc, so = G.by_source_lists(rowptr, col, 63, tn, lo, hi)
+        for k in range(lo.size):
+            n0, n1 = k * tn, min(63, (k + 1) * tn)
+            e0, e1 = int(rowptr[n0]), int(rowptr[n1])
+            W = int(hi[k] - lo[k])
+            ptr = sp[so[k]:so[k] + W + 1]
+            assert ptr[0] == 0 and ptr[-1] == e1 - e0 and np.all(np.diff(ptr) >= 0)
+            seen = set()
+            for w in range(W):
+                for q in range(ptr[w], ptr[w + 1]):
+                    code = int(sc[e0 + q])
+                    t_rel, slot = code >> 16, code & 0xFFFF
+                    e = int(rowptr[n0 + t_rel]) + slot                  # the by-target entry this refers to
+                    assert e0 <= e < e1 and int(col[e]) == int(lo[k]) + w
+                    seen.add(e)
+            assert seen == set(range(e0, e1))

@@ -266,7 +266,7 @@ def colsum(inp: torch.Tensor, ld: int, outer: int, inner: int, nseg: int, Cn: in
     """out[s][c] = scale * sum_{o<outer, j<inner} in[((o*nseg + s)*inner + j)*ld + c]  -> (nseg, Cn)."""
     if out is None:
         out = torch.empty(nseg, Cn, device=inp.device, dtype=torch.float32)
-    ws = torch.empty(256 * nseg * Cn, device=inp.device, dtype=torch.float32)
+    ws = torch.empty(1024 * nseg * Cn, device=inp.device, dtype=torch.float32)     # contract: include/tecmollm.h
     idr = in_drop if in_drop is not None else NO_DROP
     check(lib().tecm_colsum(_off(inp, in_off), ld, outer, inner, nseg, Cn, out.data_ptr(), Cn, 1 if accumulate else 0,
                             scale, C.byref(idr), ws.data_ptr(), stream_ptr()), "tecm_colsum")

@@ -4,19 +4,32 @@
 
 namespace {
 
+// Lane = output element (coalesced over each slab), the block's 4 waves take the slabs in turn with four loads in
+// flight each: a dW GEMM of this path has up to 256 slabs of a few thousand elements, so one thread walking all
+// slabs of its element is a serial chain of ~64 dependent-latency steps (36 us per call, 17 calls per step).
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const TecmGemm g, int splits) {
+  __shared__ float red[4][64];
   const int64_t total = g.M * g.N;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const tecm_gemm::DropCtx odc = tecm_gemm::make_drop(g.out_drop);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    float v4[4] = {0.f, 0.f, 0.f, 0.f};        // four slabs in flight: a serial chain of `splits` loads is latency-bound
-    for (int s = 0; s < splits; s += 4) {
+  for (int64_t i0 = (int64_t)blockIdx.x * 64; i0 < total; i0 += (int64_t)gridDim.x * 64) {
+    const int64_t i = i0 + lane;
+    float v4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (i < total) {
+      for (int s = wave; s < splits; s += 16) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (s + u < splits) v4[u] += g.workspace[(int64_t)(s + u) * total + i];
+        for (int u = 0; u < 4; ++u)
+          if (s + 4 * u < splits) v4[u] += g.workspace[(int64_t)(s + 4 * u) * total + i];
+      }
     }
-    const float v = (v4[0] + v4[1]) + (v4[2] + v4[3]);
-    const int64_t m = i / g.N;
-    tecm_gemm::epilogue_store(g, odc, m, (int32_t)(i - m * g.N), v);
+    red[wave][lane] = (v4[0] + v4[1]) + (v4[2] + v4[3]);
+    __syncthreads();
+    if (wave == 0 && i < total) {
+      const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+      const int64_t m = i / g.N;
+      tecm_gemm::epilogue_store(g, odc, m, (int32_t)(i - m * g.N), v);
+    }
+    __syncthreads();
   }
 }
 
@@ -128,8 +141,8 @@ static int gemm_entry(const TecmGemm* d, void* stream, bool bf16) {
   if (splits < 0) return splits;
   if (splits > 1) {
     const int64_t total = g.M * g.N;
-    const int64_t want = (total + 255) / 256;
-    const int blocks = (int)(want < 2048 ? want : 2048);
+    const int64_t want = (total + 63) / 64;
+    const int blocks = (int)(want < 4096 ? want : 4096);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, gk, splits);
     TECM_CHECK_LAUNCH("tecm_gemm_f32/splitk_reduce");
   }

@@ -636,12 +636,12 @@ __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ i
     ws[((int64_t)s * gridDim.y + rb) * C + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
-// stage 1, float4 form for 16-byte friendly inputs without dropout: a block owns a chunk of rows and ALL C columns,
+// stage 1, float4 form for 16-byte friendly inputs: a block owns a chunk of rows and ALL C columns,
 // thread = (row slot, column quad), so a wave reads whole 1 KiB runs of consecutive rows instead of 256-byte
 // slivers (narrow matrices -- 24 .. 128 columns -- ran at 0.3 .. 1 TB/s through the lane-per-column kernel).
 __global__ __launch_bounds__(256) void colsum_stage1_v4(const float* __restrict__ in, int64_t ld, int64_t outer,
-                                                        int64_t inner, int nseg, int C, float* __restrict__ ws,
-                                                        int64_t chunk) {
+                                                        int64_t inner, int nseg, int C, DropCtxN idc,
+                                                        float* __restrict__ ws, int64_t chunk) {
   __shared__ float4 red[256];
   const int Q = C >> 2;                       // quads per row (host: Q <= 256)
   const int RPB = 256 / Q;                    // row slots per pass
@@ -664,7 +664,14 @@ __global__ __launch_bounds__(256) void colsum_stage1_v4(const float* __restrict_
             const int64_t o = ri / inner, j = ri - o * inner;
             row = (o * nseg + s) * inner + j;
           }
-          const float4 v = *reinterpret_cast<const float4*>(in + row * ld + 4 * q);
+          float4 v = *reinterpret_cast<const float4*>(in + row * ld + 4 * q);
+          if (idc.thresh) {
+            const uint64_t di = (uint64_t)(row * idc.ld + 4 * q);
+            v.x *= tecm_drop_mult(idc.seed, di, idc.thresh, idc.inv);
+            v.y *= tecm_drop_mult(idc.seed, di + 1, idc.thresh, idc.inv);
+            v.z *= tecm_drop_mult(idc.seed, di + 2, idc.thresh, idc.inv);
+            v.w *= tecm_drop_mult(idc.seed, di + 3, idc.thresh, idc.inv);
+          }
           a[u].x += v.x; a[u].y += v.y; a[u].z += v.z; a[u].w += v.w;
         }
       }
@@ -694,8 +701,15 @@ __global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ w
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane, s = blockIdx.y;
   float acc = 0.f;
-  if (c < C)
-    for (int rb = wave; rb < RB; rb += 4) acc += ws[((int64_t)s * RB + rb) * C + c];
+  if (c < C) {
+    float a4[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int rb = wave; rb < RB; rb += 16) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (rb + 4 * u < RB) a4[u] += ws[((int64_t)s * RB + rb + 4 * u) * C + c];
+    }
+    acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+  }
   red[wave][lane] = acc;
   __syncthreads();
   if (wave == 0 && c < C) {
@@ -901,14 +915,14 @@ extern "C" int tecm_colsum(const float* in, int64_t ld, int64_t outer, int64_t i
   rb = (total + chunk - 1) / chunk;
   hipStream_t st = (hipStream_t)stream;
   const DropCtxN idc = make_dropn(in_drop);
-  if (idc.thresh == 0 && C % 4 == 0 && C <= 1024 && ld % 4 == 0 && tecm_aligned(in, 16) && tecm_aligned(workspace, 16)) {
+  if (C % 4 == 0 && C <= 1024 && ld % 4 == 0 && tecm_aligned(in, 16) && tecm_aligned(workspace, 16)) {
     int64_t rb4 = 1024 / nseg;                          // workspace contract: >= 1024 * nseg * C floats
     if (rb4 > (total + 63) / 64) rb4 = (total + 63) / 64;
     if (rb4 < 1) rb4 = 1;
     const int64_t chunk4 = (total + rb4 - 1) / rb4;
     rb4 = (total + chunk4 - 1) / chunk4;
     hipLaunchKernelGGL(colsum_stage1_v4, dim3((unsigned)rb4, nseg), dim3(256), 0, st, in, ld, outer, inner, nseg, C,
-                       workspace, chunk4);
+                       idc, workspace, chunk4);
     TECM_CHECK_LAUNCH("tecm_colsum/stage1_v4");
     hipLaunchKernelGGL(colsum_stage2, dim3(colblocks, nseg), dim3(256), 0, st, workspace, (int)rb4, nseg, C, out, ldo,
                        accumulate, scale);

@@ -140,7 +140,8 @@ class SpatialFn(torch.autograd.Function):
         dWr = s[o:o + Cc * Cc].view(Cc, Cc); o += Cc * Cc
         dbr = s[o:o + Cc]; o += Cc
         datt = s[o:o + Cc].view_as(att)
-        dbias = colsum(dout, CP, B * L * N, 1, 1, Cc)[0]        # d bias = column sums of dout (out = h + gat + bias)
+        dbias = colsum(dout, CP, B * L * N, 1, 1, CP)[0, :Cc]   # d bias = column sums of dout (out = h + gat + bias);
+        #                                                         all 24 padded columns: the float4 reduction path
         return (None, None, d_node, d_tod, d_doy, d_year, d_season, dWl, dbl, dWr, dbr, datt, dbias,
                 None, None, None, None)
 

@@ -524,7 +524,7 @@ __device__ __forceinline__ void block_epilogue(const TecmGemm& g, f32x16 (&acc)[
   }
 }
 
-template <int ALAY, int BLAY, int AVEC, int BVEC, int BN, bool WIN, bool DROP>
+template <int ALAY, int BLAY, int AVEC, int BVEC, int BN, bool WIN, bool DROP, int BMT = BM>
 __global__ __launch_bounds__(threads_for(BN), (AVEC == 4 && BVEC == 4) ? (threads_for(BN) == 512 ? 4 : 2) : 1) void gemm_kernel(const TecmGemm g,
                                                                                            int tiles_m, int tiles_n,
                                                                                            int k_chunk) {
@@ -532,11 +532,12 @@ __global__ __launch_bounds__(threads_for(BN), (AVEC == 4 && BVEC == 4) ? (thread
   constexpr int NWAVES = NTHREADS / 64;
   constexpr int WN = BN >= 128 ? (NWAVES == 8 ? 4 : 2) : (BN == 64 ? 2 : 1);
   constexpr int WM = NWAVES / WN;
-  constexpr int WTM = BM / WM;
+  constexpr int WTM = BMT / WM;
+  static_assert(WTM >= 32 && WTM % 32 == 0, "wave tile");
   constexpr int WTN = BN / WN;
   constexpr int MT = WTM / 32;
   constexpr int NT = WTN / 32;
-  using AStager = Stager<ALAY == TECM_A_KM, BM, AVEC, WIN, DROP, NTHREADS>;
+  using AStager = Stager<ALAY == TECM_A_KM, BMT, AVEC, WIN, DROP, NTHREADS>;
   using BStager = Stager<BLAY == TECM_B_KN, BN, BVEC, WIN, DROP, NTHREADS>;
   constexpr int A_FLOATS = AStager::R * AStager::LD;
   constexpr int B_FLOATS = BStager::R * BStager::LD;
@@ -563,7 +564,7 @@ __global__ __launch_bounds__(threads_for(BN), (AVEC == 4 && BVEC == 4) ? (thread
   const int gsz = min(tiles_m - first_m, GROUP_M);
   const int in_group = wg - group * per_group;
   const int tm = first_m + in_group % gsz, tn = in_group / gsz;
-  const int64_t m0 = (int64_t)tm * BM;
+  const int64_t m0 = (int64_t)tm * BMT;
   const int64_t n0 = (int64_t)tn * BN;
   const int32_t kbeg = blockIdx.z * k_chunk;
   const int32_t kend = min((int32_t)g.K, kbeg + k_chunk);
@@ -717,15 +718,15 @@ __global__ __launch_bounds__(threads_for(BN), (AVEC == 4 && BVEC == 4) ? (thread
   block_epilogue<MT, NT, WTM, WTN, STG_LD>(g, acc, smem, wave, lane, wm, wn, m0, n0);
 }
 
-template <int ALAY, int BLAY, int AVEC, int BVEC, int BN, bool WIN, bool DROP>
+template <int ALAY, int BLAY, int AVEC, int BVEC, int BN, bool WIN, bool DROP, int BMT = BM>
 int launch(const TecmGemm& g, hipStream_t st) {
-  const int tiles_m = (int)((g.M + BM - 1) / BM);
+  const int tiles_m = (int)((g.M + BMT - 1) / BMT);
   const int tiles_n = (int)((g.N + BN - 1) / BN);
   int splits = g.split_k > 1 ? g.split_k : 1;
   int k_chunk = (int)(((g.K + splits - 1) / splits + BK - 1) / BK) * BK;
   splits = (int)((g.K + k_chunk - 1) / k_chunk);
   dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)splits);
-  hipLaunchKernelGGL((gemm_kernel<ALAY, BLAY, AVEC, BVEC, BN, WIN, DROP>), grid, dim3(threads_for(BN)), 0, st, g, tiles_m,
+  hipLaunchKernelGGL((gemm_kernel<ALAY, BLAY, AVEC, BVEC, BN, WIN, DROP, BMT>), grid, dim3(threads_for(BN)), 0, st, g, tiles_m,
                      tiles_n, k_chunk);
   TECM_CHECK_LAUNCH("tecm_gemm_f32");
   return splits;      // > 0: number of K splits actually launched
@@ -746,6 +747,16 @@ int dispatch(const TecmGemm& g, int avec, int bvec, bool win, bool drop, hipStre
     if (avec == 4 && bvec >= 2) return launch<ALAY, BLAY, 4, 2, BN, true, true>(g, st);
   }
   return launch<ALAY, BLAY, 1, 1, BN, true, true>(g, st);
+}
+
+// M <= 64 (the Conv1d weight gradients of the first block: M = C_out = 64, K = 1.1 M rows): 64-row block tiles,
+// so that half of every MFMA is not spent on clamped rows.  float4 loaders only.
+template <int ALAY, int BLAY, int BN>
+int dispatch_m64(const TecmGemm& g, bool win, bool drop, hipStream_t st) {
+  if (!win && !drop) return launch<ALAY, BLAY, 4, 4, BN, false, false, 64>(g, st);
+  if (win && !drop) return launch<ALAY, BLAY, 4, 4, BN, true, false, 64>(g, st);
+  if (!win && drop) return launch<ALAY, BLAY, 4, 4, BN, false, true, 64>(g, st);
+  return launch<ALAY, BLAY, 4, 4, BN, true, true, 64>(g, st);
 }
 
 }  // namespace tecm_gemm

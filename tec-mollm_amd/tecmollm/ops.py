@@ -156,7 +156,8 @@ def _kernel_name(g: TecmGemm, use16: bool = False) -> str:
     else:
         pair = (4, 2) if (av == 4 and bv >= 2) else (1, 1)
     bn = 32 if g.N <= 32 else (64 if g.N <= 64 else 128)
-    return f"gemm_kernel<{g.a_layout},{g.b_layout},{pair[0]},{pair[1]},{bn}>"
+    m64 = ",BM=64" if (g.a_layout == A_KM and g.M <= 64 and bn > 32 and pair == (4, 4)) else ""
+    return f"gemm_kernel<{g.a_layout},{g.b_layout},{pair[0]},{pair[1]},{bn}{m64}>"
 
 
 def enable_gemm_timing(detail: bool = False) -> list:

@@ -10,6 +10,7 @@ All activations after the spatial stage are time-major (B, T, N, C): row m = (b*
 from __future__ import annotations
 
 from dataclasses import dataclass
+import weakref
 from typing import List, Optional
 
 import torch
@@ -267,6 +268,35 @@ class PatchEmbedFn(torch.autograd.Function):
 
 
 # ============================================================================ stage a-6
+_NK_CACHE: dict = {}
+
+
+def _frozen_nk(W: torch.Tensor) -> Optional[torch.Tensor]:
+    """[N][K] copy of a FROZEN transformers-Conv1D weight W[K][N] (the fp32 MFMA GEMM reads a [row][k] B tile
+    with one ds_read_b128 per fragment, a [k][row] tile with four ds_read_b32: the forward GEMMs run ~5 % faster
+    on the transposed copy, the backward already uses W as it is).  Cached per parameter and refreshed when the
+    tensor is modified through torch (load_state_dict bumps _version).  Trainable weights return None: their
+    storage is updated by the fused optimizer behind torch's version counter."""
+    if W.requires_grad:
+        return None
+    key = id(W)
+    hit = _NK_CACHE.get(key)
+    if hit is not None and hit[0]() is W and hit[1] == W._version and hit[2] == W.data_ptr():
+        return hit[3]
+    if len(_NK_CACHE) > 64:                                  # drop entries whose parameter is gone (ids get reused)
+        for k in [k for k, v in _NK_CACHE.items() if v[0]() is None]:
+            del _NK_CACHE[k]
+    wt = W.detach().t().contiguous()
+    _NK_CACHE[key] = (weakref.ref(W), W._version, W.data_ptr(), wt)
+    return wt
+
+
+def _fwd_weight(W: torch.Tensor, K: int, N: int):
+    """(tensor, ldb, b_layout) for  x[M,K] . W[K,N]  in the forward pass."""
+    wt = _frozen_nk(W)
+    return (wt, K, B_NK) if wt is not None else (W, N, B_KN)
+
+
 class GPT2StackFn(torch.autograd.Function):
     """GPT2Block x n_layers + ln_f with LoRA(r=32) on c_attn (modeling_gpt2.py:262-310, :620;
     peft Linear: modules.py:177-186).  h0 (B, T, N, 768) already holds inputs_embeds + wpe (+ embd dropout).
@@ -290,25 +320,36 @@ class GPT2StackFn(torch.autograd.Function):
             ops.layernorm_fwd(h, D, ln1w, ln1b, u, KE, st1, M, D)
             lspec = plan.spec(site_lora(i), KE)
             gemm(M, LORA_R, D, u, KE, lA, D, u, KE, c_off=D, a_drop=lspec, bf16=plan.bf16)
-            wcat = _empty(KE, F3, like=h)                   # [ W ; (alpha/r) B^T ]  K-extended c_attn
+            wcat = _empty(KE, F3, like=h)                   # [ W ; (alpha/r) B^T ]  K-extended c_attn (backward operand)
             wcat[:D].copy_(Wqkv)
             ops.transpose_scale(lB, LORA_R, wcat, F3, LORA_R, F3, LORA_SCALE, dst_off=D * F3)
             qkv = _empty(M, F3, like=h)
-            gemm(M, F3, KE, u, KE, wcat, F3, qkv, F3, b_layout=B_KN, bias=bqkv, bf16=plan.bf16)
+            WqkvT = _frozen_nk(Wqkv)
+            if WqkvT is not None:                           # forward operand in [N][K] form: [ W^T | (alpha/r) B ]
+                wcatT = _empty(F3, KE, like=h)
+                wcatT[:, :D].copy_(WqkvT)
+                torch.mul(lB.detach(), LORA_SCALE, out=wcatT[:, D:])
+                gemm(M, F3, KE, u, KE, wcatT, KE, qkv, F3, b_layout=B_NK, bias=bqkv, bf16=plan.bf16)
+            else:
+                gemm(M, F3, KE, u, KE, wcat, F3, qkv, F3, b_layout=B_KN, bias=bqkv, bf16=plan.bf16)
             cx = _empty(M, D, like=h)
             aspec = plan.spec(site_attn(i), 1)
             ops.attention_fwd(qkv, cx, B, T, N, GPT_HEADS, D, aspec)
             h2 = _empty(M, D, like=h)
-            gemm(M, D, D, cx, D, Wo, D, h2, D, b_layout=B_KN, bias=bo, out_drop=plan.spec(site_res1(i), D),
+            Wo_f, ldo_f, lay_o = _fwd_weight(Wo, D, D)
+            gemm(M, D, D, cx, D, Wo_f, ldo_f, h2, D, b_layout=lay_o, bias=bo, out_drop=plan.spec(site_res1(i), D),
                  residual=(h, D), bf16=plan.bf16)
             u2 = _empty(M, D, like=h)
             st2 = _empty(M, 2, like=h)
             ops.layernorm_fwd(h2, D, ln2w, ln2b, u2, D, st2, M, D)
             a = _empty(M, F4, like=h)
             f = _empty(M, F4, like=h)
-            gemm(M, F4, D, u2, D, Wfc, F4, f, F4, b_layout=B_KN, bias=bfc, preact=(a, F4), act=ACT_GELU_TANH, bf16=plan.bf16)
+            Wfc_f, ldfc_f, lay_fc = _fwd_weight(Wfc, D, F4)
+            gemm(M, F4, D, u2, D, Wfc_f, ldfc_f, f, F4, b_layout=lay_fc, bias=bfc, preact=(a, F4), act=ACT_GELU_TANH,
+                 bf16=plan.bf16)
             h3 = _empty(M, D, like=h)
-            gemm(M, D, F4, f, F4, Wpr, D, h3, D, b_layout=B_KN, bias=bpr, out_drop=plan.spec(site_res2(i), D),
+            Wpr_f, ldpr_f, lay_pr = _fwd_weight(Wpr, F4, D)
+            gemm(M, D, F4, f, F4, Wpr_f, ldpr_f, h3, D, b_layout=lay_pr, bias=bpr, out_drop=plan.spec(site_res2(i), D),
                  residual=(h2, D), bf16=plan.bf16)
             saved += [h, u, st1, wcat, qkv, cx, h2, st2, u2, a]
             h = h3

@@ -290,3 +290,31 @@ def test_bf16_autocast_selects_bf16_and_full_step_tracks_fp32_oracle(dev):
     named = dict(model.named_parameters())
     worst = max(rel_err(named[k].grad, g) for k, g in grads_ref.items() if g.abs().max() > 0)
     assert worst < 8e-2, worst
+
+
+def test_frozen_weight_transposes_follow_the_parameter(dev):
+    """The forward GEMMs read cached [N][K] copies of the frozen GPT-2 weights: a second model (whose parameters may
+    reuse the ids / addresses of a collected one) and an in-place weight reload must both be picked up."""
+    cfg = R.default_config(L_in=16, L_out=12, num_nodes=6, llm_layers=1)
+    outs = []
+    for seed in (21, 22):
+        p = R.init_params(cfg, seed=seed)
+        x, tf, y = R.synthetic_batch(1, 16, 6, cfg["spatial_in_channels_base"], 12, seed=5)
+        ei, _ = R.grid_graph(2, 3, threshold_km=2000.0)
+        model = build_model(cfg, p, dev, "per_timestep").eval()
+        tfd = tf[:, :, 0, :].contiguous().to(dev).unsqueeze(-2).expand(1, 16, 6, 4)
+        with torch.no_grad():
+            out = model(x.to(dev), tfd, ei.to(dev))
+        ref = R.forward(x, tf, ei, p, cfg, None)
+        assert rel_err(out, ref) < 1e-3
+        outs.append(out)
+        del model
+    # same module object, weights replaced in place (load_state_dict): the cache must refresh
+    p1, p2 = R.init_params(cfg, seed=31), R.init_params(cfg, seed=32)
+    model = build_model(cfg, p1, dev, "per_timestep").eval()
+    with torch.no_grad():
+        a = model(x.to(dev), tfd, ei.to(dev))
+        model.load_state_dict(p2, strict=True)
+        b = model(x.to(dev), tfd, ei.to(dev))
+    assert rel_err(a, R.forward(x, tf, ei, p1, cfg, None)) < 1e-3
+    assert rel_err(b, R.forward(x, tf, ei, p2, cfg, None)) < 1e-3

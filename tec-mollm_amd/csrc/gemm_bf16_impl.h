@@ -76,8 +76,9 @@ struct DStager {
     if (!wen) {
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
-        const int64_t row = row0 + r0 + i * RSTEP;
+        int64_t row = row0 + r0 + i * RSTEP;
         if (row < rows_total) rowok |= 1u << i;
+        else row = rows_total - 1;            // clamped: a valid address; the tile row it feeds is never stored
         ptr[i] = P + row * ld + kbeg + cv;
         if constexpr (DROP) didx[i] = row * dc.ld + kbeg + cv;
       }
@@ -124,6 +125,36 @@ struct DStager {
     }
     (void)k0;
   }
+  // Steady state of the plain view (tile entirely inside [kbeg, kend), rows pre-clamped): no masks, no selects.
+  template <int IB, int IE>
+  __device__ __forceinline__ void load_steady(int64_t /*ld*/, const DropCtx& dc) {
+    if constexpr (IB >= IE) return;
+    if constexpr (IB == 0) okbits = ~0u;
+#pragma unroll
+    for (int i = IB; i < IE; ++i) {
+      gload<4>(ptr[i], ptr[i], true, regs[i]);
+      if constexpr (DROP) { dsave[i] = didx[i]; didx[i] += BK; }
+      ptr[i] += BK;
+    }
+    if constexpr (IE == NV) kk += BK;
+  }
+  template <int IB, int IE>
+  __device__ __forceinline__ void store_steady(__bf16* lds, const DropCtx& dc) {
+    if constexpr (IB >= IE) return;
+    const int cv = (threadIdx.x % VPR) * 4;
+    const int r0 = threadIdx.x / VPR;
+#pragma unroll
+    for (int i = IB; i < IE; ++i) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = regs[i][e];
+      if constexpr (DROP) apply_drop<4>(dc, dsave[i], v);
+      uint2 pk;
+      pk.x = pack_bf16(v[0], v[1]);
+      pk.y = pack_bf16(v[2], v[3]);
+      *reinterpret_cast<uint2*>(lds + (r0 + i * RSTEP) * LDH + cv) = pk;
+    }
+  }
   template <int IB, int IE>
   __device__ __forceinline__ void store_part(__bf16* lds, const DropCtx& dc) {
     if constexpr (IB >= IE) return;
@@ -165,6 +196,7 @@ struct TStager {
     const int kp0 = threadIdx.x / QPR;
     inner = (int32_t)(fixed0 + q4);
     inner_ok = inner < fixed_lim;
+    if (!inner_ok) inner = 0;                 // clamped column quad (valid address, never stored); WIN: tap/c of column 0
     okbits = 0;
     tap = 0;
     c = 0;
@@ -213,6 +245,41 @@ struct TStager {
 #pragma unroll
       for (int e = 0; e < 4; ++e) { regs[i][e] = lo[e]; regs[i][4 + e] = hi[e]; }
       okbits = (okbits & ~(3u << (2 * i))) | ((ok0 ? 1u : 0u) << (2 * i)) | ((ok1 ? 1u : 0u) << (2 * i + 1));
+    }
+  }
+  template <int IB, int IE>
+  __device__ __forceinline__ void load_steady(int64_t ld, const DropCtx& dc) {
+    if constexpr (IB >= IE) return;
+    if constexpr (IB == 0) okbits = ~0u;
+#pragma unroll
+    for (int i = IB; i < IE; ++i) {
+      float lo[4], hi[4];
+      gload<4>(ptr[i], ptr[i], true, lo);
+      gload<4>(ptr[i] + ld, ptr[i], true, hi);
+      if constexpr (DROP) { dsave[i] = didx[i]; dsave_hi[i] = didx[i] + dc.ld; didx[i] += (int64_t)BK * dc.ld; }
+      ptr[i] += (int64_t)BK * ld;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { regs[i][e] = lo[e]; regs[i][4 + e] = hi[e]; }
+    }
+  }
+  template <int IB, int IE>
+  __device__ __forceinline__ void store_steady(__bf16* lds, const DropCtx& dc) {
+    if constexpr (IB >= IE) return;
+    const int q4 = (threadIdx.x % QPR) * 4;
+    const int kp0 = threadIdx.x / QPR;
+#pragma unroll
+    for (int i = IB; i < IE; ++i) {
+      float lo[4], hi[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { lo[e] = regs[i][e]; hi[e] = regs[i][4 + e]; }
+      if constexpr (DROP) {
+        apply_drop<4>(dc, dsave[i], lo);
+        apply_drop<4>(dc, dsave_hi[i], hi);
+      }
+      const int kcol = 2 * (kp0 + i * KSTEP);
+      uint32_t* base = reinterpret_cast<uint32_t*>(lds + q4 * LDH + kcol);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) base[e * (LDH / 2)] = pack_bf16(lo[e], hi[e]);
     }
   }
   template <int IB, int IE>
@@ -322,7 +389,8 @@ __global__ __launch_bounds__(NTH, 2) void gemm_bf16_kernel(const TecmGemm g, int
   __syncthreads();
 
   int cur = 0;
-  for (int32_t k0 = kbeg; k0 < kend; k0 += BK) {
+  auto tile = [&](int32_t k0, auto fullc) {
+    constexpr bool FULL = decltype(fullc)::value;         // K-tiles t+1 and t+2 lie entirely inside [kbeg, kend)
     const __bf16* Ac = smem + cur * TILE_ELEMS;
     const __bf16* Bc = Ac + A_ELEMS;
     __bf16* An = smem + (cur ^ 1) * TILE_ELEMS;
@@ -343,18 +411,29 @@ __global__ __launch_bounds__(NTH, 2) void gemm_bf16_kernel(const TecmGemm g, int
       // a quarter of the staging work per k-step (see gemm_impl.h)
       constexpr int AB = (ANV * s) / 4, AE = (ANV * (s + 1)) / 4;
       constexpr int BB = (BNV * s) / 4, BE = (BNV * (s + 1)) / 4;
-      if (k0 + BK < kend) {
-        a_store(std::integral_constant<int, AB>{}, std::integral_constant<int, AE>{}, An);
-        b_store(std::integral_constant<int, BB>{}, std::integral_constant<int, BE>{}, An + A_ELEMS);
-      }
-      if (k0 + 2 * BK < kend) {
-        sa.template load_part<AB, AE>(g.A, g.a_win, g.lda, k0 + 2 * BK, kend, adc);
-        sb.template load_part<BB, BE>(g.B, g.b_win, g.ldb, k0 + 2 * BK, kend, bdc);
+      if constexpr (FULL && !WIN) {
+        // mask-free staging: the conversion pass is VALU-bound (4 cvt + pack per float4), every select saved counts
+        sa.template store_steady<AB, AE>(An, adc);
+        sb.template store_steady<BB, BE>(An + A_ELEMS, bdc);
+        sa.template load_steady<AB, AE>(g.lda, adc);
+        sb.template load_steady<BB, BE>(g.ldb, bdc);
+      } else {
+        if (FULL || k0 + BK < kend) {
+          a_store(std::integral_constant<int, AB>{}, std::integral_constant<int, AE>{}, An);
+          b_store(std::integral_constant<int, BB>{}, std::integral_constant<int, BE>{}, An + A_ELEMS);
+        }
+        if (FULL || k0 + 2 * BK < kend) {
+          sa.template load_part<AB, AE>(g.A, g.a_win, g.lda, k0 + 2 * BK, kend, adc);
+          sb.template load_part<BB, BE>(g.B, g.b_win, g.ldb, k0 + 2 * BK, kend, bdc);
+        }
       }
     });
     __syncthreads();
     cur ^= 1;
-  }
+  };
+  int32_t k0 = kbeg;
+  for (; k0 + 3 * BK <= kend; k0 += BK) tile(k0, std::true_type{});
+  for (; k0 < kend; k0 += BK) tile(k0, std::false_type{});
 
   // ---- epilogue: identical to the fp32 kernel's, two 32-row slabs per wave through LDS
   const DropCtx odc = make_drop(g.out_drop);

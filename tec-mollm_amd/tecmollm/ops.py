@@ -156,8 +156,14 @@ def _kernel_name(g: TecmGemm, use16: bool = False) -> str:
     else:
         pair = (4, 2) if (av == 4 and bv >= 2) else (1, 1)
     bn = 32 if g.N <= 32 else (64 if g.N <= 64 else 128)
-    m64 = ",BM=64" if (g.a_layout == A_KM and g.M <= 64 and bn > 32 and pair == (4, 4)) else ""
-    return f"gemm_kernel<{g.a_layout},{g.b_layout},{pair[0]},{pair[1]},{bn}{m64}>"
+    m64 = ",64" if (g.a_layout == A_KM and g.M <= 64 and bn > 32 and pair == (4, 4)) else ",128"   # block rows
+    if pair == (4, 4):                      # float4 loaders: one instance per (WIN, DROP); narrower vectors: the general one
+        win = bool(g.a_win.enabled or g.b_win.enabled)
+        drp = bool(g.a_drop.p > 0 or g.b_drop.p > 0)
+    else:
+        win = drp = True
+    flags = f",{'true' if win else 'false'},{'true' if drp else 'false'}"
+    return f"gemm_kernel<{g.a_layout},{g.b_layout},{pair[0]},{pair[1]},{bn}{flags}{m64}>"
 
 
 def enable_gemm_timing(detail: bool = False) -> list:

@@ -18,7 +18,7 @@ def load(d, counter):
         m = re.search(r"(gemm_bf16_kernel|gemm_kernel)<([^>]*)>", name)
         if m:
             a = [x.strip() for x in m.group(2).split(",")]
-            key = f"{m.group(1)}<{','.join(a[:5] if m.group(1) == 'gemm_kernel' else a[:2])}>"
+            key = f"{m.group(1)}<{','.join(a if m.group(1) == 'gemm_kernel' else a[:2])}>"     # exact instantiation
         else:
             key = re.sub(r"\(.*", "", name).split("::")[-1].split("<")[0].replace("void ", "")
         e = agg[key]

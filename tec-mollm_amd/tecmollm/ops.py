@@ -81,6 +81,7 @@ def gemm(M: int, N: int, K: int, A: torch.Tensor, lda: int, B: torch.Tensor, ldb
     if residual is not None:
         g.residual, g.ldr = residual[0].data_ptr(), residual[1]
     g.accumulate = 1 if accumulate else 0
+    g._p1 = GROUP_M
     ws = None
     if split_k > 1:
         ws = torch.empty(split_k * M * N, device=Cout.device, dtype=torch.float32)
@@ -104,6 +105,7 @@ def gemm(M: int, N: int, K: int, A: torch.Tensor, lda: int, B: torch.Tensor, ldb
     _timing.append((name, 2.0 * M * N * K, e0, e1))
 
 
+GROUP_M = 0          # m-tiles per L2 super-tile of the fp32 GEMM (0 = the kernel's default, 8); tools/ sweep it
 BF16_MIN_N = 64
 
 

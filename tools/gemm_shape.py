@@ -8,6 +8,7 @@ from tecmollm import ops
 
 dev = torch.device("cuda")
 BF16 = os.environ.get('BF16', '0') == '1'
+ops.GROUP_M = int(os.environ.get('GROUP_M', '0'))
 for spec in os.environ.get("SHAPES", "16384,2048,16384,kn").split(";"):
     M, N, K, lay = spec.split(",")
     M, N, K = int(M), int(N), int(K)

@@ -525,12 +525,12 @@ __device__ __forceinline__ void block_epilogue(const TecmGemm& g, f32x16 (&acc)[
 }
 
 template <int ALAY, int BLAY, int AVEC, int BVEC, int BN, bool WIN, bool DROP, int BMT = BM>
-__global__ __launch_bounds__(threads_for(BN), (AVEC == 4 && BVEC == 4) ? (threads_for(BN) == 512 ? 4 : 2) : 1) void gemm_kernel(const TecmGemm g,
+__global__ __launch_bounds__(threads_for(BN), (AVEC == 4 && BVEC == 4) ? (threads_for(BN) == 512 ? (BMT > 128 ? 2 : 4) : 2) : 1) void gemm_kernel(const TecmGemm g,
                                                                                            int tiles_m, int tiles_n,
                                                                                            int k_chunk) {
   constexpr int NTHREADS = threads_for(BN);
   constexpr int NWAVES = NTHREADS / 64;
-  constexpr int WN = BN >= 128 ? (NWAVES == 8 ? 4 : 2) : (BN == 64 ? 2 : 1);
+  constexpr int WN = BN >= 128 ? (NWAVES == 8 ? (BMT > 128 ? 2 : 4) : 2) : (BN == 64 ? 2 : 1);
   constexpr int WM = NWAVES / WN;
   constexpr int WTM = BMT / WM;
   static_assert(WTM >= 32 && WTM % 32 == 0, "wave tile");

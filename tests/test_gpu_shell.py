@@ -269,3 +269,47 @@ def test_checkpoint_round_trip_with_wrapper_prefixes(dev, tmp_path):
         if v.dtype.is_floating_point:
             torch.testing.assert_close(v.cpu(), saved[k] + 1.0)
     assert opt.flat_param.data_ptr() == before and opt.params[0].data_ptr() == before      # flat views survive a load
+
+
+# ------------------------------------------------------------------------------------ the reference's DDP wrapper
+def _ddp_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import ref_cpu as R
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        cfg = R.default_config(L_in=16, L_out=12, num_nodes=6, llm_layers=1)
+        model = _model(cfg, 3, dev).eval()                       # eval: dropout off, ranks differ only by their data
+        ddp = torch.nn.parallel.DistributedDataParallel(model)   # train.py:354, default flags
+        x, tf, ei, y = _inputs(cfg, 4, (2, 3), 7, dev)
+        sl = slice(2 * rank, 2 * rank + 2)
+        out_ = ddp(x[sl], tf[sl], ei, None)
+        torch.nn.functional.huber_loss(out_, y[sl]).backward()
+        torch.cuda.synchronize()
+        out[rank] = {k: p.grad.detach().cpu() for k, p in model.named_parameters() if p.requires_grad}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_model_trains_under_the_reference_ddp_wrapper(dev):
+    """nn.parallel.DistributedDataParallel(model) as train.py:354 builds it (two ranks share this GPU over gloo):
+    every trainable parameter receives a gradient through the autograd hooks and the averaged gradients equal the
+    single-process gradients of the concatenated batch."""
+    import socket
+    import torch.multiprocessing as mp
+    from oracle import ref_cpu as R
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_ddp_worker, args=(2, port, out), nprocs=2, join=True)
+    cfg = R.default_config(L_in=16, L_out=12, num_nodes=6, llm_layers=1)
+    model = _model(cfg, 3, dev).eval()
+    x, tf, ei, y = _inputs(cfg, 4, (2, 3), 7, dev)
+    torch.nn.functional.huber_loss(model(x, tf, ei, None), y).backward()
+    want = {k: p.grad.detach().cpu() for k, p in model.named_parameters() if p.requires_grad}
+    assert set(out[0]) == set(want) and len(want) > 20
+    for k, g in want.items():
+        assert torch.equal(out[0][k], out[1][k]), k                 # DDP left both ranks with the same averaged grads
+        torch.testing.assert_close(out[0][k], g, rtol=2e-4, atol=1e-6, msg=k)

@@ -313,3 +313,32 @@ def test_model_trains_under_the_reference_ddp_wrapper(dev):
     for k, g in want.items():
         assert torch.equal(out[0][k], out[1][k]), k                 # DDP left both ranks with the same averaged grads
         torch.testing.assert_close(out[0][k], g, rtol=2e-4, atol=1e-6, msg=k)
+
+
+# ------------------------------------------------------------------------------------ epoch loops
+def test_epoch_loops_train_and_validate_on_a_learnable_series(dev):
+    """train_one_epoch / validate (train.py:52-168) over the device dataset: a smooth synthetic series is learnable,
+    so a few epochs must lower the validation loss; metrics come back with the reference's keys."""
+    from oracle import ref_cpu as R
+    from src.data.dataset import SlidingWindowSamplerDataset
+    from tecmollm.loop import train_one_epoch, validate
+    from tecmollm.train import TrainStep
+    cfg = R.default_config(L_in=16, L_out=12, num_nodes=12, llm_layers=1)
+    T, H, W, C = 120, 3, 4, cfg["spatial_in_channels_base"]
+    t = torch.arange(T, dtype=torch.float32)
+    base = torch.sin(2 * torch.pi * t / 24)[:, None, None] * (1 + 0.1 * torch.arange(H * W).view(H, W))
+    X = base[..., None].repeat(1, 1, 1, C) + 0.01 * torch.randn(T, H, W, C, generator=torch.Generator().manual_seed(0))
+    Y = torch.stack([torch.roll(base, -k - 1, 0) for k in range(12)], -1)          # the next 12 steps
+    TF = torch.stack([t % 12, t % 366, torch.zeros(T), (t // 30) % 4], 1)
+    ds = SlidingWindowSamplerDataset.from_tensors(X, Y, TF, 16, 12, device=dev)
+    model = _model(cfg, 5, dev)
+    ei = R.grid_graph(3, 4)[0].to(dev)
+    ts = TrainStep(model, lr=2e-3, accumulation_steps=2)
+    v0, m0 = validate(model, ds, ei, 16, scaler=(20.0, 8.0))
+    losses = [train_one_epoch(ts, ds, ei, 16, order=torch.randperm(len(ds), generator=torch.Generator().manual_seed(e)).tolist())
+              for e in range(4)]
+    v1, m1 = validate(model, ds, ei, 16, scaler=(20.0, 8.0))
+    assert v1 < 0.7 * v0 and losses[-1] < losses[0]
+    assert set(m1) == {"mae_avg", "rmse_avg", "r2_score_avg", "pearson_r_avg", "mae_by_horizon", "rmse_by_horizon",
+                       "r2_by_horizon", "pearson_by_horizon"} and len(m1["rmse_by_horizon"]) == 12
+    assert m1["rmse_avg"] < m0["rmse_avg"]

@@ -73,23 +73,42 @@ class FlatAdamW:
         self._partials = torch.empty(_lib.TECM_NORM_BLOCKS, device=dev, dtype=torch.float64)
         self.total_norm = torch.zeros(1, device=dev, dtype=torch.float32)
         o = 0
+        self.grad_views: List[torch.Tensor] = []
         with torch.no_grad():
             for p, k in zip(self.params, self.sizes):
                 self.flat_param[o:o + k].copy_(p.detach().reshape(-1))
                 p.data = self.flat_param[o:o + k].view(p.shape)
-                p.grad = self.flat_grad[o:o + k].view(p.shape)
+                self.grad_views.append(self.flat_grad[o:o + k].view(p.shape))
+                p.grad = self.grad_views[-1]
                 o += k
         self.step_count = 0
+
+    def detach_grads(self) -> None:
+        """Set every p.grad to None so that the next backward hands its gradient tensors over (autograd's
+        AccumulateGrad then stores them instead of launching one `p.grad += g` kernel per parameter);
+        `absorb_grads` adds them into the flat buffer with one multi-tensor launch."""
+        for p in self.params:
+            p.grad = None
+
+    def absorb_grads(self) -> None:
+        """flat_grad += every p.grad that does not already live in the flat buffer; those are released (set to None)."""
+        dst, src = [], []
+        for p, v in zip(self.params, self.grad_views):
+            g = p.grad
+            if g is None or g.data_ptr() == v.data_ptr():
+                continue
+            if g.shape != v.shape or g.dtype != torch.float32 or g.device != v.device:
+                raise TecmError("a parameter's .grad has the wrong shape / dtype / device")
+            dst.append(v)
+            src.append(g)
+            p.grad = None
+        if dst:
+            torch._foreach_add_(dst, src)
 
     def step(self, lr: float = None, max_norm: float = 1.0, grad_scale: float = 1.0, zero_grad: bool = True) -> torch.Tensor:
         """clip_grad_norm_(max_norm) on grad*grad_scale, AdamW update, optional zero_grad.  Returns the
         (device, un-synced) total gradient norm before clipping."""
-        o = 0
-        for p, k in zip(self.params, self.sizes):     # somebody replaced .grad (e.g. zero_grad(set_to_none=True))
-            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
-                raise TecmError("a parameter's .grad no longer aliases the flat gradient buffer; "
-                                "use FlatAdamW.zero_grad() instead of set_to_none")
-            o += k
+        self.absorb_grads()                           # gradients autograd stored outside the flat buffer
         self.step_count += 1
         a = TecmAdamW(n=self.n, param=self.flat_param.data_ptr(), grad=self.flat_grad.data_ptr(),
                       exp_avg=self.exp_avg.data_ptr(), exp_avg_sq=self.exp_avg_sq.data_ptr(),

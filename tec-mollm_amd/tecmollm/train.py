@@ -91,9 +91,13 @@ class TrainStep:
 
     def step(self, x, time_features, edge_index, edge_weight, y) -> torch.Tensor:
         """One micro-batch; the optimizer fires every `accumulation_steps` calls.  Returns the (device) loss."""
+        if self.native:
+            self.optimizer.detach_grads()              # backward hands its gradient tensors over; one add for all of them
         out = self.model(x, time_features, edge_index, edge_weight)
         loss = self._loss(out, y)
         (loss / self.accumulation_steps).backward()
+        if self.native:
+            self.optimizer.absorb_grads()
         self._micro += 1
         if self._micro % self.accumulation_steps == 0:
             self.finish_accumulation()

@@ -108,16 +108,16 @@ def test_flat_adamw_state_dict_round_trips_through_torch_adamw(dev):
         torch.testing.assert_close(p.detach(), tp.detach(), rtol=2e-6, atol=1e-8)
 
 
-def test_optimizer_rejects_cpu_parameters_and_replaced_grads(dev):
+def test_optimizer_rejects_cpu_parameters_and_absorbs_foreign_grads(dev):
     from tecmollm import TecmError
     from tecmollm.optim import FlatAdamW
     with pytest.raises(TecmError):
         FlatAdamW([torch.nn.Parameter(torch.zeros(4))])
     p = torch.nn.Parameter(torch.zeros(8, device=dev))
     opt = FlatAdamW([p])
-    p.grad = torch.ones(8, device=dev)
-    with pytest.raises(TecmError):
-        opt.step()
+    p.grad = torch.ones(8, device=dev)                      # a gradient stored outside the flat buffer is absorbed
+    opt.step(max_norm=0.0, zero_grad=False)
+    assert p.grad is None and float(opt.flat_grad.sum()) == 8.0
 
 
 def test_train_step_native_equals_torch_optimizer_path(dev):

@@ -318,3 +318,37 @@ def test_frozen_weight_transposes_follow_the_parameter(dev):
         b = model(x.to(dev), tfd, ei.to(dev))
     assert rel_err(a, R.forward(x, tf, ei, p1, cfg, None)) < 1e-3
     assert rel_err(b, R.forward(x, tf, ei, p2, cfg, None)) < 1e-3
+
+
+def test_full_size_batch_of_8_properties(dev):
+    """BASELINE configs[1] size (B=8, L_in=48, N=2911, F=10) through properties that need no oracle run:
+    samples are independent (row b of the batch == the same sample run alone, bit for bit: no kernel mixes rows of
+    different samples and none of the forward kernels uses atomics), the batch order is irrelevant, eval forward
+    is deterministic, and the train-mode dropout masks are a pure function of (torch seed, forward-call count, position)."""
+    cfg = R.default_config(L_in=48, L_out=12, num_nodes=2911, c_in=10, d_emb=12)
+    p = R.init_params(cfg, seed=4)
+    model = build_model(cfg, p, dev, "per_timestep").eval()
+    x, tf, _ = R.synthetic_batch(8, 48, 2911, 10, 12, seed=77)
+    ei = R.grid_graph()[0].to(dev)
+    xd = x.to(dev)
+    tfd = tf[:, :, 0, :].contiguous().to(dev).unsqueeze(-2).expand(8, 48, 2911, 4)
+    with torch.no_grad():
+        full = model(xd, tfd, ei)
+        again = model(xd, tfd, ei)
+        assert full.shape == (8, 12, 2911, 1) and torch.isfinite(full).all()
+        assert torch.equal(full, again)                                   # deterministic
+        for b in (0, 3, 7):
+            alone = model(xd[b:b + 1], tfd[b:b + 1], ei)
+            assert torch.equal(alone[0], full[b]), b                      # sample independence, bit-exact
+        perm = torch.tensor([5, 2, 7, 0, 1, 6, 3, 4], device=dev)
+        shuffled = model(xd[perm], tfd[perm], ei)
+        assert torch.equal(shuffled, full[perm])                          # batch-order equivariance
+    from src.model import modules as M_
+    model.train()
+
+    def run(seed, call):
+        torch.manual_seed(seed)
+        M_._seed_counter[0] = call                                        # mask seed = f(torch seed, forward-call count)
+        return model(xd[:2], tfd[:2], ei)
+    a, b_, c, d_ = run(11, 0), run(11, 0), run(12, 0), run(11, 1)
+    assert torch.equal(a, b_) and not torch.equal(a, c) and not torch.equal(a, d_)

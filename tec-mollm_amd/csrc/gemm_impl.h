@@ -150,9 +150,13 @@ struct Stager {
   static constexpr int RSTEP = NTHREADS / VPR;
   static_assert((R * VPR) % NTHREADS == 0 && NTHREADS % VPR == 0, "tile/thread mapping");
 
-  float regs[NV][VEC];
-  uint32_t okbits;                        // bit i: vector i of the tile held in regs is in range (else stored as 0)
-  int64_t dsave[DROP ? NV : 1];           // dropout index of vector i of the tile held in regs
+  // One K-tile's worth of this thread's vectors in flight.  Kept apart from the address state so that the prologue
+  // can have K-tiles 0 and 1 in flight at the same time (two Tiles, one round trip instead of two).
+  struct Tile {
+    float regs[NV][VEC];
+    uint32_t okbits = 0;                  // bit i: vector i is in range (else stored as 0)
+    int64_t dsave[DROP ? NV : 1];         // dropout index of vector i
+  };
   // --- plain view state
   const float* ptr[NV];                   // address of this thread's vector i in the NEXT tile to load
   uint32_t rowok;                         // bit i: fixed row i in range (ROWK=false) / unused
@@ -169,7 +173,6 @@ struct Stager {
     const int cv = (threadIdx.x % VPR) * VEC;
     const int r0 = threadIdx.x / VPR;
     rowok = 0;
-    okbits = 0;
     inner_ok = true;
     tap = 0;
     c = 0;
@@ -212,12 +215,12 @@ struct Stager {
 
   // Load this thread's vectors [IB, IE) of the tile starting at k0; the call that covers the last vector
   // (IE == NV) advances the per-tile state.  load() = all vectors.
-  __device__ __forceinline__ void load(const float* __restrict__ P, const TecmWin& w, int64_t ld, int32_t k0,
+  __device__ __forceinline__ void load(Tile& tl, const float* __restrict__ P, const TecmWin& w, int64_t ld, int32_t k0,
                                        int32_t klim, const DropCtx& dc) {
-    load_part<0, NV>(P, w, ld, k0, klim, dc);
+    load_part<0, NV>(tl, P, w, ld, k0, klim, dc);
   }
   template <int IB, int IE>
-  __device__ __forceinline__ void load_part(const float* __restrict__ P, const TecmWin& w, int64_t ld, int32_t k0,
+  __device__ __forceinline__ void load_part(Tile& tl, const float* __restrict__ P, const TecmWin& w, int64_t ld, int32_t k0,
                                             int32_t klim, const DropCtx& dc) {
     if constexpr (IB >= IE) return;
     const int r0 = threadIdx.x / VPR;
@@ -229,9 +232,9 @@ struct Stager {
 #pragma unroll
         for (int i = IB; i < IE; ++i) {
           const bool ok = kok && ((rowok >> i) & 1u);
-          gload<VEC>(ptr[i], P, ok, regs[i]);
-          okbits = (okbits & ~(1u << i)) | ((ok ? 1u : 0u) << i);
-          if constexpr (DROP) { dsave[i] = didx[i]; didx[i] += BK; }
+          gload<VEC>(ptr[i], P, ok, tl.regs[i]);
+          tl.okbits = (tl.okbits & ~(1u << i)) | ((ok ? 1u : 0u) << i);
+          if constexpr (DROP) { tl.dsave[i] = didx[i]; didx[i] += BK; }
           ptr[i] += BK;
         }
         if constexpr (LAST) kk += BK;
@@ -239,9 +242,9 @@ struct Stager {
 #pragma unroll
         for (int i = IB; i < IE; ++i) {
           const bool ok = inner_ok && (k0 + r0 + i * RSTEP) < klim;
-          gload<VEC>(ptr[i], P, ok, regs[i]);
-          okbits = (okbits & ~(1u << i)) | ((ok ? 1u : 0u) << i);
-          if constexpr (DROP) { dsave[i] = didx[i]; didx[i] += (int64_t)BK * dc.ld; }
+          gload<VEC>(ptr[i], P, ok, tl.regs[i]);
+          tl.okbits = (tl.okbits & ~(1u << i)) | ((ok ? 1u : 0u) << i);
+          if constexpr (DROP) { tl.dsave[i] = didx[i]; didx[i] += (int64_t)BK * dc.ld; }
           ptr[i] += (int64_t)BK * ld;
         }
       }
@@ -254,9 +257,9 @@ struct Stager {
           const int32_t t_in = wr[i].t0 + tap;            // INVALID + tap stays hugely negative
           const bool ok = kok && t_in >= 0 && t_in < w.Lin;
           const int64_t row = wr[i].srow + tapoff;
-          gload<VEC>(P + row * ld + c, P, ok, regs[i]);
-          okbits = (okbits & ~(1u << i)) | ((ok ? 1u : 0u) << i);
-          if constexpr (DROP) dsave[i] = row * dc.ld + c;
+          gload<VEC>(P + row * ld + c, P, ok, tl.regs[i]);
+          tl.okbits = (tl.okbits & ~(1u << i)) | ((ok ? 1u : 0u) << i);
+          if constexpr (DROP) tl.dsave[i] = row * dc.ld + c;
         }
         if constexpr (LAST) {
           kk += BK;
@@ -270,9 +273,9 @@ struct Stager {
           const int32_t t_in = rr.t0 + tap;
           const bool ok = inner_ok && t_in >= 0 && t_in < w.Lin;
           const int64_t row = rr.srow + (int64_t)tap * w.N;
-          gload<VEC>(P + row * ld + c, P, ok, regs[i]);
-          okbits = (okbits & ~(1u << i)) | ((ok ? 1u : 0u) << i);
-          if constexpr (DROP) dsave[i] = row * dc.ld + c;
+          gload<VEC>(P + row * ld + c, P, ok, tl.regs[i]);
+          tl.okbits = (tl.okbits & ~(1u << i)) | ((ok ? 1u : 0u) << i);
+          if constexpr (DROP) tl.dsave[i] = row * dc.ld + c;
         }
       }
     }
@@ -281,22 +284,22 @@ struct Stager {
   // Steady state of the plain view (every k of the tile in range, rows/columns pre-clamped in init): no masks,
   // no selects -- one global load and one 64-bit pointer bump per vector.  Out-of-range rows/columns carry
   // clamped (finite or not, irrelevant) data into accumulator rows/columns that the epilogue never stores.
-  __device__ __forceinline__ void load_steady(int64_t ld, const DropCtx& dc) {
-    okbits = ~0u;
+  __device__ __forceinline__ void load_steady(Tile& tl, int64_t ld, const DropCtx& dc) {
+    tl.okbits = ~0u;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      gload<VEC>(ptr[i], ptr[i], true, regs[i]);
+      gload<VEC>(ptr[i], ptr[i], true, tl.regs[i]);
       if constexpr (!ROWK) {
-        if constexpr (DROP) { dsave[i] = didx[i]; didx[i] += BK; }
+        if constexpr (DROP) { tl.dsave[i] = didx[i]; didx[i] += BK; }
         ptr[i] += BK;
       } else {
-        if constexpr (DROP) { dsave[i] = didx[i]; didx[i] += (int64_t)BK * dc.ld; }
+        if constexpr (DROP) { tl.dsave[i] = didx[i]; didx[i] += (int64_t)BK * dc.ld; }
         ptr[i] += (int64_t)BK * ld;
       }
     }
     if constexpr (!ROWK) kk += BK;
   }
-  __device__ __forceinline__ void store_steady(float* lds, const DropCtx& dc) {
+  __device__ __forceinline__ void store_steady(const Tile& tl, float* lds, const DropCtx& dc) {
     const int cv = (threadIdx.x % VPR) * VEC;
     const int r0 = threadIdx.x / VPR;
 #pragma unroll
@@ -304,28 +307,28 @@ struct Stager {
       if constexpr (DROP) {
         float v[VEC];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) v[e] = regs[i][e];
-        apply_drop<VEC>(dc, dsave[i], v);
+        for (int e = 0; e < VEC; ++e) v[e] = tl.regs[i][e];
+        apply_drop<VEC>(dc, tl.dsave[i], v);
         lds_store<VEC>(lds + (r0 + i * RSTEP) * LD + cv, v);
       } else {
-        lds_store<VEC>(lds + (r0 + i * RSTEP) * LD + cv, regs[i]);
+        lds_store<VEC>(lds + (r0 + i * RSTEP) * LD + cv, tl.regs[i]);
       }
     }
   }
 
-  __device__ __forceinline__ void store(float* lds, const DropCtx& dc) { store_part<0, NV>(lds, dc); }
+  __device__ __forceinline__ void store(const Tile& tl, float* lds, const DropCtx& dc) { store_part<0, NV>(tl, lds, dc); }
   template <int IB, int IE>
-  __device__ __forceinline__ void store_part(float* lds, const DropCtx& dc) {
+  __device__ __forceinline__ void store_part(const Tile& tl, float* lds, const DropCtx& dc) {
     if constexpr (IB >= IE) return;
     const int cv = (threadIdx.x % VPR) * VEC;
     const int r0 = threadIdx.x / VPR;
 #pragma unroll
     for (int i = IB; i < IE; ++i) {
       float v[VEC];
-      const bool ok = (okbits >> i) & 1u;
+      const bool ok = (tl.okbits >> i) & 1u;
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) v[e] = ok ? regs[i][e] : 0.f;
-      if constexpr (DROP) apply_drop<VEC>(dc, dsave[i], v);
+      for (int e = 0; e < VEC; ++e) v[e] = ok ? tl.regs[i][e] : 0.f;
+      if constexpr (DROP) apply_drop<VEC>(dc, tl.dsave[i], v);
       lds_store<VEC>(lds + (r0 + i * RSTEP) * LD + cv, v);
     }
   }
@@ -577,6 +580,8 @@ __global__ __launch_bounds__(threads_for(BN), (AVEC == 4 && BVEC == 4) ? (thread
 
   AStager sa;
   BStager sb;
+  typename AStager::Tile ta;              // the K-tile in flight (main loop); the prologue adds a second pair
+  typename BStager::Tile tb;
   sa.init(g.A, g.a_win, g.lda, m0, g.M, kbeg, m0, g.M, adc);
   sb.init(g.B, g.b_win, g.ldb, n0, g.N, kbeg, n0, g.N, bdc);
 
@@ -624,14 +629,20 @@ __global__ __launch_bounds__(threads_for(BN), (AVEC == 4 && BVEC == 4) ? (thread
           acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][j], bf[jn][j], acc[i][jn], 0, 0, 0);
   };
 
-  // prologue: tile 0 -> LDS buffer 0, tile 1 -> registers (in flight)
-  sa.load(g.A, g.a_win, g.lda, kbeg, kend, adc);
-  sb.load(g.B, g.b_win, g.ldb, kbeg, kend, bdc);
-  sa.store(smem, adc);
-  sb.store(smem + A_FLOATS, bdc);
-  if (kbeg + BK < kend) {
-    sa.load(g.A, g.a_win, g.lda, kbeg + BK, kend, adc);
-    sb.load(g.B, g.b_win, g.ldb, kbeg + BK, kend, bdc);
+  // prologue: K-tiles 0 and 1 go out together (the accumulators are not live yet, so the second register set is
+  // free): one exposed global round trip per output tile instead of two.  Tile 0 -> LDS buffer 0, tile 1 stays
+  // in flight in (ta, tb).
+  {
+    typename AStager::Tile ta0;
+    typename BStager::Tile tb0;
+    sa.load(ta0, g.A, g.a_win, g.lda, kbeg, kend, adc);
+    sb.load(tb0, g.B, g.b_win, g.ldb, kbeg, kend, bdc);
+    if (kbeg + BK < kend) {
+      sa.load(ta, g.A, g.a_win, g.lda, kbeg + BK, kend, adc);
+      sb.load(tb, g.B, g.b_win, g.ldb, kbeg + BK, kend, bdc);
+    }
+    sa.store(ta0, smem, adc);
+    sb.store(tb0, smem + A_FLOATS, bdc);
   }
   __syncthreads();
 
@@ -659,23 +670,23 @@ __global__ __launch_bounds__(threads_for(BN), (AVEC == 4 && BVEC == 4) ? (thread
         if (FULL || k0 + BK < kend) {
           if constexpr (TECM_ABLATE == 3 && FULL) {
 #pragma unroll
-            for (int i = 0; i < ANV; ++i) asm volatile("" ::"v"(sa.regs[i][0]), "v"(sa.regs[i][1]), "v"(sa.regs[i][2]), "v"(sa.regs[i][3]));
+            for (int i = 0; i < ANV; ++i) asm volatile("" ::"v"(ta.regs[i][0]), "v"(ta.regs[i][1]), "v"(ta.regs[i][2]), "v"(ta.regs[i][3]));
 #pragma unroll
-            for (int i = 0; i < BNV; ++i) asm volatile("" ::"v"(sb.regs[i][0]), "v"(sb.regs[i][1]), "v"(sb.regs[i][2]), "v"(sb.regs[i][3]));
+            for (int i = 0; i < BNV; ++i) asm volatile("" ::"v"(tb.regs[i][0]), "v"(tb.regs[i][1]), "v"(tb.regs[i][2]), "v"(tb.regs[i][3]));
           } else if constexpr (FULL && !WIN) {
-            sa.store_steady(An, adc);
-            sb.store_steady(An + A_FLOATS, bdc);
+            sa.store_steady(ta, An, adc);
+            sb.store_steady(tb, An + A_FLOATS, bdc);
           } else {
-            sa.store(An, adc);
-            sb.store(An + A_FLOATS, bdc);
+            sa.store(ta, An, adc);
+            sb.store(tb, An + A_FLOATS, bdc);
           }
         }
         if constexpr (FULL && !WIN && TECM_ABLATE != 4) {
-          sa.load_steady(g.lda, adc);
-          sb.load_steady(g.ldb, bdc);
+          sa.load_steady(ta, g.lda, adc);
+          sb.load_steady(tb, g.ldb, bdc);
         } else if ((FULL && TECM_ABLATE != 4) || (!FULL && k0 + 2 * BK < kend)) {
-          sa.load(g.A, g.a_win, g.lda, k0 + 2 * BK, kend, adc);
-          sb.load(g.B, g.b_win, g.ldb, k0 + 2 * BK, kend, bdc);
+          sa.load(ta, g.A, g.a_win, g.lda, k0 + 2 * BK, kend, adc);
+          sb.load(tb, g.B, g.b_win, g.ldb, k0 + 2 * BK, kend, bdc);
         }
       }
       if constexpr (FULL && !WIN && !DROP && AVEC == 4 && BVEC == 4) {

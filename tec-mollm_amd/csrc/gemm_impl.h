@@ -6,21 +6,25 @@
 // operands are addressed through "row views" so that Conv1d-over-time, the strided 1x1 conv,
 // latent patching and the head's flatten never materialise an im2col / permuted copy.
 //
-// Block = 256 threads = 4 waves, tile BM x BN x BK = 128 x {128,32} x 32.
-//   BN=128: waves 2(m) x 2(n), each wave 64x64 = 2x2 MFMA 32x32 tiles (64 accumulator VGPRs)
-//   BN= 32: waves 4(m) x 1(n), each wave 32x32
+// Tile BM x BN x BK = 128 x {128, 64, 32} x 32 (64 x BN for the M <= 64 weight-gradient GEMMs).
+//   BN = 128: 512 threads = 8 waves as 2(m) x 4(n), each wave 64 x 32 = two 32x32 MFMA tiles (32 accumulator VGPRs),
+//             108 VGPRs, 72 KiB of LDS -> two blocks (16 waves) per CU
+//   BN <= 64: 256 threads = 4 waves
 // LDS tiles keep the operand's own orientation:
 //   [row][k] tiles (MK / NK): leading dim 36 floats -> ds_read_b128 of 4 consecutive k is
 //       conflict-free (16 lanes x 4 banks, row stride 36 = 4 mod 32 hits 16 distinct slots);
 //   [k][row] tiles (KM / KN): leading dim rows+4 -> ds_read_b32, lanes 0..31 consecutive banks.
 // The k index fed to MFMA step (q,j) by lane half h is k = 8q + 4h + j for BOTH operands, which is
 // what makes the b128 read legal (any bijection of k works as long as A and B agree).
-// Global -> register prefetch of tile t+1 is issued before the MFMAs of tile t (one LDS buffer).
+// Pipeline: two LDS buffers, one barrier per K-tile; K-tile t+1 is parked in the idle buffer and t+2 fetched
+// into registers while the MFMAs of tile t run (the prologue sends K-tiles 0 and 1 out together).
 //
 // The f32 MFMA is slow enough (64 cycles per 32x32x2) that the loop is MFMA-bound only if the loader
 // costs a few dozen VALU instructions per K-tile: all per-row address state is resolved before the
 // K loop and advanced incrementally; the window view and the dropout prologue are compile-time
-// variants (WIN / DROP) so the plain variant carries none of their code.
+// variants (WIN / DROP) so the plain variant carries none of their code, and in its steady state the plain
+// variant stages with no masks at all (rows / columns pre-clamped, see Stager::load_steady).
+// Measured limits and the experiments that did not pay: DESIGN.md section 4, tools/experiments/.
 #pragma once
 #include "common.h"
 #ifndef TECM_BIG_THREADS

@@ -98,6 +98,11 @@ int tecm_gemm_f32(const TecmGemm* desc, void* stream);
  * staged into LDS, accumulation / epilogue / outputs stay fp32 -- what torch.autocast(bf16) does to the inputs
  * of Linear / Conv1d / Conv1D (train.py:68).  Operands must be 16-byte friendly (else TECM_E_ALIGN). */
 int tecm_gemm_bf16(const TecmGemm* desc, void* stream);
+/* "bf16x3": fp32 tensors, every factor split into a bf16 head and a bf16 remainder while it is staged, each product
+ * evaluated as lo.hi + hi.lo + hi.hi on the bf16 matrix cores with fp32 accumulation (~16 mantissa bits per factor,
+ * dot-product relative error ~1e-5; the bf16 MFMA runs at 16x the exact-f32 MFMA rate on gfx950).  Opt-in
+ * (model_config["precision"] = "bf16x3"); serves the plain MK x NK contraction only, TECM_E_ARG otherwise. */
+int tecm_gemm_bf16x3(const TecmGemm* g, void* stream);
 
 /* ------------------------------------------------------------------ stage a-1..a-3 (fused)
  * SpatioTemporalEmbedding.forward (modules.py:230-266) + GATv2Conv (modules.py:329-336,:356)

@@ -1,6 +1,7 @@
 // extern "C" entry point of the fp32 MFMA GEMM (kernel template: gemm_impl.h; instantiations:
 // gemm_mk_nk.hip, gemm_mk_kn.hip, gemm_km_kn.hip -- one translation unit per operand-layout pair).
 #include "gemm_bf16_impl.h"
+int tecm_gemm_x3_dispatch(const TecmGemm& g, hipStream_t st);      // gemm_x3.hip
 
 namespace {
 
@@ -68,16 +69,24 @@ bool win_ok(const TecmWin& w) {
 
 }  // namespace
 
-static int gemm_entry(const TecmGemm* d, void* stream, bool bf16);
+enum { MODE_F32 = 0, MODE_BF16 = 1, MODE_X3 = 2 };
+static int gemm_entry(const TecmGemm* d, void* stream, int mode);
 
-extern "C" int tecm_gemm_f32(const TecmGemm* d, void* stream) { return gemm_entry(d, stream, false); }
+extern "C" int tecm_gemm_f32(const TecmGemm* d, void* stream) { return gemm_entry(d, stream, MODE_F32); }
 
 // Same contract as tecm_gemm_f32, operands rounded to bf16 on the way into LDS, fp32 accumulate / epilogue /
 // outputs.  Needs 16-byte friendly operands (the float4 loader); returns TECM_E_ALIGN otherwise so that the
 // caller can decide to use tecm_gemm_f32 for that call.
-extern "C" int tecm_gemm_bf16(const TecmGemm* d, void* stream) { return gemm_entry(d, stream, true); }
+extern "C" int tecm_gemm_bf16(const TecmGemm* d, void* stream) { return gemm_entry(d, stream, MODE_BF16); }
 
-static int gemm_entry(const TecmGemm* d, void* stream, bool bf16) {
+// Same contract again, every product evaluated as three bf16 matrix-core products of the hi/lo bf16 split of its
+// fp32 factors (gemm_x3_impl.h): ~1e-5 relative error at 3/16 of the exact kernel's matrix-core time.  Serves the
+// plain MK x NK contraction only (no a_win / b_win, no a_drop / b_drop, 16-byte friendly operands); anything else
+// returns TECM_E_ARG so that the caller runs tecm_gemm_f32 for that call.
+extern "C" int tecm_gemm_bf16x3(const TecmGemm* d, void* stream) { return gemm_entry(d, stream, MODE_X3); }
+
+static int gemm_entry(const TecmGemm* d, void* stream, int mode) {
+  const bool bf16 = mode == MODE_BF16;
   TECM_REQUIRE(d != nullptr, TECM_E_ARG, "tecm_gemm_f32: null descriptor");
   const TecmGemm& g = *d;
   TECM_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, TECM_E_ARG, "tecm_gemm_f32: M,N,K must be positive (%lld,%lld,%lld)",
@@ -114,6 +123,12 @@ static int gemm_entry(const TecmGemm* d, void* stream, bool bf16) {
   if (bf16)
     TECM_REQUIRE(avec == 4 && bvec == 4, TECM_E_ALIGN,
                  "tecm_gemm_bf16: operands must be 16-byte aligned with leading dims / K / Cw multiples of 4");
+  if (mode == MODE_X3) {
+    TECM_REQUIRE(g.a_layout == TECM_A_MK && g.b_layout == TECM_B_NK && !win && !drop, TECM_E_ARG,
+                 "tecm_gemm_bf16x3: serves the plain MK x NK contraction only (no operand windows / prologue dropout)");
+    TECM_REQUIRE(avec == 4 && bvec == 4, TECM_E_ALIGN,
+                 "tecm_gemm_bf16x3: operands must be 16-byte aligned with leading dims / K multiples of 4");
+  }
   TecmGemm gk = g;                 // private copy: _p0 carries the epilogue-vectorisation flag to the kernel
   gk._p0 = vec4 ? 1 : 0;
   const bool erf = g.act == TECM_ACT_GELU_ERF;
@@ -125,7 +140,9 @@ static int gemm_entry(const TecmGemm* d, void* stream, bool bf16) {
     gk.out_drop.p = 0.f;
   }
   int splits;
-  if (bf16) {
+  if (mode == MODE_X3) {
+    splits = tecm_gemm_x3_dispatch(gk, st);
+  } else if (bf16) {
     if (g.a_layout == TECM_A_MK && g.b_layout == TECM_B_NK)
       splits = tecm_gemm16_dispatch_mk_nk(gk, win, drop, st);
     else if (g.a_layout == TECM_A_MK)

@@ -35,9 +35,12 @@ def autocast_bf16() -> bool:
 
 def make_plan(module: nn.Module, p: float = 0.1, precision: str = "auto") -> F_.DropPlan:
     """One plan per forward call: dropout seeds (base seed = torch seed + call count) and the GEMM precision:
-    "fp32" = exact-f32 MFMA, "bf16" = bf16 MFMA with fp32 accumulate, "auto" = bf16 iff under bf16 autocast."""
+    "fp32" = exact-f32 MFMA, "bf16" = bf16 MFMA with fp32 accumulate, "auto" = bf16 iff under bf16 autocast,
+    "bf16x3" = fp32 emulated by three bf16 MFMAs per product on the plain GPT-2 GEMMs (opt-in, ~1e-5)."""
     _seed_counter[0] += 1
     bf16 = precision == "bf16" or (precision == "auto" and autocast_bf16())
+    if precision == "bf16x3":
+        bf16 = 2                                   # ops.PREC_BF16X3
     return F_.DropPlan(training=module.training, p=p, base_seed=(torch.initial_seed() + 7919 * _seed_counter[0]),
                        bf16=bf16)
 

@@ -54,6 +54,7 @@ def gemm(M: int, N: int, K: int, A: torch.Tensor, lda: int, B: torch.Tensor, ldb
          bf16: bool = False) -> None:
     """C[M,N] = epilogue(alpha * A_view[M,K] . B_view[K,N]); see TecmGemm in include/tecmollm.h.
     *_off are element offsets added to the base pointers (column slices of wider buffers).
+    bf16 is the precision code: 0/False exact fp32, 1/True bf16 matrix cores, 2 bf16x3 (split-bf16, ~1e-5).
     bf16=True asks for the bf16 matrix cores (operands rounded to bf16, fp32 accumulate); calls the bf16
     kernel cannot serve (N < 64 output columns or operands that are not 16-byte friendly) run on the exact
     fp32 kernel instead -- the choice is a pure function of shapes/alignment (`uses_bf16`), never silent
@@ -88,16 +89,19 @@ def gemm(M: int, N: int, K: int, A: torch.Tensor, lda: int, B: torch.Tensor, ldb
         g.split_k, g.workspace = split_k, ws.data_ptr()
     else:
         g.split_k = 1
-    use16 = bf16 and _bf16_ok(g)
-    fn = lib().tecm_gemm_bf16 if use16 else lib().tecm_gemm_f32
+    mode = int(bf16)                                    # 0 exact fp32, 1 bf16 (autocast semantics), 2 bf16x3
+    use16 = mode == PREC_BF16 and _bf16_ok(g)
+    use3 = mode == PREC_BF16X3 and _x3_ok(g)
+    fn, what = ((lib().tecm_gemm_bf16x3, "tecm_gemm_bf16x3") if use3 else
+                (lib().tecm_gemm_bf16, "tecm_gemm_bf16") if use16 else (lib().tecm_gemm_f32, "tecm_gemm_f32"))
     if _timing is None:
-        check(fn(C.byref(g), stream_ptr()), "tecm_gemm_bf16" if use16 else "tecm_gemm_f32")
+        check(fn(C.byref(g), stream_ptr()), what)
         return
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    check(fn(C.byref(g), stream_ptr()), "tecm_gemm_bf16" if use16 else "tecm_gemm_f32")
+    check(fn(C.byref(g), stream_ptr()), what)
     e1.record()
-    name = _kernel_name(g, use16)
+    name = "gemm_x3_kernel" if use3 else _kernel_name(g, use16)
     if _timing_detail:
         name += (f" M={M} N={N} K={K} win={g.a_win.enabled}{g.b_win.enabled}{g.c_win.enabled}"
                  f" drop={int(g.a_drop.p > 0)}{int(g.b_drop.p > 0)}{int(g.out_drop.p > 0)} split={g.split_k}"
@@ -105,6 +109,7 @@ def gemm(M: int, N: int, K: int, A: torch.Tensor, lda: int, B: torch.Tensor, ldb
     _timing.append((name, 2.0 * M * N * K, e0, e1))
 
 
+PREC_FP32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
 GROUP_M = 0          # m-tiles per L2 super-tile of the fp32 GEMM (0 = the kernel's default, 8); tools/ sweep it
 BF16_MIN_N = 64
 
@@ -117,6 +122,22 @@ def uses_bf16(N: int, K: int, lda: int, ldb: int, a_layout: int = A_MK, b_layout
     if a_layout == A_MK and K % 4:
         return False
     return True
+
+
+def uses_x3(N: int, K: int, lda: int, ldb: int, a_layout: int = A_MK, b_layout: int = B_NK, a_win: bool = False,
+            b_win: bool = False, a_drop: bool = False, b_drop: bool = False) -> bool:
+    """Which GEMMs the bf16x3 (split-bf16) kernel serves when that mode is requested: the plain MK x NK contraction
+    with at least 64 output columns; every other call runs on the exact fp32 kernel."""
+    if a_layout != A_MK or b_layout != B_NK or a_win or b_win or a_drop or b_drop:
+        return False
+    return N >= BF16_MIN_N and lda % 4 == 0 and ldb % 4 == 0 and K % 4 == 0
+
+
+def _x3_ok(g: TecmGemm) -> bool:
+    if not uses_x3(g.N, g.K, g.lda, g.ldb, g.a_layout, g.b_layout, bool(g.a_win.enabled), bool(g.b_win.enabled),
+                   g.a_drop.p > 0, g.b_drop.p > 0):
+        return False
+    return g.A % 16 == 0 and g.B % 16 == 0
 
 
 def _bf16_ok(g: TecmGemm) -> bool:

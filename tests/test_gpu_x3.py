@@ -1,0 +1,103 @@
+"""GPU tests of the opt-in bf16x3 mode (tecm_gemm_bf16x3): fp32 operands split into bf16 hi + lo while staged, each
+product = lo.hi + hi.lo + hi.hi on the bf16 matrix cores, fp32 accumulate.  Reference = fp64 matmul of the fp32
+operands: the split keeps ~16 mantissa bits per factor, so the error bar is 5e-5 of the result's max magnitude --
+between the exact kernel (2e-6) and plain bf16 (4e-3), and 20x inside the 1e-3 parity bar of the path."""
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+from tests.parity import build_model, oracle_step, rel_err
+
+pytestmark = pytest.mark.gpu
+X3 = 2          # ops.PREC_BF16X3
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda")
+
+
+def _rand(*shape, dev, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dev)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 200, 96), (513, 768, 800), (1000, 3072, 768), (77, 64, 52), (256, 128, 32),
+                                   (257, 129, 36), (2000, 768, 3072)])
+def test_x3_gemm_accuracy_and_epilogue(dev, M, N, K):
+    from tecmollm import ops
+    A, Bn = _rand(M, K, dev=dev, seed=1), _rand(N, K, dev=dev, seed=2)
+    bias, res = _rand(N, dev=dev, seed=4), _rand(M, N, dev=dev, seed=5)
+    C = torch.full((M, N), float("nan"), device=dev)
+    ops.gemm(M, N, K, A, K, Bn, K, C, N, bias=bias, residual=(res, N), bf16=X3)
+    ref = A.double() @ Bn.double().t() + bias.double() + res.double()
+    e3 = _rel(C, ref)
+    assert e3 < 5e-5, e3
+    ops.gemm(M, N, K, A, K, Bn, K, C, N, bias=bias, residual=(res, N), bf16=True)
+    e1 = _rel(C, ref)
+    ops.gemm(M, N, K, A, K, Bn, K, C, N, bias=bias, residual=(res, N))
+    e0 = _rel(C, ref)
+    assert e0 < e3 < e1 / 20, (e0, e3, e1)              # and it really is the split kernel: between exact and plain bf16
+
+
+def test_x3_split_k_activation_and_strided_operands(dev):
+    from tecmollm import ops
+    M, N, K = 640, 256, 4000
+    Abuf, Bbuf = _rand(M, K + 40, dev=dev, seed=1), _rand(N, K + 8, dev=dev, seed=2)
+    A, Bn = Abuf[:, 8:8 + K], Bbuf[:, 4:4 + K]            # 16-byte aligned column slices, leading dims K+40 / K+8
+    C = torch.full((M, N), float("nan"), device=dev)
+    pre = torch.empty(M, N, device=dev)
+    ops.gemm(M, N, K, Abuf, K + 40, Bbuf, K + 8, C, N, a_off=8, b_off=4, split_k=3, bf16=X3)
+    assert _rel(C, A.double() @ Bn.double().t()) < 5e-5
+    ops.gemm(M, N, K, Abuf, K + 40, Bbuf, K + 8, C, N, a_off=8, b_off=4, alpha=0.02, act=ops.ACT_GELU_TANH,
+             preact=(pre, N), bf16=X3)
+    z = 0.02 * (A.double() @ Bn.double().t())
+    assert _rel(pre, z) < 5e-5
+    assert _rel(C, torch.nn.functional.gelu(z, approximate="tanh")) < 5e-5
+
+
+def test_x3_other_layouts_run_on_the_exact_kernel(dev):
+    """KN / KM operands, window views and prologue dropout are not served by the split kernel: the call runs on the
+    exact fp32 kernel (ops.uses_x3 mirrors the rule) -- never a silent precision change the other way."""
+    from tecmollm import ops
+    M, N, K = 300, 256, 128
+    A, Bk = _rand(M, K, dev=dev, seed=1), _rand(K, N, dev=dev, seed=2)
+    C = torch.empty(M, N, device=dev)
+    assert not ops.uses_x3(N, K, K, N, ops.A_MK, ops.B_KN)
+    ops.gemm(M, N, K, A, K, Bk, N, C, N, b_layout=ops.B_KN, bf16=X3)
+    assert _rel(C, A.double() @ Bk.double()) < 3e-6
+    assert ops.uses_x3(N, K, K, K) and not ops.uses_x3(32, K, K, K) and not ops.uses_x3(N, K, K, K, a_drop=True)
+
+
+def test_x3_model_forward_backward_tracks_the_fp32_oracle(dev):
+    """Whole model with precision="bf16x3": forward and every trainable gradient against the fp32 CPU oracle, at the
+    path's own 1e-3 bar (the exact mode passes the same comparison at ~1e-5)."""
+    cfg = R.default_config(L_in=16, L_out=12, num_nodes=12)
+    p = R.init_params(cfg, seed=12)
+    x, tf, y = R.synthetic_batch(2, 16, 12, cfg["spatial_in_channels_base"], 12, seed=13)
+    ei, _ = R.grid_graph(3, 4, threshold_km=170.0)
+    out_ref, loss_ref, grads_ref = oracle_step(cfg, p, x, tf, ei, y, None)
+    from src.model.tec_mollm import TEC_MoLLM
+    mc = dict(cfg, gat_graphs="per_timestep", include_wte=False, load_pretrained_gpt2=False, precision="bf16x3")
+    model = TEC_MoLLM(mc)
+    model.load_state_dict(p, strict=True)
+    model = model.to(dev).eval()
+    tfd = tf[:, :, 0, :].contiguous().to(dev).unsqueeze(-2).expand(2, 16, 12, 4)
+    out = model(x.to(dev), tfd, ei.to(dev))
+    loss = torch.nn.functional.huber_loss(out, y.to(dev))
+    loss.backward()
+    assert rel_err(out, out_ref) < 1e-3
+    named = dict(model.named_parameters())
+    worst = max(rel_err(named[k].grad, g) for k, g in grads_ref.items() if g.abs().max() > 0)
+    assert worst < 1e-3, worst
+    # and the mode is really on: the forward differs from the exact mode by more than fp32 round-off
+    model.precision = "fp32"
+    with torch.no_grad():
+        exact = model(x.to(dev), tfd, ei.to(dev))
+    assert 1e-7 < rel_err(out, exact) < 1e-3

@@ -7,7 +7,7 @@ import torch
 from tecmollm import ops
 
 dev = torch.device("cuda")
-BF16 = os.environ.get('BF16', '0') == '1'
+BF16 = int(os.environ.get('BF16', '0'))       # 0 exact fp32, 1 bf16, 2 bf16x3
 ops.GROUP_M = int(os.environ.get('GROUP_M', '0'))
 for spec in os.environ.get("SHAPES", "16384,2048,16384,kn").split(";"):
     M, N, K, lay = spec.split(",")

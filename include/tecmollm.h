@@ -103,6 +103,10 @@ int tecm_gemm_bf16(const TecmGemm* desc, void* stream);
  * dot-product relative error ~1e-5; the bf16 MFMA runs at 16x the exact-f32 MFMA rate on gfx950).  Opt-in
  * (model_config["precision"] = "bf16x3"); serves the plain MK x NK contraction only, TECM_E_ARG otherwise. */
 int tecm_gemm_bf16x3(const TecmGemm* g, void* stream);
+/* "bf16x6": three-way split (hi + mid + lo carries all 24 mantissa bits), six products hi.lo + lo.hi + mid.mid +
+ * hi.mid + mid.hi + hi.hi: only terms below 2^-24 of a product are dropped -- fp32-grade accuracy at 6/16 of the exact
+ * matrix time.  Same scope and return convention as tecm_gemm_bf16x3. */
+int tecm_gemm_bf16x6(const TecmGemm* g, void* stream);
 
 /* ------------------------------------------------------------------ stage a-1..a-3 (fused)
  * SpatioTemporalEmbedding.forward (modules.py:230-266) + GATv2Conv (modules.py:329-336,:356)

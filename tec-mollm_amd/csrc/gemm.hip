@@ -1,7 +1,7 @@
 // extern "C" entry point of the fp32 MFMA GEMM (kernel template: gemm_impl.h; instantiations:
 // gemm_mk_nk.hip, gemm_mk_kn.hip, gemm_km_kn.hip -- one translation unit per operand-layout pair).
 #include "gemm_bf16_impl.h"
-int tecm_gemm_x3_dispatch(const TecmGemm& g, hipStream_t st);      // gemm_x3.hip
+int tecm_gemm_x3_dispatch(const TecmGemm& g, int products, hipStream_t st);      // gemm_x3.hip
 
 namespace {
 
@@ -69,7 +69,7 @@ bool win_ok(const TecmWin& w) {
 
 }  // namespace
 
-enum { MODE_F32 = 0, MODE_BF16 = 1, MODE_X3 = 2 };
+enum { MODE_F32 = 0, MODE_BF16 = 1, MODE_X3 = 2, MODE_X6 = 3 };
 static int gemm_entry(const TecmGemm* d, void* stream, int mode);
 
 extern "C" int tecm_gemm_f32(const TecmGemm* d, void* stream) { return gemm_entry(d, stream, MODE_F32); }
@@ -84,6 +84,8 @@ extern "C" int tecm_gemm_bf16(const TecmGemm* d, void* stream) { return gemm_ent
 // plain MK x NK contraction only (no a_win / b_win, no a_drop / b_drop, 16-byte friendly operands); anything else
 // returns TECM_E_ARG so that the caller runs tecm_gemm_f32 for that call.
 extern "C" int tecm_gemm_bf16x3(const TecmGemm* d, void* stream) { return gemm_entry(d, stream, MODE_X3); }
+// Three-way split (hi + mid + lo = all 24 mantissa bits), six products: fp32-grade accuracy at 6/16 of the exact time.
+extern "C" int tecm_gemm_bf16x6(const TecmGemm* d, void* stream) { return gemm_entry(d, stream, MODE_X6); }
 
 static int gemm_entry(const TecmGemm* d, void* stream, int mode) {
   const bool bf16 = mode == MODE_BF16;
@@ -123,7 +125,7 @@ static int gemm_entry(const TecmGemm* d, void* stream, int mode) {
   if (bf16)
     TECM_REQUIRE(avec == 4 && bvec == 4, TECM_E_ALIGN,
                  "tecm_gemm_bf16: operands must be 16-byte aligned with leading dims / K / Cw multiples of 4");
-  if (mode == MODE_X3) {
+  if (mode == MODE_X3 || mode == MODE_X6) {
     TECM_REQUIRE(g.a_layout == TECM_A_MK && g.b_layout == TECM_B_NK && !win && !drop, TECM_E_ARG,
                  "tecm_gemm_bf16x3: serves the plain MK x NK contraction only (no operand windows / prologue dropout)");
     TECM_REQUIRE(avec == 4 && bvec == 4, TECM_E_ALIGN,
@@ -140,8 +142,8 @@ static int gemm_entry(const TecmGemm* d, void* stream, int mode) {
     gk.out_drop.p = 0.f;
   }
   int splits;
-  if (mode == MODE_X3) {
-    splits = tecm_gemm_x3_dispatch(gk, st);
+  if (mode == MODE_X3 || mode == MODE_X6) {
+    splits = tecm_gemm_x3_dispatch(gk, mode == MODE_X6 ? 6 : 3, st);
   } else if (bf16) {
     if (g.a_layout == TECM_A_MK && g.b_layout == TECM_B_NK)
       splits = tecm_gemm16_dispatch_mk_nk(gk, win, drop, st);

@@ -6,13 +6,17 @@
 // result carries ~16 mantissa bits per factor (relative error of a dot product ~1e-5): two orders inside the
 // 1e-3 parity bar, but NOT exact fp32 -- an opt-in mode (model_config["precision"] = "bf16x3"), never the default.
 //
+// The same kernel with a THREE-way split (hi + mid + lo carries all 24 mantissa bits of an fp32 value) and the six
+// products  hi.lo + lo.hi + mid.mid + hi.mid + mid.hi + hi.hi  ("bf16x6") drops only terms below 2^-24 of the
+// product: fp32-grade accuracy (GEMM error vs fp64 ~ the exact kernel's) at 6/16 of the exact matrix time.
+//
 // Scope: the plain dense contraction  C = epilogue(A[M,K] . B[N,K]^T)  with both operands [row][k] (MK x NK), no
 // window view / dropout prologue on A or B -- i.e. the eight GPT-2 GEMMs per layer (the forward ones read the
 // cached [N][K] copies of the frozen weights).  Everything else stays on the exact kernel.
 //
-// Block = 512 threads = 8 waves as 4(m) x 2(n), tile 256 x 128 x 32; a wave owns 64 x 64 = 2 x 2 MFMA tiles and
-// issues 2 k-steps x 4 tiles x 3 products = 24 MFMAs per K-tile.  LDS per buffer: hi and lo images of A and B,
-// [row][k] bf16 with an 80-byte pitch (32 k + 8 pad: a fragment = one conflict-free ds_read_b128), 61 KiB; two
+// Block = 512 threads = 8 waves as 4(m) x 2(n), tile 256 x 128 x BK (x3: BK = 32, x6: BK = 16); a wave owns
+// 64 x 64 = 2 x 2 MFMA tiles and issues 24 MFMAs per K-tile either way.  LDS per buffer: NS images of A and B,
+// [row][k] bf16 with a (BK + 8)-element pitch (a fragment = one conflict-free ds_read_b128): 61 / 55 KiB; two
 // buffers, one barrier per K-tile, same register-staged pipeline and epilogue as the bf16 kernel.
 #pragma once
 #include "gemm_bf16_impl.h"
@@ -34,9 +38,7 @@ using tecm_gemm16::bf16x8;
 
 constexpr int BM = 256;
 constexpr int BN = 128;
-constexpr int BK = 32;
 constexpr int NTH = 512;
-constexpr int LDH = BK + 8;          // 80-byte rows
 
 // hi/lo split of a float pair, packed as two bf16x2 words
 __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
@@ -50,12 +52,30 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t&
   lo = __builtin_bit_cast(uint32_t, l);
 }
 
+// three-way split: hi + mid + lo reproduces every mantissa bit of a finite fp32 value
+__device__ __forceinline__ void split3(float a, float b, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+  bf16x2 h, m, l;
+  h[0] = (__bf16)a;
+  h[1] = (__bf16)b;
+  const float ra = a - (float)h[0], rb = b - (float)h[1];
+  m[0] = (__bf16)ra;
+  m[1] = (__bf16)rb;
+  l[0] = (__bf16)(ra - (float)m[0]);
+  l[1] = (__bf16)(rb - (float)m[1]);
+  hi = __builtin_bit_cast(uint32_t, h);
+  mid = __builtin_bit_cast(uint32_t, m);
+  lo = __builtin_bit_cast(uint32_t, l);
+}
+
 // [row][k] source, float4 along k; rows pre-clamped (out-of-range rows feed accumulator rows that are never stored)
-template <int ROWS>
+template <int ROWS, int NS, int BK>
 struct SplitStager {
-  static constexpr int VPR = BK / 4;                  // 8 vectors per row
-  static constexpr int NV = ROWS * VPR / NTH;         // 4 (A) or 2 (B)
-  static constexpr int RSTEP = NTH / VPR;             // 64 rows between a thread's vectors
+  static constexpr int LDH = BK + 8;
+  static constexpr int IMG = ROWS * LDH;              // elements of one image
+  static constexpr int VPR = BK / 4;                  // vectors per row
+  static constexpr int NV = ROWS * VPR / NTH;
+  static constexpr int RSTEP = NTH / VPR;             // rows between a thread's vectors
+  static_assert(NV >= 1 && ROWS * VPR % NTH == 0, "tile / thread mapping");
   float regs[NV][4];
   const float* ptr[NV];
   uint32_t okmask;                                    // bit i: vector i of the tile in regs lies inside K
@@ -98,8 +118,9 @@ struct SplitStager {
     }
     if constexpr (IE == NV) kk += BK;
   }
+  // images of one operand are consecutive in LDS: [hi | (mid) | lo]
   template <int IB, int IE, bool MASKED>
-  __device__ __forceinline__ void store_part(__bf16* hi_img, __bf16* lo_img) {
+  __device__ __forceinline__ void store_part(__bf16* img) {
     if constexpr (IB >= IE) return;
     const int cv = (threadIdx.x % VPR) * 4;
     const int r0 = threadIdx.x / VPR;
@@ -108,27 +129,40 @@ struct SplitStager {
       float v[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = (!MASKED || ((okmask >> i) & 1u)) ? regs[i][e] : 0.f;
-      uint2 h, l;
-      split2(v[0], v[1], h.x, l.x);
-      split2(v[2], v[3], h.y, l.y);
       const int off = (r0 + i * RSTEP) * LDH + cv;
-      *reinterpret_cast<uint2*>(hi_img + off) = h;
-      *reinterpret_cast<uint2*>(lo_img + off) = l;
+      if constexpr (NS == 2) {
+        uint2 h, l;
+        split2(v[0], v[1], h.x, l.x);
+        split2(v[2], v[3], h.y, l.y);
+        *reinterpret_cast<uint2*>(img + off) = h;
+        *reinterpret_cast<uint2*>(img + IMG + off) = l;
+      } else {
+        uint2 h, m, l;
+        split3(v[0], v[1], h.x, m.x, l.x);
+        split3(v[2], v[3], h.y, m.y, l.y);
+        *reinterpret_cast<uint2*>(img + off) = h;
+        *reinterpret_cast<uint2*>(img + IMG + off) = m;
+        *reinterpret_cast<uint2*>(img + 2 * IMG + off) = l;
+      }
     }
   }
 };
 
+template <int NS, int BK>
 __global__ __launch_bounds__(NTH, 2) void gemm_x3_kernel(const TecmGemm g, int tiles_m, int tiles_n, int k_chunk) {
   constexpr int WN = 2, WM = 4;
   constexpr int WTM = BM / WM, WTN = BN / WN;          // 64 x 64 per wave
   constexpr int MT = WTM / 32, NT = WTN / 32;
-  using AStager = SplitStager<BM>;
-  using BStager = SplitStager<BN>;
-  constexpr int A_ELEMS = BM * LDH, B_ELEMS = BN * LDH;
-  constexpr int TILE_ELEMS = 2 * (A_ELEMS + B_ELEMS);  // [A_hi | A_lo | B_hi | B_lo], bf16 elements
+  constexpr int KSTEPS = BK / 16;
+  using AStager = SplitStager<BM, NS, BK>;
+  using BStager = SplitStager<BN, NS, BK>;
+  constexpr int LDH = AStager::LDH;
+  constexpr int A_IMG = AStager::IMG, B_IMG = BStager::IMG;
+  constexpr int TILE_ELEMS = NS * (A_IMG + B_IMG);     // [A images | B images], bf16 elements
   constexpr int STG_LD = WTN + 4;
   constexpr int STG_BYTES = 8 * 32 * STG_LD * 4;
   constexpr int SMEM_BYTES = 2 * TILE_ELEMS * 2 > STG_BYTES ? 2 * TILE_ELEMS * 2 : STG_BYTES;
+  static_assert(SMEM_BYTES <= 160 * 1024, "LDS budget");
   __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_BYTES];
   __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);
 
@@ -168,78 +202,70 @@ __global__ __launch_bounds__(NTH, 2) void gemm_x3_kernel(const TecmGemm g, int t
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   constexpr int ANV = AStager::NV, BNV = BStager::NV;
-  auto images = [&](int buf, __bf16*& ah, __bf16*& al, __bf16*& bh, __bf16*& bl) {
-    ah = smem + buf * TILE_ELEMS;
-    al = ah + A_ELEMS;
-    bh = al + A_ELEMS;
-    bl = bh + B_ELEMS;
-  };
 
   // prologue: K-tile 0 -> LDS buffer 0, K-tile 1 -> registers (in flight)
-  {
-    __bf16 *ah, *al, *bh, *bl;
-    images(0, ah, al, bh, bl);
-    sa.load_part<0, ANV>(g.A, kend);
-    sb.load_part<0, BNV>(g.B, kend);
-    sa.store_part<0, ANV, true>(ah, al);
-    sb.store_part<0, BNV, true>(bh, bl);
-    if (kbeg + BK < kend) {
-      sa.load_part<0, ANV>(g.A, kend);
-      sb.load_part<0, BNV>(g.B, kend);
-    }
+  sa.template load_part<0, ANV>(g.A, kend);
+  sb.template load_part<0, BNV>(g.B, kend);
+  sa.template store_part<0, ANV, true>(smem);
+  sb.template store_part<0, BNV, true>(smem + NS * A_IMG);
+  if (kbeg + BK < kend) {
+    sa.template load_part<0, ANV>(g.A, kend);
+    sb.template load_part<0, BNV>(g.B, kend);
   }
   __syncthreads();
 
   int cur = 0;
   auto tile = [&](int32_t k0, auto fullc) {
     constexpr bool FULL = decltype(fullc)::value;         // K-tiles t+1 and t+2 lie entirely inside [kbeg, kend)
-    __bf16 *ah, *al, *bh, *bl, *nah, *nal, *nbh, *nbl;
-    images(cur, ah, al, bh, bl);
-    images(cur ^ 1, nah, nal, nbh, nbl);
-    static_for<2>([&](auto sc) {
-      constexpr int s = decltype(sc)::value;              // k-step of 16 inside the 32-deep tile
-      bf16x8 afh[MT], afl[MT], bfh[NT], bfl[NT];
+    const __bf16* aimg = smem + cur * TILE_ELEMS;
+    const __bf16* bimg = aimg + NS * A_IMG;
+    __bf16* naimg = smem + (cur ^ 1) * TILE_ELEMS;
+    __bf16* nbimg = naimg + NS * A_IMG;
+    static_for<KSTEPS>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;              // k-step of 16 inside the tile
+      bf16x8 af[NS][MT], bf[NS][NT];                      // [0] = hi ... [NS-1] = lo
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int off = (wm * WTM + i * 32 + r) * LDH + 16 * s + 8 * h;
-        afh[i] = *reinterpret_cast<const bf16x8*>(ah + off);
-        afl[i] = *reinterpret_cast<const bf16x8*>(al + off);
+      for (int p = 0; p < NS; ++p) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+          af[p][i] = *reinterpret_cast<const bf16x8*>(aimg + p * A_IMG + (wm * WTM + i * 32 + r) * LDH + 16 * s + 8 * h);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          bf[p][j] = *reinterpret_cast<const bf16x8*>(bimg + p * B_IMG + (wn * WTN + j * 32 + r) * LDH + 16 * s + 8 * h);
       }
+      auto prod = [&](auto pa, auto pb) {
+        constexpr int PA = decltype(pa)::value, PB = decltype(pb)::value;
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int off = (wn * WTN + j * 32 + r) * LDH + 16 * s + 8 * h;
-        bfh[j] = *reinterpret_cast<const bf16x8*>(bh + off);
-        bfl[j] = *reinterpret_cast<const bf16x8*>(bl + off);
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA][i], bf[PB][j], acc[i][j], 0, 0, 0);
+      };
+      using I0 = std::integral_constant<int, 0>;
+      using I1 = std::integral_constant<int, 1>;
+      using I2 = std::integral_constant<int, 2>;
+      // smallest terms first, the head product last
+      if constexpr (NS == 2) {
+        prod(I1{}, I0{}); prod(I0{}, I1{}); prod(I0{}, I0{});
+      } else {
+        prod(I0{}, I2{}); prod(I2{}, I0{}); prod(I1{}, I1{}); prod(I0{}, I1{}); prod(I1{}, I0{}); prod(I0{}, I0{});
       }
-      // the two cross terms first, the head product last
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afl[i], bfh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afh[i], bfl[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afh[i], bfh[j], acc[i][j], 0, 0, 0);
-      // half of the staging work per k-step
-      constexpr int AB = (ANV * s) / 2, AE = (ANV * (s + 1)) / 2;
-      constexpr int BB = (BNV * s) / 2, BE = (BNV * (s + 1)) / 2;
+      // 1/KSTEPS of the staging work per k-step
+      constexpr int AB = (ANV * s) / KSTEPS, AE = (ANV * (s + 1)) / KSTEPS;
+      constexpr int BB = (BNV * s) / KSTEPS, BE = (BNV * (s + 1)) / KSTEPS;
       if constexpr (FULL) {
-        sa.store_part<AB, AE, false>(nah, nal);
-        sb.store_part<BB, BE, false>(nbh, nbl);
-        sa.load_steady<AB, AE>();
-        sb.load_steady<BB, BE>();
+        sa.template store_part<AB, AE, false>(naimg);
+        sb.template store_part<BB, BE, false>(nbimg);
+        sa.template load_steady<AB, AE>();
+        sb.template load_steady<BB, BE>();
       } else {
         if (k0 + BK < kend) {
-          sa.store_part<AB, AE, true>(nah, nal);
-          sb.store_part<BB, BE, true>(nbh, nbl);
+          sa.template store_part<AB, AE, true>(naimg);
+          sb.template store_part<BB, BE, true>(nbimg);
         }
         if (k0 + 2 * BK < kend) {
-          sa.load_part<AB, AE>(g.A, kend);
-          sb.load_part<BB, BE>(g.B, kend);
+          sa.template load_part<AB, AE>(g.A, kend);
+          sb.template load_part<BB, BE>(g.B, kend);
         }
       }
     });
@@ -306,18 +332,19 @@ __global__ __launch_bounds__(NTH, 2) void gemm_x3_kernel(const TecmGemm g, int t
   });
 }
 
-inline int launch_x3(const TecmGemm& g, hipStream_t st) {
+template <int NS, int BK>
+int launch_split(const TecmGemm& g, hipStream_t st) {
   const int tiles_m = (int)((g.M + BM - 1) / BM);
   const int tiles_n = (int)((g.N + BN - 1) / BN);
   int splits = g.split_k > 1 ? g.split_k : 1;
   int k_chunk = (int)(((g.K + splits - 1) / splits + BK - 1) / BK) * BK;
   splits = (int)((g.K + k_chunk - 1) / k_chunk);
   dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)splits);
-  hipLaunchKernelGGL(gemm_x3_kernel, grid, dim3(NTH), 0, st, g, tiles_m, tiles_n, k_chunk);
-  TECM_CHECK_LAUNCH("tecm_gemm_bf16x3");
+  hipLaunchKernelGGL((gemm_x3_kernel<NS, BK>), grid, dim3(NTH), 0, st, g, tiles_m, tiles_n, k_chunk);
+  TECM_CHECK_LAUNCH("tecm_gemm_bf16x3/x6");
   return splits;
 }
 
 }  // namespace tecm_gemm3
 
-int tecm_gemm_x3_dispatch(const TecmGemm& g, hipStream_t st);
+int tecm_gemm_x3_dispatch(const TecmGemm& g, int products, hipStream_t st);      // products = 3 or 6

@@ -41,6 +41,8 @@ def make_plan(module: nn.Module, p: float = 0.1, precision: str = "auto") -> F_.
     bf16 = precision == "bf16" or (precision == "auto" and autocast_bf16())
     if precision == "bf16x3":
         bf16 = 2                                   # ops.PREC_BF16X3
+    elif precision == "bf16x6":
+        bf16 = 3                                   # ops.PREC_BF16X6
     return F_.DropPlan(training=module.training, p=p, base_seed=(torch.initial_seed() + 7919 * _seed_counter[0]),
                        bf16=bf16)
 

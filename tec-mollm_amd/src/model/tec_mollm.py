@@ -11,7 +11,8 @@ dict, same forward signature and output shape, same parameter names.  Difference
   * model_config may carry `precision`: "auto" (default: bf16 matrix cores iff called under
     `torch.autocast('cuda', torch.bfloat16)` as train.py:68 does, exact fp32 otherwise), "fp32", "bf16", or
     "bf16x3" (opt-in: the plain GPT-2 GEMMs evaluate every fp32 product as three bf16 matrix-core products of the
-    hi/lo bf16 split of its factors -- relative error ~1e-5, far inside the 1e-3 parity bar, but not exact fp32);
+    hi/lo bf16 split of its factors -- relative error ~1e-5, far inside the 1e-3 parity bar, but not exact fp32;
+    "bf16x6": three-way split, six products, fp32-grade accuracy at 6/16 of the exact matrix time);
   * model_config may carry `gat_graphs`: "reference" (default: a single-graph edge_index only
     connects graph 0 = (t=0, b=0), exactly what the reference computes -- SURVEY.md section 0) or
     "per_timestep" (every (b, t) graph aggregates neighbours, what the reference's comments intend).
@@ -56,8 +57,8 @@ class TEC_MoLLM(nn.Module):
         if len(cfg["temporal_strides"]) != 2 or len(cfg["temporal_channel_list"]) != 2:
             raise ValueError("exactly two temporal conv blocks are supported (tec_mollm.py:51)")
         self.precision = cfg.get("precision", "auto")
-        if self.precision not in ("auto", "fp32", "bf16", "bf16x3"):
-            raise ValueError("precision must be 'auto' (follow torch.autocast), 'fp32', 'bf16' or 'bf16x3'")
+        if self.precision not in ("auto", "fp32", "bf16", "bf16x3", "bf16x6"):
+            raise ValueError("precision must be 'auto' (follow torch.autocast), 'fp32', 'bf16', 'bf16x3' or 'bf16x6'")
         self.gat_graphs = cfg.get("gat_graphs", "reference")
         if self.gat_graphs not in ("reference", "per_timestep"):
             raise ValueError("gat_graphs must be 'reference' or 'per_timestep'")

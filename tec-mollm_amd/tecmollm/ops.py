@@ -54,7 +54,8 @@ def gemm(M: int, N: int, K: int, A: torch.Tensor, lda: int, B: torch.Tensor, ldb
          bf16: bool = False) -> None:
     """C[M,N] = epilogue(alpha * A_view[M,K] . B_view[K,N]); see TecmGemm in include/tecmollm.h.
     *_off are element offsets added to the base pointers (column slices of wider buffers).
-    bf16 is the precision code: 0/False exact fp32, 1/True bf16 matrix cores, 2 bf16x3 (split-bf16, ~1e-5).
+    bf16 is the precision code: 0/False exact fp32, 1/True bf16 matrix cores, 2 bf16x3 (split-bf16, ~1e-5),
+    3 bf16x6 (three-way split, fp32-grade).
     bf16=True asks for the bf16 matrix cores (operands rounded to bf16, fp32 accumulate); calls the bf16
     kernel cannot serve (N < 64 output columns or operands that are not 16-byte friendly) run on the exact
     fp32 kernel instead -- the choice is a pure function of shapes/alignment (`uses_bf16`), never silent
@@ -91,8 +92,9 @@ def gemm(M: int, N: int, K: int, A: torch.Tensor, lda: int, B: torch.Tensor, ldb
         g.split_k = 1
     mode = int(bf16)                                    # 0 exact fp32, 1 bf16 (autocast semantics), 2 bf16x3
     use16 = mode == PREC_BF16 and _bf16_ok(g)
-    use3 = mode == PREC_BF16X3 and _x3_ok(g)
-    fn, what = ((lib().tecm_gemm_bf16x3, "tecm_gemm_bf16x3") if use3 else
+    use3 = mode in (PREC_BF16X3, PREC_BF16X6) and _x3_ok(g)
+    fn, what = ((lib().tecm_gemm_bf16x6, "tecm_gemm_bf16x6") if (use3 and mode == PREC_BF16X6) else
+                (lib().tecm_gemm_bf16x3, "tecm_gemm_bf16x3") if use3 else
                 (lib().tecm_gemm_bf16, "tecm_gemm_bf16") if use16 else (lib().tecm_gemm_f32, "tecm_gemm_f32"))
     if _timing is None:
         check(fn(C.byref(g), stream_ptr()), what)
@@ -101,7 +103,7 @@ def gemm(M: int, N: int, K: int, A: torch.Tensor, lda: int, B: torch.Tensor, ldb
     e0.record()
     check(fn(C.byref(g), stream_ptr()), what)
     e1.record()
-    name = "gemm_x3_kernel" if use3 else _kernel_name(g, use16)
+    name = ("gemm_x3_kernel<3,16>" if mode == PREC_BF16X6 else "gemm_x3_kernel<2,32>") if use3 else _kernel_name(g, use16)
     if _timing_detail:
         name += (f" M={M} N={N} K={K} win={g.a_win.enabled}{g.b_win.enabled}{g.c_win.enabled}"
                  f" drop={int(g.a_drop.p > 0)}{int(g.b_drop.p > 0)}{int(g.out_drop.p > 0)} split={g.split_k}"
@@ -109,7 +111,7 @@ def gemm(M: int, N: int, K: int, A: torch.Tensor, lda: int, B: torch.Tensor, ldb
     _timing.append((name, 2.0 * M * N * K, e0, e1))
 
 
-PREC_FP32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
+PREC_FP32, PREC_BF16, PREC_BF16X3, PREC_BF16X6 = 0, 1, 2, 3
 GROUP_M = 0          # m-tiles per L2 super-tile of the fp32 GEMM (0 = the kernel's default, 8); tools/ sweep it
 BF16_MIN_N = 64
 

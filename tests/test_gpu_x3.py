@@ -101,3 +101,49 @@ def test_x3_model_forward_backward_tracks_the_fp32_oracle(dev):
     with torch.no_grad():
         exact = model(x.to(dev), tfd, ei.to(dev))
     assert 1e-7 < rel_err(out, exact) < 1e-3
+
+
+X6 = 3          # ops.PREC_BF16X6
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 200, 96), (513, 768, 800), (1000, 3072, 768), (77, 64, 52), (256, 128, 16),
+                                   (257, 129, 36), (2000, 768, 3072)])
+def test_x6_gemm_is_fp32_grade(dev, M, N, K):
+    """Three-way split, six products: the error against fp64 is of the same order as the exact-f32 kernel's."""
+    from tecmollm import ops
+    A, Bn = _rand(M, K, dev=dev, seed=1), _rand(N, K, dev=dev, seed=2)
+    bias = _rand(N, dev=dev, seed=4)
+    C = torch.full((M, N), float("nan"), device=dev)
+    ref = A.double() @ Bn.double().t() + bias.double()
+    ops.gemm(M, N, K, A, K, Bn, K, C, N, bias=bias, bf16=X6)
+    e6 = _rel(C, ref)
+    ops.gemm(M, N, K, A, K, Bn, K, C, N, bias=bias)
+    e0 = _rel(C, ref)
+    ops.gemm(M, N, K, A, K, Bn, K, C, N, bias=bias, bf16=X3)
+    e3 = _rel(C, ref)
+    assert e6 < 1.5 * e0 + 1e-7 and e6 < e3 / 2, (e0, e6, e3)      # measured: e6 ~ e0 ~ 1e-6, e3 ~ 5e-6, bf16 ~ 2e-3
+
+
+def test_x6_split_k_and_model_step(dev):
+    from tecmollm import ops
+    M, N, K = 640, 256, 4000
+    A, Bn = _rand(M, K, dev=dev, seed=1), _rand(N, K, dev=dev, seed=2)
+    C = torch.full((M, N), float("nan"), device=dev)
+    ops.gemm(M, N, K, A, K, Bn, K, C, N, split_k=3, bf16=X6)
+    assert _rel(C, A.double() @ Bn.double().t()) < 4e-6
+    cfg = R.default_config(L_in=16, L_out=12, num_nodes=12)
+    p = R.init_params(cfg, seed=12)
+    x, tf, y = R.synthetic_batch(2, 16, 12, cfg["spatial_in_channels_base"], 12, seed=13)
+    ei, _ = R.grid_graph(3, 4, threshold_km=170.0)
+    out_ref, loss_ref, grads_ref = oracle_step(cfg, p, x, tf, ei, y, None)
+    from src.model.tec_mollm import TEC_MoLLM
+    mc = dict(cfg, gat_graphs="per_timestep", include_wte=False, load_pretrained_gpt2=False, precision="bf16x6")
+    model = TEC_MoLLM(mc)
+    model.load_state_dict(p, strict=True)
+    model = model.to(dev).eval()
+    tfd = tf[:, :, 0, :].contiguous().to(dev).unsqueeze(-2).expand(2, 16, 12, 4)
+    out = model(x.to(dev), tfd, ei.to(dev))
+    torch.nn.functional.huber_loss(out, y.to(dev)).backward()
+    named = dict(model.named_parameters())
+    worst = max(rel_err(named[k].grad, g) for k, g in grads_ref.items() if g.abs().max() > 0)
+    assert rel_err(out, out_ref) < 2e-5 and worst < 5e-5, (rel_err(out, out_ref), worst)      # the exact mode's own level

@@ -171,7 +171,9 @@ def _vec(p: int, ld: int, w: TecmWin, inner_is_k: bool, K: int) -> int:
 def _kernel_name(g: TecmGemm, use16: bool = False) -> str:
     """Name of the template instance csrc/gemm.hip dispatches to (mirrors pick_vec / dispatch_vec)."""
     if use16:
-        return f"gemm_bf16_kernel<{g.a_layout},{g.b_layout}>"
+        win16 = "true" if (g.a_win.enabled or g.b_win.enabled) else "false"
+        drp16 = "true" if (g.a_drop.p > 0 or g.b_drop.p > 0) else "false"
+        return f"gemm_bf16_kernel<{g.a_layout},{g.b_layout},{win16},{drp16}>"
     av = _vec(g.A, g.lda, g.a_win, g.a_layout == A_MK, g.K)
     bv = _vec(g.B, g.ldb, g.b_win, g.b_layout == B_NK, g.K)
     if av == 4 and bv == 4:

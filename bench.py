@@ -175,7 +175,7 @@ def main():
     from src.model.tec_mollm import TEC_MoLLM
     from tecmollm import ops
     from tecmollm.train import TrainStep
-    from oracle.ref_cpu import grid_graph, synthetic_batch       # synthetic inputs only (no oracle compute)
+    from tecmollm.synthetic import grid_graph, synthetic_batch
 
     cfg = make_config(args)
     mc = dict(cfg, gat_graphs=args.gat, include_wte=False, load_pretrained_gpt2=False, precision=args.precision)

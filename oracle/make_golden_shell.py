@@ -2,8 +2,9 @@
 
 Run in the authoring container only (needs /root/reference):   python oracle/make_golden_shell.py
 
-Imports `/root/reference/src/evaluation/metrics.py` (numpy / sklearn / scipy / joblib -- all installed)
-and `/root/reference/src/data/dataset.py` (torch only) unmodified, feeds seeded inputs, stores inputs and
+Imports `/root/reference/src/evaluation/metrics.py` (numpy / sklearn / scipy / joblib -- all installed),
+`/root/reference/src/data/dataset.py` (torch only) and the numpy/scipy/sklearn functions of
+`/root/reference/src/graph/graph_constructor.py` unmodified, feeds seeded inputs, stores inputs and
 the functions' outputs under tests/golden/shell_*.npz.
 """
 from __future__ import annotations
@@ -91,6 +92,24 @@ def main():
                         x=np.stack([it["x"].numpy() for it in items]), y=np.stack([it["y"].numpy() for it in items]),
                         tf=np.stack([it["x_time_features"].numpy() for it in items]),
                         index_error_past_end=raised, length_when_too_short=len(ds_short))
+    # ------------------------------------------------------------ grid graph from the reference's graph_constructor
+    # src/graph/graph_constructor.py imports src.data.data_loader (h5py, not installed) only for its HDF5 helper; the
+    # name is pre-seeded as an empty placeholder so that the pure numpy/scipy/sklearn functions can be called.
+    import types
+    ph = types.ModuleType("src.data.data_loader")
+    ph.load_and_split_data = None
+    sys.modules["src.data.data_loader"] = ph
+    from src.graph import graph_constructor as GC
+    graphs = {}
+    for tag, (lat, lon, thr) in {"full": (15.0 + np.arange(41), 70.0 + np.arange(71), 150.0),
+                                 "small": (30.0 + 0.5 * np.arange(5), 100.0 + 0.5 * np.arange(7), 120.0)}.items():
+        dist = GC.calculate_haversine_distance_matrix(lat, lon)
+        adj = GC.construct_binary_adjacency(dist, thr)
+        norm = GC.symmetrically_normalize_adjacency(adj)
+        graphs[f"{tag}_lat"], graphs[f"{tag}_lon"], graphs[f"{tag}_thr"] = lat, lon, np.float64(thr)
+        graphs[f"{tag}_edge_index"] = np.vstack((norm.row, norm.col)).astype(np.int32)
+        graphs[f"{tag}_edge_weight"] = norm.data.astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "shell_graph.npz"), **graphs)
     print("wrote", sorted(f for f in os.listdir(OUT) if f.startswith("shell_")))
 
 

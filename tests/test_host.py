@@ -269,3 +269,43 @@ def test_by_source_lists_are_a_permutation_of_each_tile_segment():
                     assert e0 <= e < e1 and int(col[e]) == int(lo[k]) + w
                     seen.add(e)
             assert seen == set(range(e0, e1))
+
+
+def test_grid_graph_matches_reference_graph_constructor(golden_dir):
+    """src/graph/graph_constructor.py (product, banded search) and the oracle's grid_graph against edges and weights
+    produced by the reference's own calculate_haversine_distance_matrix / construct_binary_adjacency /
+    symmetrically_normalize_adjacency (oracle/make_golden_shell.py), full 41 x 71 grid and a small half-degree grid."""
+    from src.graph import graph_constructor as GC
+    g = np.load(os.path.join(golden_dir, "shell_graph.npz"))
+    for tag in ("full", "small"):
+        lat, lon, thr = g[f"{tag}_lat"], g[f"{tag}_lon"], float(g[f"{tag}_thr"])
+        ei, ew = GC.build_grid_graph(lat, lon, thr)
+        assert np.array_equal(ei.numpy(), g[f"{tag}_edge_index"].astype(np.int64))          # same edges, same order
+        np.testing.assert_allclose(ew.numpy(), g[f"{tag}_edge_weight"], rtol=1e-6)
+    # the dense helpers of the mirrored API agree with the banded builder
+    lat, lon, thr = g["small_lat"], g["small_lon"], float(g["small_thr"])
+    row, col, data = GC.symmetrically_normalize_adjacency(
+        GC.construct_binary_adjacency(GC.calculate_haversine_distance_matrix(lat, lon), thr))
+    assert np.array_equal(np.vstack((row, col)), g["small_edge_index"])
+    np.testing.assert_allclose(data, g["small_edge_weight"], rtol=1e-6)
+    # the oracle's own builder (used by the parity tests) is the same graph
+    ei_o, ew_o = R.grid_graph()
+    assert np.array_equal(ei_o.numpy(), g["full_edge_index"].astype(np.int64))
+    np.testing.assert_allclose(ew_o.numpy(), g["full_edge_weight"], rtol=1e-6)
+    assert ei_o.shape[1] == 20924
+
+
+def test_synthetic_inputs_do_not_come_from_the_oracle():
+    """bench.py and tools/ draw their inputs from the product package; the oracle keeps an identical generator for
+    the parity tests.  Outside tests/, only bench.py's cpu_baseline leg and smoke() may touch oracle/."""
+    from tecmollm import synthetic
+    a, b = synthetic.synthetic_batch(2, 4, 5, 3, 2, seed=9), R.synthetic_batch(2, 4, 5, 3, 2, seed=9)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    body = src[src.index("def main():"):]
+    assert "oracle" not in body.replace("cpu_baseline", "")       # main() reaches the oracle only through cpu_baseline()
+    for root, _, files in os.walk(os.path.join(ROOT, "tec-mollm_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                txt = open(os.path.join(root, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, os.path.join(root, f)

@@ -7,7 +7,7 @@ import torch
 from tecmollm import ops
 from tecmollm.train import TrainStep
 from src.model.tec_mollm import TEC_MoLLM
-from oracle.ref_cpu import grid_graph, synthetic_batch
+from tecmollm.synthetic import grid_graph, synthetic_batch
 
 prec = os.environ.get("PRECISION", "fp32")
 B, L, Lo, cin = 8, 48, 12, 10

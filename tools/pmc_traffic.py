@@ -20,7 +20,8 @@ def load(d, counter):
             a = [x.strip() for x in m.group(2).split(",")]
             key = f"{m.group(1)}<{','.join(a if m.group(1) == 'gemm_kernel' else a[:2])}>"     # exact instantiation
         else:
-            key = re.sub(r"\(.*", "", name).split("::")[-1].split("<")[0].replace("void ", "")
+            base = name.replace("(anonymous namespace)::", "").replace("void ", "")
+            key = re.sub(r"\(.*", "", base).split("::")[-1].strip()            # keeps template arguments, e.g. gn_gelu_bwd_reg<1, 4, 9>
         e = agg[key]
         e[0] += 1
         e[1] += float(r["Counter_Value"])

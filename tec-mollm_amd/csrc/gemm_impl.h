@@ -168,6 +168,9 @@ struct Stager {
   int64_t didx[DROP ? NV : 1];            // dropout index of the vector's first element
   // --- window view state
   WinRow wr[(WIN && !ROWK) ? NV : 1];     // fixed rows (A-window)
+  // ROWK window (weight-gradient form: the view's rows are the reduction index): (n, t_out, b) of the row each
+  // vector reads next, advanced by BK rows per K-tile without the two integer divisions of win_row()
+  int32_t rn[(WIN && ROWK) ? NV : 1], rt[(WIN && ROWK) ? NV : 1], rb[(WIN && ROWK) ? NV : 1];
   int32_t tap, c;                         // per-thread tap / channel of the inner index (kk = tap*Cw + c)
   int32_t kk;                             // ROWK=false: current inner index k0 + cv
 
@@ -213,6 +216,14 @@ struct Stager {
         inner_ok = inner < fixed_lim;
         tap = inner / w.Cw;
         c = inner - tap * w.Cw;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const uint32_t row = (uint32_t)(kbeg + r0 + i * RSTEP);
+          const uint32_t q = row / (uint32_t)w.N;
+          rn[i] = (int32_t)(row - q * (uint32_t)w.N);
+          rb[i] = (int32_t)(q / (uint32_t)w.Lout);
+          rt[i] = (int32_t)(q - (uint32_t)rb[i] * (uint32_t)w.Lout);
+        }
       }
     }
   }
@@ -273,13 +284,18 @@ struct Stager {
       } else {
 #pragma unroll
         for (int i = IB; i < IE; ++i) {
-          const WinRow rr = win_row(w, (int64_t)k0 + r0 + i * RSTEP, klim);
-          const int32_t t_in = rr.t0 + tap;
-          const bool ok = inner_ok && t_in >= 0 && t_in < w.Lin;
-          const int64_t row = rr.srow + (int64_t)tap * w.N;
+          // row k0 + r0 + i*RSTEP of the view = (rb, rt, rn); same result as win_row(), no divisions
+          const int32_t t_in = rt[i] * w.stride_t - w.pad + tap;
+          const bool ok = inner_ok && (k0 + r0 + i * RSTEP) < klim && t_in >= 0 && t_in < w.Lin;
+          const int64_t row = ((int64_t)rb[i] * w.Lin + t_in) * (int64_t)w.N + rn[i];
           gload<VEC>(P + row * ld + c, P, ok, tl.regs[i]);
           tl.okbits = (tl.okbits & ~(1u << i)) | ((ok ? 1u : 0u) << i);
           if constexpr (DROP) tl.dsave[i] = row * dc.ld + c;
+          rn[i] += BK;                                       // the next K-tile is BK view rows further
+          while (rn[i] >= w.N) {
+            rn[i] -= w.N;
+            if (++rt[i] >= w.Lout) { rt[i] = 0; ++rb[i]; }
+          }
         }
       }
     }

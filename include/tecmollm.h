@@ -211,6 +211,12 @@ int tecm_conv_weight_pack(const float* w, float* fwd_pack, float* bwd_pack, int3
 int tecm_conv_weight_unpack(const float* dpack, float* dw, int32_t Cout, int32_t Cin, int32_t k,
                             void* stream);
 
+/* dst[r][c] = src[r][c] * keep(seed, r*drop.ld + c) / (1 - p): the counter-based dropout mask every kernel of this
+ * library recomputes (F.dropout of tec_mollm.py:115, GPT-2's embd dropout), materialised once where the masked
+ * tensor is consumed several times.  cols, ld_src, ld_dst multiples of 4; 16-byte aligned. */
+int tecm_dropout_apply(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t rows, int32_t cols,
+                       const TecmDrop* drop, void* stream);
+
 /* dst[r*ldd + c] = scale * src[c*lds + r]  (r < rows, c < cols): builds the K-extended c_attn weight
  * [W ; (alpha/r) * B^T] (modules.py:177-183) and other small transposes. */
 int tecm_transpose_scale(const float* src, int64_t lds, float* dst, int64_t ldd, int32_t rows,

@@ -72,7 +72,40 @@ __global__ __launch_bounds__(256) void transpose_scale_kernel(const float* __res
   }
 }
 
+// dst = dropout(src, drop): element (r, c) keeps iff hash(seed, r*drop.ld + c) passes; float4 streaming copy
+__global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restrict__ src, int64_t lds_, float* __restrict__ dst,
+                                                            int64_t ldd, int64_t rows, int32_t cols4, uint64_t seed,
+                                                            int64_t dld, uint32_t thresh, float inv) {
+  const int64_t total = rows * cols4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / cols4;
+    const int32_t c = (int32_t)(i - r * cols4) * 4;
+    float4 v = *reinterpret_cast<const float4*>(src + r * lds_ + c);
+    const uint64_t di = (uint64_t)(r * dld + c);
+    v.x *= tecm_drop_mult(seed, di, thresh, inv);
+    v.y *= tecm_drop_mult(seed, di + 1, thresh, inv);
+    v.z *= tecm_drop_mult(seed, di + 2, thresh, inv);
+    v.w *= tecm_drop_mult(seed, di + 3, thresh, inv);
+    *reinterpret_cast<float4*>(dst + r * ldd + c) = v;
+  }
+}
+
 }  // namespace
+
+extern "C" int tecm_dropout_apply(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t rows, int32_t cols,
+                                  const TecmDrop* drop, void* stream) {
+  TECM_REQUIRE(src && dst && drop, TECM_E_ARG, "tecm_dropout_apply: null pointer");
+  TECM_REQUIRE(rows > 0 && cols > 0 && drop->p > 0.f && drop->p < 1.f, TECM_E_ARG, "tecm_dropout_apply: bad shape / p");
+  TECM_REQUIRE(cols % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0 && tecm_aligned(src, 16) && tecm_aligned(dst, 16),
+               TECM_E_ALIGN, "tecm_dropout_apply: rows must be 16-byte friendly");
+  const int64_t total = rows * (cols / 4);
+  const int64_t want = (total + 255) / 256;
+  hipLaunchKernelGGL(dropout_apply_kernel, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, (hipStream_t)stream, src,
+                     ld_src, dst, ld_dst, rows, cols / 4, drop->seed, drop->ld, tecm_drop_thresh(drop->p),
+                     1.0f / (1.0f - drop->p));
+  TECM_CHECK_LAUNCH("tecm_dropout_apply");
+  return TECM_OK;
+}
 
 extern "C" int tecm_huber_fwd_bwd(const float* pred, const float* target, float* dpred, float* loss_out, int64_t n,
                                   float delta, float grad_scale, float* workspace, void* stream) {

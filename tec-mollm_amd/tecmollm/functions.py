@@ -252,18 +252,22 @@ class PatchEmbedFn(torch.autograd.Function):
         K = patch_len * D
         dh0 = dh0.contiguous()
         w = win(N, Lc, P, patch_len, patch_len, D, 0)
-        dbp = colsum(dh0, d_llm, M, 1, 1, d_llm, in_drop=dspec)[0]
+        # the embd-dropout mask of the forward epilogue, applied once: the masked gradient feeds two column sums and
+        # two GEMMs
+        if dspec is not None:
+            dh0 = ops.dropout_apply(dh0, M, d_llm, dspec)
+        dbp = colsum(dh0, d_llm, M, 1, 1, d_llm)[0]
         dwpe = None
         if has_wpe:
             dwpe = torch.zeros_like(wpe)
-            colsum(dh0, d_llm, B, N, P, d_llm, in_drop=dspec, out=dwpe)      # rows 0..P-1 of wpe
+            colsum(dh0, d_llm, B, N, P, d_llm, out=dwpe)                     # rows 0..P-1 of wpe
         dWp = _empty(d_llm, K, like=conv)
-        gemm(d_llm, K, M, dh0, d_llm, conv, D, dWp, K, a_layout=A_KM, b_layout=B_KN, b_win=w, a_drop=dspec,
+        gemm(d_llm, K, M, dh0, d_llm, conv, D, dWp, K, a_layout=A_KM, b_layout=B_KN, b_win=w,
              split_k=pick_split_k(d_llm, K, M), bf16=plan.bf16)
         dconv = _empty(B, Lc, N, D, like=conv)
         if P * patch_len != Lc:
             dconv.zero_()
-        gemm(M, K, d_llm, dh0, d_llm, Wp, K, dconv, D, b_layout=B_KN, c_win=w, a_drop=dspec, bf16=plan.bf16)
+        gemm(M, K, d_llm, dh0, d_llm, Wp, K, dconv, D, b_layout=B_KN, c_win=w, bf16=plan.bf16)
         return dconv, dWp, dbp, dwpe, None, None
 
 
@@ -441,11 +445,15 @@ class HeadFn(torch.autograd.Function):
         hspec = plan.spec(SITE_HEAD, Hd)
         pre = _empty(S, Hd, like=hid)
         h1 = _empty(S, Hd, like=hid)
-        gemm(S, Hd, K1, hid, D, W1, K1, h1, Hd, a_win=w, a_drop=pspec, bias=b1, preact=(pre, Hd), act=ACT_GELU_ERF,
+        hid = hid.contiguous()
+        # F.dropout(hid) is read by the forward GEMM (once per 128-column tile) and again by the W1 gradient: mask it
+        # once (one streaming pass) instead of hashing every element in both GEMM loaders
+        hd = ops.dropout_apply(hid, B * T * N, D, pspec) if pspec is not None else hid
+        gemm(S, Hd, K1, hd, D, W1, K1, h1, Hd, a_win=w, bias=b1, preact=(pre, Hd), act=ACT_GELU_ERF,
              out_drop=hspec, bf16=plan.bf16)
         pred = _empty(B, N, Lo, like=hid)
         gemm(S, Lo, Hd, h1, Hd, W2, Hd, pred, Lo, bias=b2, bf16=plan.bf16)
-        ctx.save_for_backward(hid, W1, W2, pre, h1)
+        ctx.save_for_backward(hd, W1, W2, pre, h1)
         ctx.meta = (B, T, N, D, Hd, K1, Lo, w, pspec, hspec)
         ctx.plan = plan
         return pred
@@ -465,7 +473,7 @@ class HeadFn(torch.autograd.Function):
              out_drop=hspec, bf16=plan.bf16)
         db1 = colsum(dpre, Hd, S, 1, 1, Hd)[0]
         dW1 = _empty(Hd, K1, like=hid)
-        gemm(Hd, K1, S, dpre, Hd, hid, D, dW1, K1, a_layout=A_KM, b_layout=B_KN, b_win=w, b_drop=pspec,
+        gemm(Hd, K1, S, dpre, Hd, hid, D, dW1, K1, a_layout=A_KM, b_layout=B_KN, b_win=w,       # hid = dropout(hid) here
              split_k=pick_split_k(Hd, K1, S), bf16=plan.bf16)
         dhid = _empty(B, T, N, D, like=hid)
         gemm(S, K1, Hd, dpre, Hd, W1, K1, dhid, D, b_layout=B_KN, c_win=w, out_drop=pspec, bf16=plan.bf16)

@@ -307,6 +307,15 @@ def colsum(inp: torch.Tensor, ld: int, outer: int, inner: int, nseg: int, Cn: in
     return out
 
 
+def dropout_apply(src: torch.Tensor, rows: int, cols: int, spec: TecmDrop, ld: Optional[int] = None) -> torch.Tensor:
+    """dropout(src) with the library's counter-based mask (index = row*spec.ld + col) as a new contiguous tensor."""
+    dst = torch.empty_like(src)
+    ld = cols if ld is None else ld
+    check(lib().tecm_dropout_apply(src.data_ptr(), ld, dst.data_ptr(), ld, rows, cols, C.byref(spec), stream_ptr()),
+          "tecm_dropout_apply")
+    return dst
+
+
 def huber_fwd_bwd(pred: torch.Tensor, target: torch.Tensor, delta: float = 1.0, grad_scale: float = 1.0,
                   want_grad: bool = True) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     n = pred.numel()

@@ -352,3 +352,38 @@ def test_full_size_batch_of_8_properties(dev):
         return model(xd[:2], tfd[:2], ei)
     a, b_, c, d_ = run(11, 0), run(11, 0), run(12, 0), run(11, 1)
     assert torch.equal(a, b_) and not torch.equal(a, c) and not torch.equal(a, d_)
+
+
+@pytest.mark.parametrize("kind", ["no_edges", "irregular"])
+def test_spatial_irregular_graphs(dev, kind):
+    """Graphs a lat/lon grid never produces: no edges at all (every node sees only its implicit self loop), and a
+    random directed multigraph with duplicate edges (kept, PyG semantics), explicit self loops (stripped and re-added
+    once), isolated nodes, one high-degree hub and long-range edges (wide LDS windows).  Forward and all gradients
+    against the oracle."""
+    N, B, L = 150, 2, 3
+    cfg = R.default_config(num_nodes=N)
+    p = R.init_params(cfg, seed=8)
+    x, tf, _ = R.synthetic_batch(B, L, N, cfg["spatial_in_channels_base"], 12, seed=9)
+    g = torch.Generator().manual_seed(10)
+    if kind == "no_edges":
+        ei = torch.zeros(2, 0, dtype=torch.int64)
+    else:
+        src = torch.randint(0, N, (400,), generator=g)
+        dst = torch.randint(0, N, (400,), generator=g)
+        dst[dst == 7] = 8                                       # node 7: no in-edges
+        hub = torch.stack([torch.arange(40, 100), torch.full((60,), 3)])          # node 3: 60 extra in-edges
+        loops = torch.stack([torch.arange(0, 20), torch.arange(0, 20)])           # explicit self loops
+        dup = torch.stack([src[:50], dst[:50]])                                    # duplicates
+        ei = torch.cat([torch.stack([src, dst]), hub, loops, dup], 1)
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items() if k.startswith((R.P_EMB, R.P_GAT))}
+    ref = R.spatial(R.embed(x, tf, pr), ei, pr, 2, None)
+    ref_tm = ref.view(L, B, N, 22).permute(1, 0, 2, 3)
+    out, ps, names = _run_spatial(p, x, tf, ei, dev, B * L)
+    assert rel_err(out[..., :22], ref_tm) < TOL
+    gout = torch.randn(B, L, N, 22, generator=torch.Generator().manual_seed(11))
+    gref = torch.autograd.grad(ref_tm, [pr[n] for n in names], gout)
+    gpad = torch.zeros(B, L, N, 24)
+    gpad[..., :22] = gout
+    ghip = torch.autograd.grad(out, ps, gpad.to(dev))
+    for n, a, b in zip(names, ghip, gref):
+        assert rel_err(a, b) < TOL, n

@@ -246,7 +246,8 @@ def main():
                                    f"F={args.c_in} (d_emb={22 - args.c_in}), full fwd+bwd+AdamW, "
                                    f"{PRECISION_TEXT[args.precision]}, "
                                    f"GATv2 {args.gat}, dropout {'off' if args.eval_mode else 'on (p=0.1)'}",
-                       "global_batch": B * world, "parallelism": f"dp{world}", "final_loss": round(float(loss), 5)},
+                       "global_batch": B * world, "parallelism": f"dp{world}", "final_loss": round(float(loss), 5),
+                       "peak_hbm_gb_per_gpu": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -189,6 +189,9 @@ struct TStager {
   uint32_t okbits;                                    // bit 2i: row 2kp valid, bit 2i+1: row 2kp+1 valid
   int64_t didx[DROP ? NI : 1], dsave[DROP ? NI : 1], dsave_hi[DROP ? NI : 1];
   int32_t tap, c, inner;
+  // window view (weight-gradient form): (n, t_out, b) of view row k0 + 2*(kp0 + i*KSTEP), advanced by BK rows per
+  // K-tile instead of two integer divisions per row per tile
+  int32_t rn[WIN ? NI : 1], rt[WIN ? NI : 1], rb[WIN ? NI : 1];
 
   __device__ __forceinline__ void init(const float* __restrict__ P, const TecmWin& w, int64_t ld, int32_t kbeg,
                                        int64_t fixed0, int64_t fixed_lim, const DropCtx& dc) {
@@ -211,6 +214,14 @@ struct TStager {
     } else if constexpr (WIN) {
       tap = inner / w.Cw;
       c = inner - tap * w.Cw;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const uint32_t row = (uint32_t)(kbeg + 2 * (kp0 + i * KSTEP));
+        const uint32_t q = row / (uint32_t)w.N;
+        rn[i] = (int32_t)(row - q * (uint32_t)w.N);
+        rb[i] = (int32_t)(q / (uint32_t)w.Lout);
+        rt[i] = (int32_t)(q - (uint32_t)rb[i] * (uint32_t)w.Lout);
+      }
     }
   }
   template <int IB, int IE>
@@ -232,15 +243,24 @@ struct TStager {
         if constexpr (DROP) { dsave[i] = didx[i]; dsave_hi[i] = didx[i] + dc.ld; didx[i] += (int64_t)BK * dc.ld; }
         ptr[i] += (int64_t)BK * ld;
       } else {
-        // window rows are the reduction index (weight-gradient form): decompose both k rows
-        const WinRow ra = win_row(w, krow, klim), rb = win_row(w, krow + 1, klim);
-        const int32_t ta = ra.t0 + tap, tb = rb.t0 + tap;
-        ok0 = inner_ok && ta >= 0 && ta < w.Lin;
-        ok1 = inner_ok && tb >= 0 && tb < w.Lin;
-        const int64_t rowa = ra.srow + (int64_t)tap * w.N, rowb = rb.srow + (int64_t)tap * w.N;
-        gload<4>(P + rowa * ld + c, P, ok0, lo);
-        gload<4>(P + rowb * ld + c, P, ok1, hi);
-        if constexpr (DROP) { dsave[i] = rowa * dc.ld + c; dsave_hi[i] = rowb * dc.ld + c; }
+        // window rows are the reduction index (weight-gradient form): view rows krow and krow + 1
+        if constexpr (WIN) {
+          int32_t n1 = rn[i] + 1, t1 = rt[i], b1 = rb[i];                  // row krow + 1
+          if (n1 >= w.N) { n1 = 0; if (++t1 >= w.Lout) { t1 = 0; ++b1; } }
+          const int32_t ta = rt[i] * w.stride_t - w.pad + tap, tb = t1 * w.stride_t - w.pad + tap;
+          ok0 = inner_ok && krow < klim && ta >= 0 && ta < w.Lin;
+          ok1 = inner_ok && krow + 1 < klim && tb >= 0 && tb < w.Lin;
+          const int64_t rowa = ((int64_t)rb[i] * w.Lin + ta) * (int64_t)w.N + rn[i];
+          const int64_t rowb = ((int64_t)b1 * w.Lin + tb) * (int64_t)w.N + n1;
+          gload<4>(P + rowa * ld + c, P, ok0, lo);
+          gload<4>(P + rowb * ld + c, P, ok1, hi);
+          if constexpr (DROP) { dsave[i] = rowa * dc.ld + c; dsave_hi[i] = rowb * dc.ld + c; }
+          rn[i] += BK;                                                      // next K-tile
+          while (rn[i] >= w.N) {
+            rn[i] -= w.N;
+            if (++rt[i] >= w.Lout) { rt[i] = 0; ++rb[i]; }
+          }
+        }
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) { regs[i][e] = lo[e]; regs[i][4 + e] = hi[e]; }

@@ -380,8 +380,11 @@ class GPT2StackFn(torch.autograd.Function):
         # every LayerNorm backward also emits dropout(dx) for the GEMM that sits behind the next resid dropout
         sp = plan.spec(site_res2(n_layers - 1), D)
         dhm = _empty(M, D, like=dout) if sp is not None else dh
+        nig = ctx.needs_input_grad                        # (h0, n_layers, plan, *params): params start at index 3
+        base_f = 3 + n_layers * GPT2StackFn.PER_LAYER
         dlnfw, dlnfb = ops.layernorm_bwd(dout, D, h_last, D, lnfw, stf, None, dh, M, D,
-                                         dx_masked=dhm if sp is not None else None, mask_drop=sp)
+                                         dx_masked=dhm if sp is not None else None, mask_drop=sp,
+                                         need_dgb=nig[base_f] or nig[base_f + 1])
         pgrads: List[Optional[torch.Tensor]] = [None] * (n_layers * GPT2StackFn.PER_LAYER)
         for i in reversed(range(n_layers)):
             (ln1w, ln1b, Wqkv, bqkv, lA, lB, Wo, bo, ln2w, ln2b, Wfc, bfc, Wpr,
@@ -397,8 +400,10 @@ class GPT2StackFn(torch.autograd.Function):
             dh2 = _empty(M, D, like=dh)
             sp = plan.spec(site_res1(i), D)
             dh2m = dhm if sp is not None else dh2             # dhm is dead once da has been formed
+            pb = 3 + i * GPT2StackFn.PER_LAYER
             dg2, db2 = ops.layernorm_bwd(du2, D, h2, D, ln2w, st2, dh, dh2, M, D,
-                                         dx_masked=dh2m if sp is not None else None, mask_drop=sp)
+                                         dx_masked=dh2m if sp is not None else None, mask_drop=sp,
+                                         need_dgb=nig[pb + 8] or nig[pb + 9])
             # attention: h2 = h + drop(ctx Wo + b)
             dcx = du2                                         # reuse buffer
             gemm(M, D, D, dh2m, D, Wo, D, dcx, D, bf16=plan.bf16)
@@ -419,7 +424,8 @@ class GPT2StackFn(torch.autograd.Function):
             sp = plan.spec(site_res2(i - 1), D) if i > 0 else None
             dhm = _empty(M, D, like=dh) if sp is not None else dhn
             dg1, db1 = ops.layernorm_bwd(du, KE, h, D, ln1w, st1, dh2, dhn, M, D,
-                                         dx_masked=dhm if sp is not None else None, mask_drop=sp)
+                                         dx_masked=dhm if sp is not None else None, mask_drop=sp,
+                                         need_dgb=nig[pb + 0] or nig[pb + 1])
             dh = dhn
             base = i * GPT2StackFn.PER_LAYER
             pgrads[base + 0], pgrads[base + 1] = dg1, db1

@@ -244,8 +244,9 @@ def layernorm_bwd_blocks(M: int, D: int) -> int:
 def layernorm_bwd(dy: torch.Tensor, lddy: int, x: torch.Tensor, ldx: int, gamma: torch.Tensor, stats: torch.Tensor,
                   dres: Optional[torch.Tensor], dx: torch.Tensor, M: int, D: int,
                   dx_masked: Optional[torch.Tensor] = None,
-                  mask_drop: Optional[TecmDrop] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """dx = dres + LN'(dy); optional dx_masked = dropout(dx, mask_drop).  Returns (dgamma, dbeta)."""
+                  mask_drop: Optional[TecmDrop] = None, need_dgb: bool = True):
+    """dx = dres + LN'(dy); optional dx_masked = dropout(dx, mask_drop).  Returns (dgamma, dbeta), or (None, None)
+    when need_dgb is False (frozen LayerNorm: the per-block partials are not reduced)."""
     nb = layernorm_bwd_blocks(M, D)
     partials = torch.empty(nb, 2 * D, device=dx.device, dtype=torch.float32)
     nbc = C.c_int32(0)
@@ -253,6 +254,8 @@ def layernorm_bwd(dy: torch.Tensor, lddy: int, x: torch.Tensor, ldx: int, gamma:
     check(lib().tecm_layernorm_bwd(dy.data_ptr(), lddy, x.data_ptr(), ldx, gamma.data_ptr(), stats.data_ptr(),
                                    ptr(dres), dx.data_ptr(), ptr(dx_masked), C.byref(od), partials.data_ptr(),
                                    C.byref(nbc), M, D, stream_ptr()), "tecm_layernorm_bwd")
+    if not need_dgb:
+        return None, None
     dgb = colsum(partials, 2 * D, nb, 1, 1, 2 * D)
     return dgb[0, :D], dgb[0, D:]
 

@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-other-precisions", action="store_true",
+                    help="skip the short informational runs of the other precision modes (N=1, default flags only)")
     return ap.parse_args()
 
 
@@ -149,6 +151,32 @@ def rmse_vs_ref(cfg, args, dev, ref):
     return {"rmse_vs_ref": m["rmse_avg"], "mae_vs_ref": m["mae_avg"], "r2_vs_ref": m["r2_score_avg"],
             "pearson_vs_ref": m["pearson_r_avg"], "max_rel_err": rel, "ref_rms": float(want.pow(2).mean().sqrt()),
             "sample": f"eval forward at B={B} on the cpu_baseline batch, scaled units, {out.shape[1]} horizons"}
+
+
+def other_precision(cfg, args, dev, mode, x, tf, ei, ew, y):
+    """samples/s of the same step in another precision mode of the library:
+    "bf16x6" = fp32 emulated by six bf16 MFMAs per product (measured GEMM error equal to the exact kernel's),
+    "bf16x3" = three products (~5e-6), "bf16" = autocast semantics (BASELINE configs[2])."""
+    from src.model.tec_mollm import TEC_MoLLM
+    from tecmollm.train import TrainStep
+    mc = dict(cfg, gat_graphs=args.gat, include_wte=False, load_pretrained_gpt2=False, precision=mode)
+    torch.manual_seed(0)
+    model = TEC_MoLLM(mc)
+    with torch.no_grad():
+        for blk in model.llm_backbone.trunk.h:
+            blk.attn.c_attn.lora_B.default.weight.normal_(std=0.02)
+    model = model.to(dev)
+    model.train(not args.eval_mode)
+    ts = TrainStep(model, world_size=1)
+    for _ in range(2):
+        ts.step(x, tf, ei, ew, y)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        ts.step(x, tf, ei, ew, y)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"samples_per_s": round(5 * x.shape[0] / dt, 2), "ms_per_step": round(dt / 5 * 1e3, 2)}
 
 
 def main():
@@ -253,6 +281,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"], ref = cpu_baseline(cfg, args)
             line["parity"] = rmse_vs_ref(cfg, args, dev, ref)
+        if world == 1 and args.precision == "fp32" and not args.no_other_precisions:
+            # informational only -- `value` above is the exact-fp32 number.  Same workload, 5 timed steps each.
+            line["other_precisions"] = {m: other_precision(cfg, args, dev, m, x, tf, ei, ew, y)
+                                        for m in ("bf16x6", "bf16x3", "bf16")}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

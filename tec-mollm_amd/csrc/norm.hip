@@ -702,13 +702,20 @@ __global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ w
   const int c = blockIdx.x * 64 + lane, s = blockIdx.y;
   float acc = 0.f;
   if (c < C) {
-    float a4[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int rb = wave; rb < RB; rb += 16) {
+    // up to 1024 partial rows: sixteen loads in flight per lane, or the pass is a chain of dependent-latency steps
+    float a16[16];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (rb + 4 * u < RB) a4[u] += ws[((int64_t)s * RB + rb + 4 * u) * C + c];
+    for (int u = 0; u < 16; ++u) a16[u] = 0.f;
+    for (int rb = wave; rb < RB; rb += 64) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (rb + 4 * u < RB) a16[u] += ws[((int64_t)s * RB + rb + 4 * u) * C + c];
     }
-    acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+#pragma unroll
+    for (int u = 8; u > 0; u >>= 1)
+#pragma unroll
+      for (int v = 0; v < u; ++v) a16[v] += a16[v + u];
+    acc = a16[0];
   }
   red[wave][lane] = acc;
   __syncthreads();

@@ -580,7 +580,9 @@ __global__ __launch_bounds__(threads_for(BN), (AVEC == 4 && BVEC == 4) ? (thread
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
   // grouped order inside the XCD's run: 8 m-tiles x all n-tiles per group, m fastest, so the ~64 blocks
   // resident on one XCD form an (8 m) x (8 n) super-tile whose A and B panels both live in that XCD's 4 MiB L2
-  const int GROUP_M = g._p1 > 0 ? g._p1 : 8;          // m-tiles per group (host-tunable: TecmGemm::_p1)
+  // m-tiles per group (host-tunable: TecmGemm::_p1).  Default from the measured L2-miss volume:
+  // 2 when the matrix is at most 8 tiles wide (N = 768 / 800: 1.3 GB per launch instead of 1.7), 8 otherwise
+  const int GROUP_M = g._p1 > 0 ? g._p1 : (tiles_n <= 8 ? 2 : 8);
   const int per_group = GROUP_M * tiles_n;
   const int group = wg / per_group;
   const int first_m = group * GROUP_M;

@@ -33,7 +33,7 @@ extern "C" {
 #define TECM_E_LAUNCH (-3)     /* hipGetLastError() != hipSuccess after the launch       */
 #define TECM_E_LDS (-4)        /* problem does not fit the 160 KiB LDS budget            */
 
-#define TECM_ABI_VERSION 2
+#define TECM_ABI_VERSION 3
 int tecm_abi_version(void);
 /* Human-readable text for the last error on this thread (host pointer, never NULL). */
 const char* tecm_last_error(void);
@@ -77,9 +77,18 @@ enum { TECM_ACT_NONE = 0, TECM_ACT_GELU_ERF = 1, TECM_ACT_GELU_TANH = 2 };
  *   if preact: preact[m*ldp+n] = v;  v = act(v);  if dact_src: v *= act'(dact_src[m*ldd+n]);
  *   v = dropout(v, out_drop);  if residual: v += residual[m*ldr+n];  if accumulate: v += C[m,n];
  *   store C (through c_win when enabled: column n is the inner index kk of the view). */
+/* io_bf16 (tecm_gemm_bf16 only, 0 everywhere else): which tensors of the call already are / shall be bf16 in HBM.
+ * A bf16 operand is [row][k] with k contiguous and its leading dimension counted in bf16 elements (multiple of 8,
+ * 16-byte aligned, K % 8 == 0); the call must be the plain MK x NK contraction.  TECM_IO_C_BF16 writes C as bf16
+ * (ldc in bf16 elements; needs the float4-friendly epilogue, no residual / accumulate / c_win / split_k); preact,
+ * dact_src, bias stay fp32.  Rounding an activation once where it is produced instead of at every consumer's
+ * loader gives bit-identical results at half the bytes. */
+#define TECM_IO_A_BF16 1
+#define TECM_IO_B_BF16 2
+#define TECM_IO_C_BF16 4
 typedef struct TecmGemm {
   int64_t M, N, K;
-  const float* A; int64_t lda; int32_t a_layout; int32_t _p0; TecmWin a_win; TecmDrop a_drop;
+  const float* A; int64_t lda; int32_t a_layout; int32_t io_bf16; TecmWin a_win; TecmDrop a_drop;
   const float* B; int64_t ldb; int32_t b_layout; int32_t _p1; TecmWin b_win; TecmDrop b_drop;
   float* C; int64_t ldc; TecmWin c_win;
   float alpha; int32_t act;

@@ -112,16 +112,20 @@ static int gemm_entry(const TecmGemm* d, void* stream, int mode) {
   TECM_REQUIRE(g.a_layout == TECM_A_MK || g.b_layout == TECM_B_KN, TECM_E_ARG,
                "tecm_gemm_f32: layout combination KM x NK is not built");
   hipStream_t st = (hipStream_t)stream;
-  const int avec = pick_vec(g.A, g.lda, g.a_win, g.a_layout == TECM_A_MK, g.K);
-  const int bvec = pick_vec(g.B, g.ldb, g.b_win, g.b_layout == TECM_B_NK, g.K);
+  int avec = pick_vec(g.A, g.lda, g.a_win, g.a_layout == TECM_A_MK, g.K);
+  int bvec = pick_vec(g.B, g.ldb, g.b_win, g.b_layout == TECM_B_NK, g.K);
+  if (g.io_bf16 & TECM_IO_A_BF16) avec = 4;            // bf16 operands are checked separately below
+  if (g.io_bf16 & TECM_IO_B_BF16) bvec = 4;
   const bool win = g.a_win.enabled || g.b_win.enabled;
   const bool drop = g.a_drop.p > 0.f || g.b_drop.p > 0.f;
   // float4 epilogue only when everything it touches is 16-byte friendly
   auto ok4 = [](const void* p, int64_t ld) { return p == nullptr || (tecm_aligned(p, 16) && ld % 4 == 0); };
-  const bool vec4 = g.N % 4 == 0 && ok4(g.C, g.ldc) && ok4(g.bias, 4) && ok4(g.rowbias, g.rb_ld) &&
+  const bool c16 = (g.io_bf16 & TECM_IO_C_BF16) != 0;
+  const bool vec4 = g.N % 4 == 0 && (c16 ? (tecm_aligned(g.C, 8) && g.ldc % 4 == 0) : ok4(g.C, g.ldc)) && ok4(g.bias, 4) && ok4(g.rowbias, g.rb_ld) &&
                     ok4(g.preact, g.ldp) && ok4(g.dact_src, g.ldd) && ok4(g.residual, g.ldr) &&
                     (!g.c_win.enabled || g.c_win.Cw % 4 == 0) &&
                     (g.split_k <= 1 || tecm_aligned(g.workspace, 16));
+  if (c16) TECM_REQUIRE(vec4, TECM_E_ALIGN, "tecm_gemm_bf16: bf16 C needs 16-byte friendly epilogue operands");
   if (bf16)
     TECM_REQUIRE(avec == 4 && bvec == 4, TECM_E_ALIGN,
                  "tecm_gemm_bf16: operands must be 16-byte aligned with leading dims / K / Cw multiples of 4");
@@ -131,8 +135,24 @@ static int gemm_entry(const TecmGemm* d, void* stream, int mode) {
     TECM_REQUIRE(avec == 4 && bvec == 4, TECM_E_ALIGN,
                  "tecm_gemm_bf16x3: operands must be 16-byte aligned with leading dims / K multiples of 4");
   }
-  TecmGemm gk = g;                 // private copy: _p0 carries the epilogue-vectorisation flag to the kernel
-  gk._p0 = vec4 ? 1 : 0;
+  const int io = g.io_bf16 & (TECM_IO_A_BF16 | TECM_IO_B_BF16 | TECM_IO_C_BF16);
+  TECM_REQUIRE(io == g.io_bf16, TECM_E_ARG, "tecm_gemm: unknown io_bf16 bits");
+  if (io) {
+    TECM_REQUIRE(bf16, TECM_E_ARG, "tecm_gemm: bf16 tensors in HBM are served by tecm_gemm_bf16 only");
+    if (io & (TECM_IO_A_BF16 | TECM_IO_B_BF16))
+      TECM_REQUIRE(g.a_layout == TECM_A_MK && g.b_layout == TECM_B_NK && !win && !drop && g.K % 8 == 0, TECM_E_ARG,
+                   "tecm_gemm_bf16: bf16 operands need the plain MK x NK contraction with K %% 8 == 0");
+    if (io & TECM_IO_A_BF16)
+      TECM_REQUIRE(tecm_aligned(g.A, 16) && g.lda % 8 == 0, TECM_E_ALIGN, "tecm_gemm_bf16: bf16 A must be 16-byte friendly");
+    if (io & TECM_IO_B_BF16)
+      TECM_REQUIRE(tecm_aligned(g.B, 16) && g.ldb % 8 == 0, TECM_E_ALIGN, "tecm_gemm_bf16: bf16 B must be 16-byte friendly");
+    if (io & TECM_IO_C_BF16)
+      TECM_REQUIRE(vec4 && !g.residual && !g.accumulate && !g.c_win.enabled && g.split_k <= 1 &&
+                       g.act != TECM_ACT_GELU_ERF,
+                   TECM_E_ARG, "tecm_gemm_bf16: bf16 C needs a 16-byte friendly plain epilogue");
+  }
+  TecmGemm gk = g;                 // private copy: io_bf16 also carries the epilogue-vectorisation flag to the kernel
+  gk.io_bf16 = io | (vec4 ? TECM_P0_VEC4 : 0);
   const bool erf = g.act == TECM_ACT_GELU_ERF;
   if (erf) {                       // GEMM writes the pre-activation, erf_post_kernel finishes (see above)
     TECM_REQUIRE(!g.residual && !g.accumulate && !g.c_win.enabled, TECM_E_ARG,

@@ -15,6 +15,7 @@
 //     of tile t (same pipeline as the fp32 kernel).
 #pragma once
 #include "gemm_impl.h"
+#include <type_traits>
 
 namespace tecm_gemm16 {
 
@@ -325,6 +326,80 @@ struct TStager {
   }
 };
 
+// bf16 source stager: the operand already lives in HBM as bf16, [row][k] with k contiguous (activations written
+// as bf16 by the producing kernel, cached bf16 copies of the frozen weights).  Pure copy: one 16-byte load and one
+// ds_write_b128 per 8 k -- no conversion VALU, half the bytes.  Plain view only (no window / dropout prologue).
+template <int ROWS>
+struct HStager {
+  static constexpr int VPR = BK / 8;                  // 8 vectors of 8 bf16 per row
+  static constexpr int NV = ROWS * VPR / NTH;         // 4 (A) or 2 (B)
+  static constexpr int RSTEP = NTH / VPR;             // 64 rows between a thread's vectors
+  static constexpr int NITEMS = NV;
+  uint4 regs[NV];
+  const __bf16* ptr[NV];
+  uint32_t okbits;
+  int32_t kk;
+
+  __device__ __forceinline__ void init(const float* __restrict__ P, const TecmWin&, int64_t ld, int64_t row0,
+                                       int64_t rows_total, int32_t kbeg, const DropCtx&) {
+    const __bf16* Ph = reinterpret_cast<const __bf16*>(P);
+    const int cv = (threadIdx.x % VPR) * 8;
+    const int r0 = threadIdx.x / VPR;
+    okbits = 0;
+    kk = kbeg + cv;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int64_t row = row0 + r0 + i * RSTEP;
+      row = row < rows_total ? row : rows_total - 1;  // clamped: feeds an accumulator row that is never stored
+      ptr[i] = Ph + row * ld + kbeg + cv;
+    }
+  }
+  template <int IB, int IE>
+  __device__ __forceinline__ void load_part(const float* __restrict__ P, const TecmWin&, int64_t, int32_t, int32_t klim,
+                                            const DropCtx&) {
+    if constexpr (IB >= IE) return;
+    const bool ok = kk < klim;                        // K % 8 == 0: a vector is entirely inside or outside
+    const __bf16* safe = reinterpret_cast<const __bf16*>(P);
+#pragma unroll
+    for (int i = IB; i < IE; ++i) {
+      regs[i] = *reinterpret_cast<const uint4*>(ok ? ptr[i] : safe);
+      okbits = (okbits & ~(1u << i)) | ((ok ? 1u : 0u) << i);
+      ptr[i] += BK;
+    }
+    if constexpr (IE == NV) kk += BK;
+  }
+  template <int IB, int IE>
+  __device__ __forceinline__ void load_steady(int64_t, const DropCtx&) {
+    if constexpr (IB >= IE) return;
+    if constexpr (IB == 0) okbits = ~0u;
+#pragma unroll
+    for (int i = IB; i < IE; ++i) {
+      regs[i] = *reinterpret_cast<const uint4*>(ptr[i]);
+      ptr[i] += BK;
+    }
+    if constexpr (IE == NV) kk += BK;
+  }
+  template <int IB, int IE>
+  __device__ __forceinline__ void store_part(__bf16* lds, const DropCtx&) {
+    if constexpr (IB >= IE) return;
+    const int cv = (threadIdx.x % VPR) * 8;
+    const int r0 = threadIdx.x / VPR;
+#pragma unroll
+    for (int i = IB; i < IE; ++i) {
+      const uint4 v = ((okbits >> i) & 1u) ? regs[i] : make_uint4(0u, 0u, 0u, 0u);
+      *reinterpret_cast<uint4*>(lds + (r0 + i * RSTEP) * LDH + cv) = v;
+    }
+  }
+  template <int IB, int IE>
+  __device__ __forceinline__ void store_steady(__bf16* lds, const DropCtx&) {
+    if constexpr (IB >= IE) return;
+    const int cv = (threadIdx.x % VPR) * 8;
+    const int r0 = threadIdx.x / VPR;
+#pragma unroll
+    for (int i = IB; i < IE; ++i) *reinterpret_cast<uint4*>(lds + (r0 + i * RSTEP) * LDH + cv) = regs[i];
+  }
+};
+
 template <bool TRANS, int ROWS, bool WIN, bool DROP>
 struct StagerSel {
   using type = DStager<ROWS, WIN, DROP>;
@@ -334,14 +409,16 @@ struct StagerSel<true, ROWS, WIN, DROP> {
   using type = TStager<ROWS, WIN, DROP>;
 };
 
-template <int ALAY, int BLAY, bool WIN, bool DROP>
+template <int ALAY, int BLAY, bool WIN, bool DROP, int ADT = 0, int BDT = 0>      // ADT / BDT: 1 = the operand is bf16 in HBM
 __global__ __launch_bounds__(NTH, 2) void gemm_bf16_kernel(const TecmGemm g, int tiles_m, int tiles_n, int k_chunk) {
+  static_assert((ADT == 0 && BDT == 0) || (!WIN && !DROP && ALAY == TECM_A_MK && BLAY == TECM_B_NK),
+                "bf16 sources: plain MK x NK only");
   constexpr int WN = 2, WM = 4;
   constexpr int WTM = BM / WM, WTN = BN / WN;          // 64 x 64 per wave
   constexpr int MT = WTM / 32, NT = WTN / 32;
   constexpr bool ATR = ALAY == TECM_A_KM, BTR = BLAY == TECM_B_KN;
-  using AStager = typename StagerSel<ATR, BM, WIN, DROP>::type;
-  using BStager = typename StagerSel<BTR, BN, WIN, DROP>::type;
+  using AStager = std::conditional_t<ADT == 1, HStager<BM>, typename StagerSel<ATR, BM, WIN, DROP>::type>;
+  using BStager = std::conditional_t<BDT == 1, HStager<BN>, typename StagerSel<BTR, BN, WIN, DROP>::type>;
   constexpr int A_ELEMS = BM * LDH, B_ELEMS = BN * LDH, TILE_ELEMS = A_ELEMS + B_ELEMS;   // bf16 elements
   constexpr int STG_LD = WTN + 4;
   constexpr int STG_BYTES = 8 * 32 * STG_LD * 4;       // one 32-row slab per wave, fp32
@@ -470,7 +547,7 @@ __global__ __launch_bounds__(NTH, 2) void gemm_bf16_kernel(const TecmGemm g, int
       });
     });
     __syncthreads();
-    if (g._p0 != 0) {
+    if (g.io_bf16 & TECM_P0_VEC4) {
       constexpr int LPR = WTN / 4, RPI = 64 / LPR;
       const int lcol = (lane % LPR) * 4, lrow = lane / LPR;
       const EpiCol ecol = epi_col(g, n0 + wn * WTN + lcol);
@@ -511,7 +588,7 @@ __global__ __launch_bounds__(NTH, 2) void gemm_bf16_kernel(const TecmGemm g, int
   });
 }
 
-template <int ALAY, int BLAY, bool WIN, bool DROP>
+template <int ALAY, int BLAY, bool WIN, bool DROP, int ADT = 0, int BDT = 0>
 int launch(const TecmGemm& g, hipStream_t st) {
   const int tiles_m = (int)((g.M + BM - 1) / BM);
   const int tiles_n = (int)((g.N + BN - 1) / BN);
@@ -519,7 +596,7 @@ int launch(const TecmGemm& g, hipStream_t st) {
   int k_chunk = (int)(((g.K + splits - 1) / splits + BK - 1) / BK) * BK;
   splits = (int)((g.K + k_chunk - 1) / k_chunk);
   dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)splits);
-  hipLaunchKernelGGL((gemm_bf16_kernel<ALAY, BLAY, WIN, DROP>), grid, dim3(NTH), 0, st, g, tiles_m, tiles_n, k_chunk);
+  hipLaunchKernelGGL((gemm_bf16_kernel<ALAY, BLAY, WIN, DROP, ADT, BDT>), grid, dim3(NTH), 0, st, g, tiles_m, tiles_n, k_chunk);
   TECM_CHECK_LAUNCH("tecm_gemm_bf16");
   return splits;
 }

@@ -40,6 +40,9 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// TecmGemm::io_bf16 as the kernels see it: the caller's bits 0..2 (TECM_IO_*) plus the host-computed epilogue flag
+#define TECM_P0_VEC4 0x100      /* every pointer / leading dimension the epilogue touches is 16-byte friendly */
+
 namespace tecm_gemm {
 
 // compile-time loop: indices reach the body as integral constants, so register arrays indexed with
@@ -477,6 +480,13 @@ __device__ __forceinline__ void epi_vec4(const TecmGemm& g, const DropCtx& odc, 
     const float4 t = *reinterpret_cast<const float4*>(g.C + off);
     o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w;
   }
+  if (g.io_bf16 & TECM_IO_C_BF16) {       // the consumer is a bf16-source GEMM: round once here instead of at its loader
+    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+    bf16x4_t h;
+    h[0] = (__bf16)o[0]; h[1] = (__bf16)o[1]; h[2] = (__bf16)o[2]; h[3] = (__bf16)o[3];
+    *reinterpret_cast<bf16x4_t*>(reinterpret_cast<__bf16*>(g.C) + off) = h;
+    return;
+  }
   *reinterpret_cast<float4*>(g.C + off) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
@@ -486,7 +496,7 @@ __device__ __forceinline__ void epi_vec4(const TecmGemm& g, const DropCtx& odc, 
 // row by row in ONE rolled loop (small code: the epilogue is executed once per block and must not thrash the
 // instruction cache): row state is resolved once per row, a lane keeps its columns, and the global stores are
 // whole contiguous row segments (float4 per lane when the host found every pointer / leading dimension
-// 16-byte friendly: g._p0 == 1).
+// 16-byte friendly: g.io_bf16 == 1).
 template <int MT, int NT, int WTM, int WTN, int STG_LD>
 __device__ __forceinline__ void block_epilogue(const TecmGemm& g, f32x16 (&acc)[MT][NT], float* smem, int wave, int lane,
                                                int wm, int wn, int64_t m0, int64_t n0) {
@@ -505,7 +515,7 @@ __device__ __forceinline__ void block_epilogue(const TecmGemm& g, f32x16 (&acc)[
     });
   });
   __syncthreads();
-  if (g._p0 != 0) {
+  if (g.io_bf16 & TECM_P0_VEC4) {
     constexpr int LPR = WTN / 4;                       // lanes per row
     constexpr int RPI = 64 / LPR;                      // rows per iteration
     const int lcol = (lane % LPR) * 4, lrow = lane / LPR;

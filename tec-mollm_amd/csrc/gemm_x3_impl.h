@@ -291,7 +291,7 @@ __global__ __launch_bounds__(NTH, 2) void gemm_x3_kernel(const TecmGemm g, int t
       });
     });
     __syncthreads();
-    if (g._p0 != 0) {
+    if (g.io_bf16 & TECM_P0_VEC4) {
       constexpr int LPR = WTN / 4, RPI = 64 / LPR;
       const int lcol = (lane % LPR) * 4, lrow = lane / LPR;
       const EpiCol ecol = epi_col(g, n0 + wn * WTN + lcol);

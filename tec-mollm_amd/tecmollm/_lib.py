@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TECM_LIB", os.path.join(_HERE, "libtecmollm_hip.so"))   # override for experiments
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_f32p = C.c_void_p
 
@@ -29,7 +29,7 @@ class TecmDrop(C.Structure):
 class TecmGemm(C.Structure):
     _fields_ = [
         ("M", C.c_int64), ("N", C.c_int64), ("K", C.c_int64),
-        ("A", c_f32p), ("lda", C.c_int64), ("a_layout", C.c_int32), ("_p0", C.c_int32),
+        ("A", c_f32p), ("lda", C.c_int64), ("a_layout", C.c_int32), ("io_bf16", C.c_int32),
         ("a_win", TecmWin), ("a_drop", TecmDrop),
         ("B", c_f32p), ("ldb", C.c_int64), ("b_layout", C.c_int32), ("_p1", C.c_int32),
         ("b_win", TecmWin), ("b_drop", TecmDrop),

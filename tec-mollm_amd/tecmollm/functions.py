@@ -275,30 +275,55 @@ class PatchEmbedFn(torch.autograd.Function):
 _NK_CACHE: dict = {}
 
 
-def _frozen_nk(W: torch.Tensor) -> Optional[torch.Tensor]:
-    """[N][K] copy of a FROZEN transformers-Conv1D weight W[K][N] (the fp32 MFMA GEMM reads a [row][k] B tile
-    with one ds_read_b128 per fragment, a [k][row] tile with four ds_read_b32: the forward GEMMs run ~5 % faster
-    on the transposed copy, the backward already uses W as it is).  Cached per parameter and refreshed when the
-    tensor is modified through torch (load_state_dict bumps _version).  Trainable weights return None: their
-    storage is updated by the fused optimizer behind torch's version counter."""
+def _frozen_copy(W: torch.Tensor, kind: str) -> Optional[torch.Tensor]:
+    """Derived copy of a FROZEN transformers-Conv1D weight W[K][N], cached per parameter and refreshed when the
+    tensor is modified through torch (load_state_dict bumps _version):
+      "nk32"  W^T as [N][K] fp32  -- the fp32 MFMA GEMM reads a [row][k] B tile with one ds_read_b128 per fragment,
+              a [k][row] tile with four ds_read_b32: the forward GEMMs run ~5 % faster on the transposed copy (the
+              backward already uses W as it is);
+      "nk16"  W^T as [N][K] bf16, "kn16"  W as [K][N] bf16 -- bf16 mode: the weight operand of the forward / backward
+              GEMMs is staged by a pure copy at half the bytes (TecmGemm::io_bf16), rounded once here instead of
+              once per tile load.
+    Trainable weights return None: their storage is updated by the fused optimizer behind torch's version counter."""
     if W.requires_grad:
         return None
-    key = id(W)
+    key = (id(W), kind)
     hit = _NK_CACHE.get(key)
     if hit is not None and hit[0]() is W and hit[1] == W._version and hit[2] == W.data_ptr():
         return hit[3]
-    if len(_NK_CACHE) > 64:                                  # drop entries whose parameter is gone (ids get reused)
+    if len(_NK_CACHE) > 256:                                 # drop entries whose parameter is gone (ids get reused)
         for k in [k for k, v in _NK_CACHE.items() if v[0]() is None]:
             del _NK_CACHE[k]
-    wt = W.detach().t().contiguous()
-    _NK_CACHE[key] = (weakref.ref(W), W._version, W.data_ptr(), wt)
-    return wt
+    Wd = W.detach()
+    if kind == "nk32":
+        out = Wd.t().contiguous()
+    elif kind == "nk16":
+        out = Wd.t().contiguous().bfloat16()
+    elif kind == "kn16":
+        out = Wd.contiguous().bfloat16()
+    else:
+        raise ValueError(kind)
+    _NK_CACHE[key] = (weakref.ref(W), W._version, W.data_ptr(), out)
+    return out
 
 
-def _fwd_weight(W: torch.Tensor, K: int, N: int):
-    """(tensor, ldb, b_layout) for  x[M,K] . W[K,N]  in the forward pass."""
-    wt = _frozen_nk(W)
+def _frozen_nk(W: torch.Tensor) -> Optional[torch.Tensor]:
+    return _frozen_copy(W, "nk32")
+
+
+def _fwd_weight(W: torch.Tensor, K: int, N: int, prec=0):
+    """(tensor, ldb, b_layout) for  x[M,K] . W[K,N]  in the forward pass (bf16 mode: the cached bf16 copy)."""
+    wt = _frozen_copy(W, "nk16" if int(prec) == ops.PREC_BF16 else "nk32")
     return (wt, K, B_NK) if wt is not None else (W, N, B_KN)
+
+
+def _bwd_weight(W: torch.Tensor, prec=0) -> torch.Tensor:
+    """B operand of  dY[M,N] . W[K,N]^T  (W read as [n = K][k = N]): bf16 mode uses the cached bf16 copy."""
+    if int(prec) == ops.PREC_BF16:
+        w16 = _frozen_copy(W, "kn16")
+        if w16 is not None:
+            return w16
+    return W
 
 
 class GPT2StackFn(torch.autograd.Function):
@@ -328,11 +353,14 @@ class GPT2StackFn(torch.autograd.Function):
             wcat[:D].copy_(Wqkv)
             ops.transpose_scale(lB, LORA_R, wcat, F3, LORA_R, F3, LORA_SCALE, dst_off=D * F3)
             qkv = _empty(M, F3, like=h)
-            WqkvT = _frozen_nk(Wqkv)
+            b16 = int(plan.bf16) == ops.PREC_BF16           # bf16 mode: weights (and fc / dA outputs) live in HBM as bf16
+            WqkvT = _frozen_copy(Wqkv, "nk16" if b16 else "nk32")
             if WqkvT is not None:                           # forward operand in [N][K] form: [ W^T | (alpha/r) B ]
-                wcatT = _empty(F3, KE, like=h)
+                wcatT = torch.empty(F3, KE, device=h.device, dtype=WqkvT.dtype)
                 wcatT[:, :D].copy_(WqkvT)
-                torch.mul(lB.detach(), LORA_SCALE, out=wcatT[:, D:])
+                wcatT[:, D:].copy_(lB.detach() * LORA_SCALE)
+                if b16:                                     # the backward's [KE][F3] operand in bf16 as well
+                    wcat = wcat.bfloat16()
                 gemm(M, F3, KE, u, KE, wcatT, KE, qkv, F3, b_layout=B_NK, bias=bqkv, bf16=plan.bf16)
             else:
                 gemm(M, F3, KE, u, KE, wcat, F3, qkv, F3, b_layout=B_KN, bias=bqkv, bf16=plan.bf16)
@@ -340,19 +368,22 @@ class GPT2StackFn(torch.autograd.Function):
             aspec = plan.spec(site_attn(i), 1)
             ops.attention_fwd(qkv, cx, B, T, N, GPT_HEADS, D, aspec)
             h2 = _empty(M, D, like=h)
-            Wo_f, ldo_f, lay_o = _fwd_weight(Wo, D, D)
+            Wo_f, ldo_f, lay_o = _fwd_weight(Wo, D, D, plan.bf16)
             gemm(M, D, D, cx, D, Wo_f, ldo_f, h2, D, b_layout=lay_o, bias=bo, out_drop=plan.spec(site_res1(i), D),
                  residual=(h, D), bf16=plan.bf16)
             u2 = _empty(M, D, like=h)
             st2 = _empty(M, 2, like=h)
             ops.layernorm_fwd(h2, D, ln2w, ln2b, u2, D, st2, M, D)
             a = _empty(M, F4, like=h)
-            f = _empty(M, F4, like=h)
-            Wfc_f, ldfc_f, lay_fc = _fwd_weight(Wfc, D, F4)
+            Wfc_f, ldfc_f, lay_fc = _fwd_weight(Wfc, D, F4, plan.bf16)
+            Wpr_f, ldpr_f, lay_pr = _fwd_weight(Wpr, F4, D, plan.bf16)
+            # gelu(fc) is only ever read by the c_proj GEMM: in bf16 mode it is written as bf16 (rounded once here
+            # instead of in that GEMM's loader: bit-identical, half the bytes both ways)
+            f16 = b16 and Wfc_f.dtype == torch.bfloat16 and Wpr_f.dtype == torch.bfloat16
+            f = torch.empty(M, F4, device=h.device, dtype=torch.bfloat16 if f16 else torch.float32)
             gemm(M, F4, D, u2, D, Wfc_f, ldfc_f, f, F4, b_layout=lay_fc, bias=bfc, preact=(a, F4), act=ACT_GELU_TANH,
                  bf16=plan.bf16)
             h3 = _empty(M, D, like=h)
-            Wpr_f, ldpr_f, lay_pr = _fwd_weight(Wpr, F4, D)
             gemm(M, D, F4, f, F4, Wpr_f, ldpr_f, h3, D, b_layout=lay_pr, bias=bpr, out_drop=plan.spec(site_res2(i), D),
                  residual=(h2, D), bf16=plan.bf16)
             saved += [h, u, st1, wcat, qkv, cx, h2, st2, u2, a]
@@ -392,10 +423,13 @@ class GPT2StackFn(torch.autograd.Function):
             h, u, st1, wcat, qkv, cx, h2, st2, u2, a = saved[i * 10:(i + 1) * 10]
             F3, F4 = Wqkv.shape[1], Wfc.shape[1]
             # MLP:  h3 = h2 + drop(gelu(u2 Wfc + b) Wpr + b)
-            da = _empty(M, F4, like=dh)
-            gemm(M, F4, D, dhm, D, Wpr, D, da, F4, act=ACT_GELU_TANH, dact_src=(a, F4), bf16=plan.bf16)
+            Wpr_b, Wfc_b = _bwd_weight(Wpr, plan.bf16), _bwd_weight(Wfc, plan.bf16)
+            # d gelu-input is only read by the next GEMM: bf16 in bf16 mode (see the forward's `f`)
+            da16 = Wpr_b.dtype == torch.bfloat16 and Wfc_b.dtype == torch.bfloat16
+            da = torch.empty(M, F4, device=dh.device, dtype=torch.bfloat16 if da16 else torch.float32)
+            gemm(M, F4, D, dhm, D, Wpr_b, D, da, F4, act=ACT_GELU_TANH, dact_src=(a, F4), bf16=plan.bf16)
             du2 = _empty(M, D, like=dh)
-            gemm(M, D, F4, da, F4, Wfc, F4, du2, D, bf16=plan.bf16)
+            gemm(M, D, F4, da, F4, Wfc_b, F4, du2, D, bf16=plan.bf16)
             del da
             dh2 = _empty(M, D, like=dh)
             sp = plan.spec(site_res1(i), D)
@@ -406,7 +440,7 @@ class GPT2StackFn(torch.autograd.Function):
                                          need_dgb=nig[pb + 8] or nig[pb + 9])
             # attention: h2 = h + drop(ctx Wo + b)
             dcx = du2                                         # reuse buffer
-            gemm(M, D, D, dh2m, D, Wo, D, dcx, D, bf16=plan.bf16)
+            gemm(M, D, D, dh2m, D, _bwd_weight(Wo, plan.bf16), D, dcx, D, bf16=plan.bf16)
             dqkv = _empty(M, F3, like=dh)
             ops.attention_bwd(qkv, dcx, dqkv, B, T, N, GPT_HEADS, D, plan.spec(site_attn(i), 1))
             du = _empty(M, KE, like=dh)                       # [ d LN1-out (base path) | dz ]

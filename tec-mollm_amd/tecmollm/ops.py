@@ -52,6 +52,8 @@ def gemm(M: int, N: int, K: int, A: torch.Tensor, lda: int, B: torch.Tensor, ldb
          preact: Optional[Tuple[torch.Tensor, int]] = None, dact_src: Optional[Tuple[torch.Tensor, int]] = None,
          residual: Optional[Tuple[torch.Tensor, int]] = None, accumulate: bool = False, split_k: int = 1,
          bf16: bool = False) -> None:
+    # A / B / Cout may be torch.bfloat16 tensors (bf16 mode only, plain MK x NK): operands that already live in HBM as
+    # bf16 (activations rounded once by their producer, cached bf16 weights) and / or a bf16 output for such a consumer
     """C[M,N] = epilogue(alpha * A_view[M,K] . B_view[K,N]); see TecmGemm in include/tecmollm.h.
     *_off are element offsets added to the base pointers (column slices of wider buffers).
     bf16 is the precision code: 0/False exact fp32, 1/True bf16 matrix cores, 2 bf16x3 (split-bf16, ~1e-5),
@@ -62,6 +64,12 @@ def gemm(M: int, N: int, K: int, A: torch.Tensor, lda: int, B: torch.Tensor, ldb
     with respect to the tests, which mirror it."""
     g = TecmGemm()
     g.M, g.N, g.K = M, N, K
+    io = (IO_A_BF16 if A.dtype == torch.bfloat16 else 0) | (IO_B_BF16 if B.dtype == torch.bfloat16 else 0) | \
+         (IO_C_BF16 if Cout.dtype == torch.bfloat16 else 0)
+    if io:
+        if int(bf16) != PREC_BF16 or a_off or b_off or c_off:
+            raise _lib.TecmError("bf16 tensors are accepted by the bf16 GEMM only, without element offsets")
+        g.io_bf16 = io
     g.A, g.lda, g.a_layout = _off(A, a_off), lda, a_layout
     g.B, g.ldb, g.b_layout = _off(B, b_off), ldb, b_layout
     g.C, g.ldc = _off(Cout, c_off), ldc
@@ -91,7 +99,7 @@ def gemm(M: int, N: int, K: int, A: torch.Tensor, lda: int, B: torch.Tensor, ldb
     else:
         g.split_k = 1
     mode = int(bf16)                                    # 0 exact fp32, 1 bf16 (autocast semantics), 2 bf16x3
-    use16 = mode == PREC_BF16 and _bf16_ok(g)
+    use16 = mode == PREC_BF16 and (io != 0 or _bf16_ok(g))
     use3 = mode in (PREC_BF16X3, PREC_BF16X6) and _x3_ok(g)
     fn, what = ((lib().tecm_gemm_bf16x6, "tecm_gemm_bf16x6") if (use3 and mode == PREC_BF16X6) else
                 (lib().tecm_gemm_bf16x3, "tecm_gemm_bf16x3") if use3 else
@@ -112,6 +120,7 @@ def gemm(M: int, N: int, K: int, A: torch.Tensor, lda: int, B: torch.Tensor, ldb
 
 
 PREC_FP32, PREC_BF16, PREC_BF16X3, PREC_BF16X6 = 0, 1, 2, 3
+IO_A_BF16, IO_B_BF16, IO_C_BF16 = 1, 2, 4       # TecmGemm.io_bf16
 GROUP_M = 0          # m-tiles per L2 super-tile of the fp32 GEMM (0 = the kernel's default, 8); tools/ sweep it
 BF16_MIN_N = 64
 

@@ -115,3 +115,26 @@ def test_bf16_dropout_epilogue_window_scatter(dev):
     ops.gemm(64, K, M, dz, 64, u, K, dA, K, a_layout=ops.A_KM, b_layout=ops.B_KN, b_drop=ops.drop(p, seedA, 800),
              bf16=True)
     assert _rel(dA, _q(dz).t() @ _q(u * ma)) < TOL
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 256, 96), (513, 768, 800), (1000, 3072, 768), (77, 64, 72)])
+def test_bf16_resident_operands_and_output_are_bit_identical(dev, M, N, K):
+    """Operands that already are bf16 in HBM (TecmGemm::io_bf16) and a bf16 output: rounding once at the producer
+    instead of in the consumer's loader must not change a single bit of the result."""
+    from tecmollm import ops
+    A, Bn = _rand(M, K, dev=dev, seed=1), _rand(N, K, dev=dev, seed=2)
+    bias = _rand(N, dev=dev, seed=4)
+    want = torch.empty(M, N, device=dev)
+    pre_w = torch.empty(M, N, device=dev)
+    ops.gemm(M, N, K, A, K, Bn, K, want, N, bias=bias, act=ops.ACT_GELU_TANH, preact=(pre_w, N), bf16=True)
+    A16, B16 = A.bfloat16(), Bn.bfloat16()
+    for a_, b_ in ((A16, B16), (A16, Bn), (A, B16)):
+        got = torch.full((M, N), float("nan"), device=dev)
+        pre = torch.empty(M, N, device=dev)
+        ops.gemm(M, N, K, a_, K, b_, K, got, N, bias=bias, act=ops.ACT_GELU_TANH, preact=(pre, N), bf16=True)
+        assert torch.equal(got, want) and torch.equal(pre, pre_w)
+    got16 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    ops.gemm(M, N, K, A16, K, B16, K, got16, N, bias=bias, act=ops.ACT_GELU_TANH, preact=(pre, N), bf16=True)
+    assert torch.equal(got16, want.bfloat16()) and torch.equal(pre, pre_w)        # RNE at the store == .bfloat16()
+    with pytest.raises(Exception):
+        ops.gemm(M, N, K, A16, K, Bn, K, got, N)                                  # fp32 kernel refuses bf16 tensors

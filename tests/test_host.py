@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(built_lib):
         assert hasattr(handle, name), f"{name} declared in tecmollm.h but not exported"
     handle.tecm_abi_version.restype = ctypes.c_int
     from tecmollm import _lib
-    assert handle.tecm_abi_version() == _lib.ABI_VERSION == 2
+    assert handle.tecm_abi_version() == _lib.ABI_VERSION == 3
     handle.tecm_last_error.restype = ctypes.c_char_p
     assert isinstance(handle.tecm_last_error(), bytes)
 

@@ -16,6 +16,10 @@ for spec in os.environ.get("SHAPES", "16384,2048,16384,kn").split(";"):
     A = torch.randn(M, K, device=dev)
     B = torch.randn((K, N) if bl == ops.B_KN else (N, K), device=dev) * 0.05
     C = torch.empty(M, N, device=dev)
+    R16 = os.environ.get("RES16", "")            # which tensors live in HBM as bf16: any of "a", "b", "c" (bf16 mode, nk only)
+    if "a" in R16: A = A.bfloat16()
+    if "b" in R16: B = B.bfloat16()
+    if "c" in R16: C = C.bfloat16()
     ldb = N if bl == ops.B_KN else K
     EPI = os.environ.get("EPI", "")
     kw = {}

@@ -342,3 +342,47 @@ def test_epoch_loops_train_and_validate_on_a_learnable_series(dev):
     assert set(m1) == {"mae_avg", "rmse_avg", "r2_score_avg", "pearson_r_avg", "mae_by_horizon", "rmse_by_horizon",
                        "r2_by_horizon", "pearson_by_horizon"} and len(m1["rmse_by_horizon"]) == 12
     assert m1["rmse_avg"] < m0["rmse_avg"]
+
+
+def test_reference_training_loop_body_runs_unchanged(dev):
+    """The statements of train.py:57-112 / :358-372 verbatim around the drop-in model: autocast(bf16), the per-step
+    gradient_checkpointing_enable() call, GradScaler scale/unscale_/step/update, clip_grad_norm_, torch AdamW over the
+    trainable parameters, CosineAnnealingWarmRestarts, accumulation_steps = 2."""
+    from oracle import ref_cpu as R
+    from torch.optim.lr_scheduler import CosineAnnealingWarmRestarts
+    cfg = R.default_config(L_in=16, L_out=12, num_nodes=12, llm_layers=1)
+    model = _model(cfg, 6, dev).train()
+    optimizer = torch.optim.AdamW(filter(lambda p: p.requires_grad, model.parameters()), lr=1e-4, weight_decay=1e-2)
+    scheduler = CosineAnnealingWarmRestarts(optimizer, T_0=10, T_mult=2, eta_min=1e-7)
+    loss_fn = torch.nn.HuberLoss(delta=1.0)
+    scaler = torch.amp.GradScaler("cuda")
+    accumulation_steps = 2
+    edge_index = R.grid_graph(3, 4)[0].to(dev)
+    edge_weight = torch.ones(edge_index.shape[1], device=dev)
+    before = torch.cat([p.detach().flatten().clone() for p in model.parameters() if p.requires_grad])
+    optimizer.zero_grad()
+    total_loss = 0.0
+    for i in range(4):
+        x5 = torch.randn(2, 16, 3, 4, cfg["spatial_in_channels_base"], device=dev)        # (B, L, H, W, C) as the dataset yields
+        y = torch.randn(2, 3, 4, 12, device=dev)
+        time_features = torch.randint(0, 4, (2, 16, 4), device=dev).float()
+        B, L, H, W, C = x5.shape
+        x = x5.view(B, L, H * W, C)
+        time_features = time_features.unsqueeze(-2).expand(B, L, H * W, -1)
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+            model.llm_backbone.model.gradient_checkpointing_enable()
+            output = model(x, time_features, edge_index, edge_weight)
+            y_reshaped = y.permute(0, 3, 1, 2).reshape(B, -1, H * W, 1)
+            loss = loss_fn(output, y_reshaped)
+            loss = loss / accumulation_steps
+        scaler.scale(loss).backward()
+        if (i + 1) % accumulation_steps == 0:
+            scaler.unscale_(optimizer)
+            torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
+            scaler.step(optimizer)
+            scaler.update()
+            optimizer.zero_grad()
+            scheduler.step()
+        total_loss += loss.item() * accumulation_steps
+    after = torch.cat([p.detach().flatten() for p in model.parameters() if p.requires_grad])
+    assert np.isfinite(total_loss) and torch.isfinite(after).all() and not torch.equal(before, after)

@@ -33,7 +33,7 @@ extern "C" {
 #define TECM_E_LAUNCH (-3)     /* hipGetLastError() != hipSuccess after the launch       */
 #define TECM_E_LDS (-4)        /* problem does not fit the 160 KiB LDS budget            */
 
-#define TECM_ABI_VERSION 3
+#define TECM_ABI_VERSION 4
 int tecm_abi_version(void);
 /* Human-readable text for the last error on this thread (host pointer, never NULL). */
 const char* tecm_last_error(void);
@@ -140,7 +140,16 @@ typedef struct TecmSpatial {
   const int32_t* tile_lo; const int32_t* tile_hi;   /* (num_tiles) window [lo,hi) of sources u targets */
   TecmDrop alpha_drop;                    /* GATv2 dropout on attention coefficients (modules.py:333) */
   float* out;                             /* (B, L, N, C) */
+  /* Device error word (one int32, never NULL, owned by the caller, sticky: the kernels only OR bits in).  The
+   * reference's nn.Embedding lookups raise on an out-of-range index (modules.py:255-258); here an index outside its
+   * table sets TECM_BAD_TOD/DOY/YEAR/SEASON, and every output row built from it is NaN -- never a clamped, valid
+   * looking embedding.  The caller reads the word back when it next synchronises (tecmollm/devcheck.py). */
+  int32_t* err_flag;
 } TecmSpatial;
+#define TECM_BAD_TOD 1
+#define TECM_BAD_DOY 2
+#define TECM_BAD_YEAR 4
+#define TECM_BAD_SEASON 8
 int tecm_spatial_fwd(const TecmSpatial* d, void* stream);
 
 typedef struct TecmSpatialGrads {

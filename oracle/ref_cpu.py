@@ -69,7 +69,8 @@ def embed(x: torch.Tensor, tf: torch.Tensor, p: Params) -> torch.Tensor:
 
 # ------------------------------------------------------------------- stage a-2
 def gatv2_conv(x: torch.Tensor, edge_index: torch.Tensor, p: Params, heads: int,
-               alpha_keep: Optional[torch.Tensor] = None, drop_p: float = 0.0) -> torch.Tensor:
+               alpha_keep: Optional[torch.Tensor] = None, drop_p: float = 0.0,
+               alpha_mult: Optional[torch.Tensor] = None) -> torch.Tensor:
     """torch_geometric.nn.GATv2Conv(in, out, heads, concat=True, add_self_loops=True,
     share_weights=False, negative_slope=0.2) restated (call site modules.py:329-336,:356).
 
@@ -79,6 +80,7 @@ def gatv2_conv(x: torch.Tensor, edge_index: torch.Tensor, p: Params, heads: int,
     max-subtraction and `+1e-16` in the denominator (PyG `utils.softmax`).
     `alpha_keep` (E',heads) in {0,1}: optional dropout keep-mask applied to alpha as
     alpha*keep/(1-drop_p); edge order = [non-self edges in given order, then self loops 0..M-1].
+    `alpha_mult` (E',heads): the same thing as a ready multiplier (0 or 1/(1-p)).
     """
     M, C = x.shape
     Wl, bl = p[P_GAT + "lin_l.weight"], p[P_GAT + "lin_l.bias"]
@@ -102,6 +104,8 @@ def gatv2_conv(x: torch.Tensor, edge_index: torch.Tensor, p: Params, heads: int,
     alpha = pexp / denom[dst]
     if alpha_keep is not None:
         alpha = alpha * alpha_keep / (1.0 - drop_p)
+    if alpha_mult is not None:
+        alpha = alpha * alpha_mult
     out = torch.zeros(M, H, Ch).index_add_(0, dst, alpha.unsqueeze(-1) * xl[src])
     return out.reshape(M, H * Ch) + bias
 
@@ -114,19 +118,21 @@ def batched_edge_index(edge_index: torch.Tensor, num_nodes: int, num_graphs: int
 
 
 def spatial(h: torch.Tensor, edge_index: torch.Tensor, p: Params, heads: int,
-            graphs_with_edges: Optional[int] = 1) -> torch.Tensor:
+            graphs_with_edges: Optional[int] = 1, alpha_mult: Optional[torch.Tensor] = None) -> torch.Tensor:
     """tec_mollm.py:84-94 + modules.py:340-359: permute to (L*B, N, C), GATv2 on the
     flattened (L*B*N, C) rows, residual add.  Returns x_spatial (L*B, N, C).
 
     graphs_with_edges=1 is the reference's literal behaviour: edge ids < N only touch
     graph 0 (t=0,b=0); every other row sees just its self loop.  None = every one of the
     L*B graphs gets the edges (the per-timestep behaviour the reference's comments intend).
+    alpha_mult (E', heads): training-mode dropout of the attention coefficients (modules.py:333, GATv2Conv
+    `dropout=0.1`) as a ready multiplier 0 | 1/(1-p), in gatv2_conv's edge order.
     """
     B, L, N, C = h.shape
     xg = h.permute(1, 0, 2, 3).reshape(-1, N, C)
     G = L * B if graphs_with_edges is None else graphs_with_edges
     ei = batched_edge_index(edge_index, N, G)
-    gat = gatv2_conv(xg.reshape(-1, C), ei, p, heads).view(L * B, N, C)
+    gat = gatv2_conv(xg.reshape(-1, C), ei, p, heads, alpha_mult=alpha_mult).view(L * B, N, C)
     return xg + gat
 
 
@@ -172,19 +178,34 @@ def gelu_new(x: torch.Tensor) -> torch.Tensor:
     return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * x.pow(3))))
 
 
-def gpt2_lora(h: torch.Tensor, p: Params, n_layers: int, q=_ident) -> torch.Tensor:
+def _mul(t: torch.Tensor, masks, key: str) -> torch.Tensor:
+    """Training-mode dropout with a GIVEN mask: masks[key] is the multiplier 0 | 1/(1-p), same shape as t
+    (None / missing key = eval mode).  The masks are inputs of the oracle, not drawn here: tests feed the
+    mirror of the device's counter-based masks (tecmollm/rng.py) so both sides drop the same elements."""
+    if masks is None or masks.get(key) is None:
+        return t
+    m = masks[key]
+    assert m.shape == t.shape, (key, tuple(m.shape), tuple(t.shape))
+    return t * m
+
+
+def gpt2_lora(h: torch.Tensor, p: Params, n_layers: int, q=_ident, masks=None) -> torch.Tensor:
     """LLMBackbone.forward modules.py:205-209 -> peft(GPT2Model)(inputs_embeds=h, all-ones mask).
-    Eval-mode (all dropouts off).  h (S, T, 768).  c_attn' = base Conv1D + 2.0 * B(A(u))."""
+    h (S, T, 768).  c_attn' = base Conv1D + 2.0 * B(A(lora_dropout(u))).
+    Dropout sites (all p = 0.1 in the reference; masks=None is eval mode): GPT2Model `drop` on
+    inputs_embeds + wpe ("embd", modeling_gpt2.py embd_pdrop), peft's lora_dropout on the LoRA branch input
+    ("lora{i}", modules.py:181), attention-probability dropout ("attn{i}", (S, heads, T, T), attn_pdrop),
+    residual dropouts after attn.c_proj and mlp.c_proj ("res1_{i}", "res2_{i}", resid_pdrop)."""
     S, T, D = h.shape
     hd = D // GPT2_HEADS
-    h = h + p[P_GPT + "wpe.weight"][:T]
+    h = _mul(h + p[P_GPT + "wpe.weight"][:T], masks, "embd")
     causal = torch.tril(torch.ones(T, T, dtype=torch.bool))
     for i in range(n_layers):
         pre = f"{P_GPT}h.{i}."
         u = F.layer_norm(h, (D,), p[pre + "ln_1.weight"], p[pre + "ln_1.bias"], LN_EPS)
         A = p[pre + "attn.c_attn.lora_A.default.weight"]     # (r, 768)
         Bm = p[pre + "attn.c_attn.lora_B.default.weight"]    # (2304, r)
-        z = u @ A.t()                                        # 32 output columns: stays on the exact fp32 kernel
+        z = _mul(u, masks, f"lora{i}") @ A.t()               # 32 output columns: stays on the exact fp32 kernel
         qkv = q(u) @ q(p[pre + "attn.c_attn.base_layer.weight"]) + p[pre + "attn.c_attn.base_layer.bias"]
         qkv = qkv + q(z) @ q(LORA_SCALE * Bm.t())            # one K-extended GEMM in the HIP path
         qq, k, v = qkv.split(D, dim=-1)
@@ -192,37 +213,42 @@ def gpt2_lora(h: torch.Tensor, p: Params, n_layers: int, q=_ident) -> torch.Tens
         k = k.view(S, T, GPT2_HEADS, hd).transpose(1, 2)
         v = v.view(S, T, GPT2_HEADS, hd).transpose(1, 2)
         w = (qq @ k.transpose(-1, -2)) / math.sqrt(hd)
-        w = w.masked_fill(~causal, float("-inf")).softmax(-1)
+        w = _mul(w.masked_fill(~causal, float("-inf")).softmax(-1), masks, f"attn{i}")
         ctx = (w @ v).transpose(1, 2).reshape(S, T, D)
-        h = h + q(ctx) @ q(p[pre + "attn.c_proj.weight"]) + p[pre + "attn.c_proj.bias"]
+        h = h + _mul(q(ctx) @ q(p[pre + "attn.c_proj.weight"]) + p[pre + "attn.c_proj.bias"], masks, f"res1_{i}")
         u = F.layer_norm(h, (D,), p[pre + "ln_2.weight"], p[pre + "ln_2.bias"], LN_EPS)
         f = gelu_new(q(u) @ q(p[pre + "mlp.c_fc.weight"]) + p[pre + "mlp.c_fc.bias"])
-        h = h + q(f) @ q(p[pre + "mlp.c_proj.weight"]) + p[pre + "mlp.c_proj.bias"]
+        h = h + _mul(q(f) @ q(p[pre + "mlp.c_proj.weight"]) + p[pre + "mlp.c_proj.bias"], masks, f"res2_{i}")
     return F.layer_norm(h, (D,), p[P_GPT + "ln_f.weight"], p[P_GPT + "ln_f.bias"], LN_EPS)
 
 
 # ------------------------------------------------------------------- stage a-8
-def head(x: torch.Tensor, p: Params, q=_ident) -> torch.Tensor:
-    """PredictionHead.forward modules.py:295-313 (eval): (S,T,768) -> (S, L_out).
+def head(x: torch.Tensor, p: Params, q=_ident, masks=None) -> torch.Tensor:
+    """PredictionHead.forward modules.py:295-313: (S,T,768) -> (S, L_out); nn.Dropout after the GELU
+    (modules.py:289, mask "head" (S, hidden)).
     The 12-column output layer stays fp32 in the bf16 mode (fewer than 64 output columns)."""
     z = x.reshape(x.shape[0], -1)
-    z = F.gelu(q(z) @ q(p[P_HEAD + "0.weight"]).t() + p[P_HEAD + "0.bias"])
+    z = _mul(F.gelu(q(z) @ q(p[P_HEAD + "0.weight"]).t() + p[P_HEAD + "0.bias"]), masks, "head")
     return z @ p[P_HEAD + "3.weight"].t() + p[P_HEAD + "3.bias"]
 
 
 # ------------------------------------------------------------------- full path
 def forward(x: torch.Tensor, tf: torch.Tensor, edge_index: torch.Tensor, p: Params, cfg: dict,
-            graphs_with_edges: Optional[int] = 1, q=_ident) -> torch.Tensor:
-    """TEC_MoLLM.forward tec_mollm.py:59-125, eval mode.  Returns (B, L_out, N, 1).
-    q=bf16_round emulates the bf16 MFMA mode (GATv2's 22x22 transforms stay fp32 there)."""
+            graphs_with_edges: Optional[int] = 1, q=_ident, masks=None) -> torch.Tensor:
+    """TEC_MoLLM.forward tec_mollm.py:59-125.  Returns (B, L_out, N, 1).
+    q=bf16_round emulates the bf16 MFMA mode (GATv2's 22x22 transforms stay fp32 there).
+    masks=None: eval mode.  masks = {site: multiplier tensor}: training mode with the given dropout masks at
+    every site of the reference -- "gat" (modules.py:333), "embd"/"lora{i}"/"attn{i}"/"res1_{i}"/"res2_{i}"
+    (GPT-2 + peft, see gpt2_lora), "post" (F.dropout tec_mollm.py:115, (S,T,768)), "head" (modules.py:289)."""
     B, L, N, _ = x.shape
     h = embed(x, tf, p)
-    xs = spatial(h, edge_index, p, cfg["spatial_heads"], graphs_with_edges)
+    xs = spatial(h, edge_index, p, cfg["spatial_heads"], graphs_with_edges,
+                 alpha_mult=None if masks is None else masks.get("gat"))
     C = xs.shape[-1]
     xt = xs.view(L, B, N, C).permute(1, 2, 0, 3).reshape(B * N, L, C)
     tok = temporal_encoder(xt, p, cfg["temporal_strides"], cfg["patch_len"], q)
-    hid = gpt2_lora(tok, p, cfg["llm_layers"], q)
-    pred = head(hid, p, q)
+    hid = _mul(gpt2_lora(tok, p, cfg["llm_layers"], q, masks), masks, "post")
+    pred = head(hid, p, q, masks)
     return pred.view(B, N, -1).permute(0, 2, 1).unsqueeze(-1)
 
 

@@ -41,19 +41,30 @@ __device__ __forceinline__ int clampi(int v, int hi) { return v < 0 ? 0 : (v >= 
 
 struct TimeIdx {
   int tod, doy, year, season;
+  int bad;      // TECM_BAD_* bits: an index outside its table (the reference's nn.Embedding raises, modules.py:255-258)
 };
 __device__ __forceinline__ TimeIdx load_time_idx(const TecmSpatial& d, int b, int t, int node) {
   const float* p = d.tf + (int64_t)b * d.tf_sb + (int64_t)t * d.tf_sl + (int64_t)node * d.tf_sn;
   TimeIdx ti;
-  ti.tod = clampi((int)p[0], 12);                       // .long() truncation, modules.py:250-253
-  ti.doy = clampi((int)p[d.tf_sf], 366);
-  ti.year = clampi((int)p[2 * d.tf_sf], d.year_rows);
-  ti.season = clampi((int)p[3 * d.tf_sf], 4);
+  const int tod = (int)p[0], doy = (int)p[d.tf_sf];     // .long() truncation, modules.py:250-253
+  const int year = (int)p[2 * d.tf_sf], season = (int)p[3 * d.tf_sf];
+  ti.bad = ((unsigned)tod >= 12u ? TECM_BAD_TOD : 0) | ((unsigned)doy >= 366u ? TECM_BAD_DOY : 0) |
+           ((unsigned)year >= (unsigned)d.year_rows ? TECM_BAD_YEAR : 0) | ((unsigned)season >= 4u ? TECM_BAD_SEASON : 0);
+  // clamped only so that the table reads below stay inside their allocations; a bad index never yields a value
+  ti.tod = clampi(tod, 12);
+  ti.doy = clampi(doy, 366);
+  ti.year = clampi(year, d.year_rows);
+  ti.season = clampi(season, 4);
   return ti;
 }
-// ((tod + doy) + year) + season -- the exact association of modules.py:260
+// ((tod + doy) + year) + season -- the exact association of modules.py:260.  An out-of-range index is reported through
+// the device error word and turns the embedding into NaN: it is rejected, not repaired.
 __device__ __forceinline__ float temporal_emb(const TecmSpatial& d, const TimeIdx& ti, int k) {
   const int D = d.Demb;
+  if (ti.bad) {
+    atomicOr(d.err_flag, ti.bad);
+    return __builtin_nanf("");
+  }
   return ((d.tod_tab[ti.tod * D + k] + d.doy_tab[ti.doy * D + k]) + d.year_tab[ti.year * D + k]) +
          d.season_tab[ti.season * D + k];
 }
@@ -678,7 +689,7 @@ int check_common(const char* who, const TecmSpatial& d) {
                "%s: built for C = Cin + Demb = 22 channels and 2 heads (got C=%d H=%d)", who, d.Cin + d.Demb, d.H);
   TECM_REQUIRE(d.Demb <= 32, TECM_E_ARG, "%s: Demb must be <= 32", who);
   TECM_REQUIRE(d.x && d.tf && d.node_tab && d.tod_tab && d.doy_tab && d.year_tab && d.season_tab && d.Wl && d.bl &&
-                   d.Wr && d.br && d.att && d.bias && d.rowptr && d.colidx && d.tile_lo && d.tile_hi,
+                   d.Wr && d.br && d.att && d.bias && d.rowptr && d.colidx && d.tile_lo && d.tile_hi && d.err_flag,
                TECM_E_ARG, "%s: null pointer", who);
   TECM_REQUIRE(d.num_tiles > 0 && d.tile_nodes > 0 && d.tile_nodes <= 256 &&
                    (int64_t)d.num_tiles * d.tile_nodes >= d.N && d.win_max >= 1,

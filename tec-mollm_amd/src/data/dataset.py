@@ -47,12 +47,31 @@ class SlidingWindowSamplerDataset(torch.utils.data.Dataset):
             raise ValueError("X must be (T, H, W, C) and Y (T, H, W, L_out) with matching T, H, W")
         if self.Y.shape[3] != L_out:
             raise ValueError(f"Y holds {self.Y.shape[3]} horizons, L_out = {L_out}")
+        self._check_time_feature_ranges()
         max_start_idx = len(self.X) - self.L_in - self.L_out + 1          # dataset.py:47-55
         self.sample_indices = list(range(0, max_start_idx, self.stride)) if max_start_idx > 0 else []
         self.num_samples = len(self.sample_indices)
         if self.num_samples <= 0:
             log.warning("Insufficient data for windowing: Total length=%d, L_in=%d, L_out=%d, stride=%d",
                         len(self.X), L_in, L_out, stride)
+
+    # table sizes of SpatioTemporalEmbedding (modules.py:219-225); num_years is a model setting, so the year column is
+    # only required to be non-negative here and is checked against the table by the kernel (device error word)
+    TIME_FEATURE_ROWS = (12, 366, None, 4)
+
+    def _check_time_feature_ranges(self) -> None:
+        """One device reduction at construction: the reference's nn.Embedding raises IndexError on an out-of-range
+        time feature the first time a batch hits it (modules.py:255-258); a resident split can say so up front."""
+        tf = self.time_features
+        if tf.dim() != 2 or tf.shape[1] < 4 or tf.shape[0] == 0:
+            return
+        lo, hi = torch.aminmax(tf[:, :4].long(), dim=0)
+        lo, hi = lo.tolist(), hi.tolist()
+        names = ("time-of-day", "day-of-year", "year", "season")
+        for c, rows in enumerate(self.TIME_FEATURE_ROWS):
+            if lo[c] < 0 or (rows is not None and hi[c] >= rows):
+                raise IndexError(f"time_features[:, {c}] ({names[c]}) spans [{lo[c]}, {hi[c]}], outside its embedding "
+                                 f"table [0, {rows if rows is not None else 'num_years'})")
 
     @classmethod
     def from_tensors(cls, X, Y, time_features, L_in: int, L_out: int, stride: int = 1, device="cuda", mode: str = "train"):

@@ -6,5 +6,6 @@ Package layout (inside `tec-mollm_amd/`, which must be on sys.path):
   src/model/       mirror of the reference's module API (`from src.model.tec_mollm import TEC_MoLLM`)
 """
 from ._lib import LIB_PATH, TecmError, lib  # noqa: F401
+from .devcheck import check_device_errors  # noqa: F401
 
-__all__ = ["LIB_PATH", "TecmError", "lib"]
+__all__ = ["LIB_PATH", "TecmError", "lib", "check_device_errors"]

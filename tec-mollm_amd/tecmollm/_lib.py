@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TECM_LIB", os.path.join(_HERE, "libtecmollm_hip.so"))   # override for experiments
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_f32p = C.c_void_p
 
@@ -61,6 +61,7 @@ class TecmSpatial(C.Structure):
         ("rowptr", C.c_void_p), ("colidx", C.c_void_p), ("tile_lo", C.c_void_p), ("tile_hi", C.c_void_p),
         ("alpha_drop", TecmDrop),
         ("out", c_f32p),
+        ("err_flag", C.c_void_p),
     ]
 
 

@@ -15,7 +15,7 @@ from typing import List, Optional
 
 import torch
 
-from . import ops
+from . import devcheck, ops
 from ._lib import TecmSpatial, TecmSpatialGrads, check, lib, stream_ptr
 from .graph import GraphMeta
 from .ops import (A_KM, A_MK, ACT_GELU_ERF, ACT_GELU_TANH, B_KN, B_NK, colsum, drop, gemm, pick_split_k, win)
@@ -80,7 +80,10 @@ class SpatialFn(torch.autograd.Function):
         d = SpatialFn._desc(x, tf, node_tab, tod_tab, doy_tab, year_tab, season_tab, Wl, bl, Wr, br, att, bias, meta,
                             heads, graphs_with_edges, plan, B, L, N, Cin, Demb)
         d.out = out.data_ptr()
+        errs = devcheck.error_word(x.device)
+        errs.poll()                                     # a bad time index reported by an earlier forward (no sync)
         check(lib().tecm_spatial_fwd(C.byref(d), stream_ptr()), "tecm_spatial_fwd")
+        errs.post()
         ctx.save_for_backward(x, tf, node_tab, tod_tab, doy_tab, year_tab, season_tab, Wl, bl, Wr, br, att, bias)
         ctx.meta, ctx.heads, ctx.R, ctx.plan = meta, heads, graphs_with_edges, plan
         return out
@@ -106,6 +109,7 @@ class SpatialFn(torch.autograd.Function):
         sp = plan.spec(SITE_GAT, meta.max_deg + 1)
         if sp is not None:
             d.alpha_drop = sp
+        d.err_flag = devcheck.error_word(x.device).ptr()
         return d
 
     @staticmethod

@@ -332,3 +332,27 @@ def test_huber_and_transpose(dev):
     dst = torch.zeros(40, 2304, device=dev)
     ops.transpose_scale(src, 32, dst, 2304, 32, 2304, 2.0, dst_off=8 * 2304)
     assert torch.equal(dst[8:], 2.0 * src.t()) and float(dst[:8].abs().max()) == 0.0
+
+
+# ----------------------------------------------------------------------------- dropout_apply (tec_mollm.py:115)
+@pytest.mark.parametrize("rows,cols,ld,p", [(1000, 768, 768, 0.1), (37, 100, 800, 0.25), (5, 3, 3, 0.5),
+                                            (513, 768, 768, 0.0)])
+def test_dropout_apply_matches_numpy_mirror(dev, rows, cols, ld, p):
+    """tecm_dropout_apply: dst[r][c] = src[r][c] * keep(seed, r*drop.ld + c) / (1 - p), bit for bit against the NumPy
+    mirror of the device hash -- the post-LLM F.dropout and the masked gradient of the embd dropout run through it."""
+    from tecmollm import ops, rng
+    src = _rand(rows, cols, dev=dev, seed=11)
+    seed = ops.splitmix64(20240517)
+    spec = ops.drop(p, seed, ld)
+    out = ops.dropout_apply(src, rows, cols, spec)
+    idx = np.arange(rows, dtype=np.uint64)[:, None] * np.uint64(ld) + np.arange(cols, dtype=np.uint64)[None, :]
+    mult = rng.keep_mult(seed, idx, p) if p > 0 else np.ones((rows, cols), np.float32)
+    want = src.cpu().numpy() * mult
+    assert np.array_equal(out.cpu().numpy(), want)
+    if p > 0 and rows * cols > 10000:
+        kept = float((out != 0).float().mean())
+        assert abs(kept - (1 - p)) < 0.01
+    # the same mask again in a second call (pure function of seed and index), and a different one for another seed
+    assert torch.equal(ops.dropout_apply(src, rows, cols, spec), out)
+    if p > 0 and rows * cols > 100:
+        assert not torch.equal(ops.dropout_apply(src, rows, cols, ops.drop(p, seed + 1, ld)), out)

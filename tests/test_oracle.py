@@ -165,3 +165,35 @@ def test_forward_shape_and_huber():
     assert out.shape == (2, 12, 12, 1)
     loss = R.huber(out, y)
     assert math.isfinite(loss.item())
+
+
+def test_train_mode_masks_cover_every_dropout_site_and_bite():
+    """The oracle in training mode: `masks` carries one multiplier tensor per dropout site of the reference.  The
+    mirror masks built from tecmollm/rng.py have the oracle's shapes, keep about 1 - p of the elements, and each site
+    on its own changes the output (no site is silently ignored); masks of all-ones reproduce eval mode exactly."""
+    from tests.parity import device_masks
+    cfg = R.default_config(L_in=16, L_out=12, num_nodes=12, llm_layers=2)
+    p = R.init_params(cfg, seed=0)
+    x, tf, y = R.synthetic_batch(2, 16, 12, 6, 12, seed=1)
+    ei, _ = R.grid_graph(3, 4, threshold_km=170.0)
+    masks = device_masks(cfg, 2, ei, base_seed=123456789, gat_graphs="per_timestep")
+    want_keys = {"gat", "embd", "post", "head"} | {f"{k}{i}" for i in range(2) for k in ("lora", "attn", "res1_", "res2_")}
+    assert set(masks) == want_keys
+    for k, m in masks.items():
+        vals = set(torch.unique(m).tolist())
+        assert vals <= {0.0, float(np.float32(1.0) / (np.float32(1.0) - np.float32(0.1)))}, k
+        if m.numel() > 2000:
+            assert abs(float((m > 0).float().mean()) - 0.9) < 0.03, k
+    ev = R.forward(x, tf, ei, p, cfg, None)
+    ones = {k: torch.ones_like(m) for k, m in masks.items()}
+    assert torch.equal(R.forward(x, tf, ei, p, cfg, None, masks=ones), ev)
+    for k in masks:
+        one = dict(ones)
+        one[k] = masks[k]
+        assert not torch.equal(R.forward(x, tf, ei, p, cfg, None, masks=one), ev), k
+    # reference graph mode: E' = E + M edges, only graph 0 has neighbours
+    mref = device_masks(cfg, 2, ei, base_seed=5, gat_graphs="reference")
+    E = int(ei.shape[1])
+    assert mref["gat"].shape == (E + 2 * 16 * 12, 2) and masks["gat"].shape == (E * 32 + 2 * 16 * 12, 2)
+    out = R.forward(x, tf, ei, p, cfg, 1, masks=mref)
+    assert out.shape == (2, 12, 12, 1) and torch.isfinite(out).all()

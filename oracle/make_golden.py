@@ -125,8 +125,15 @@ def main():
                 continue
             src = (R.P_GPT + k).replace("attn.c_attn.weight", "attn.c_attn.base_layer.weight") \
                                .replace("attn.c_attn.bias", "attn.c_attn.base_layer.bias")
-            if src in p:
-                sd[k] = p[src]
+            if src not in p:                           # persistent buffers only; a weight the oracle does not carry is a bug
+                assert k.endswith((".attn.bias", ".attn.masked_bias")), f"GPT2Model key {k} has no oracle parameter"
+                continue
+            assert tuple(sd[k].shape) == tuple(p[src].shape), (k, tuple(sd[k].shape), tuple(p[src].shape))
+            sd[k] = p[src]
+        used = {(R.P_GPT + k).replace("attn.c_attn.weight", "attn.c_attn.base_layer.weight")
+                .replace("attn.c_attn.bias", "attn.c_attn.base_layer.bias") for k in sd}
+        unused = [k for k in p if k.startswith(R.P_GPT) and "lora_" not in k and k not in used]
+        assert not unused, f"oracle GPT-2 parameters without a GPT2Model key: {unused}"
         gm.load_state_dict(sd)
         gm.eval()
         g = torch.Generator().manual_seed(25)

@@ -252,6 +252,30 @@ def forward(x: torch.Tensor, tf: torch.Tensor, edge_index: torch.Tensor, p: Para
     return pred.view(B, N, -1).permute(0, 2, 1).unsqueeze(-1)
 
 
+def random_masks(cfg: dict, B: int, edge_index: torch.Tensor, graphs_with_edges: Optional[int], p: float = 0.1,
+                 generator: Optional[torch.Generator] = None) -> dict:
+    """Training-mode dropout masks (multiplier 0 | 1/(1-p)) for every site of `forward`, drawn with torch's own
+    Bernoulli generator -- what the reference does inside each step (p = 0.1 everywhere: modules.py:181, :272, :333,
+    tec_mollm.py:115, GPT-2 config defaults).  Used by the timed CPU baseline; parity tests feed the device's masks."""
+    N, L = cfg["num_nodes"], cfg["temporal_seq_len"]
+    D, H = cfg["d_llm"], cfg["spatial_heads"]
+    T = (L // (cfg["temporal_strides"][0] * cfg["temporal_strides"][1])) // cfg["patch_len"]
+    S = B * N
+    G = L * B if graphs_with_edges is None else graphs_with_edges
+    n_edges = int((edge_index[0] != edge_index[1]).sum()) * G + L * B * N
+
+    def draw(*shape):
+        return torch.bernoulli(torch.full(shape, 1.0 - p), generator=generator) / (1.0 - p)
+
+    m = {"gat": draw(n_edges, H), "embd": draw(S, T, D), "post": draw(S, T, D), "head": draw(S, (D * T) // 4)}
+    for i in range(cfg["llm_layers"]):
+        m[f"lora{i}"] = draw(S, T, D)
+        m[f"attn{i}"] = draw(S, GPT2_HEADS, T, T)
+        m[f"res1_{i}"] = draw(S, T, D)
+        m[f"res2_{i}"] = draw(S, T, D)
+    return m
+
+
 def huber(out: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     """nn.HuberLoss(delta=1.0), mean reduction (train.py:372)."""
     return F.huber_loss(out, y, delta=1.0)

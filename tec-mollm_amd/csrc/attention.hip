@@ -107,9 +107,9 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restr
 //   dP~_ij = <dctx_i, v_j>;  dV_j += P~_ij dctx_i;  dP_ij = dP~_ij * keep/(1-p);
 //   dS_ij = P_ij (dP_ij - sum_k P_ik dP_ik);  dQ_i += dS_ij K_j / 8;  dK_j += dS_ij Q_i / 8.
 template <int TT>
-__global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restrict__ qkv,
-                                                            const float* __restrict__ dctx, float* __restrict__ dqkv,
-                                                            int B, int Trt, int N, int H, int D, DropA dr) {
+__device__ __forceinline__ void attention_bwd_body(const float* __restrict__ qkv, const float* __restrict__ dctx,
+                                                   float* __restrict__ dqkv, int B, int Trt, int N, int H, int D,
+                                                   DropA dr) {
   const int T = TT > 0 ? TT : Trt;
   const int sub = threadIdx.x & 15;
   const int64_t item = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
@@ -179,6 +179,21 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
   }
 }
 
+template <int TT>
+__global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restrict__ qkv,
+                                                            const float* __restrict__ dctx, float* __restrict__ dqkv,
+                                                            int B, int Trt, int N, int H, int D, DropA dr) {
+  attention_bwd_body<TT>(qkv, dctx, dqkv, B, Trt, N, H, D, dr);
+}
+// T = 8, 12: six float4[T] register arrays need more than 256 VGPRs -- one wave per SIMD, the whole 512-entry file
+template <int TT>
+__global__ __launch_bounds__(256, 1) void attention_bwd_kernel_wide(const float* __restrict__ qkv,
+                                                                    const float* __restrict__ dctx,
+                                                                    float* __restrict__ dqkv, int B, int Trt, int N,
+                                                                    int H, int D, DropA dr) {
+  attention_bwd_body<TT>(qkv, dctx, dqkv, B, Trt, N, H, D, dr);
+}
+
 int check(const char* who, const void* a, const void* b, const void* c, int B, int T, int N, int heads, int D) {
   TECM_REQUIRE(a && b && c, TECM_E_ARG, "%s: null pointer", who);
   TECM_REQUIRE(B > 0 && N > 0 && T > 0 && T <= 32, TECM_E_ARG, "%s: need 1 <= T <= 32 (got %d)", who, T);
@@ -214,7 +229,9 @@ extern "C" int tecm_attention_fwd(const float* qkv, float* ctx, int32_t B, int32
     case 3: ATT_FWD(3); break;
     case 4: ATT_FWD(4); break;
     case 6: ATT_FWD(6); break;
-    default: ATT_FWD(0); break;
+    case 8: ATT_FWD(8); break;
+    case 12: ATT_FWD(12); break;       // L_in = 192 with patch_len 4
+    default: ATT_FWD(0); break;        // runtime T <= 32 (L_in = 336 -> 21 tokens): k / v re-read from L1/L2
   }
 #undef ATT_FWD
   TECM_CHECK_LAUNCH("tecm_attention_fwd");
@@ -237,6 +254,12 @@ extern "C" int tecm_attention_bwd(const float* qkv, const float* dctx, float* dq
     case 3: ATT_BWD(3); break;
     case 4: ATT_BWD(4); break;
     case 6: ATT_BWD(6); break;
+    case 8:
+      hipLaunchKernelGGL((attention_bwd_kernel_wide<8>), grid, dim3(256), 0, st, qkv, dctx, dqkv, B, T, N, heads, D, dr);
+      break;
+    case 12:
+      hipLaunchKernelGGL((attention_bwd_kernel_wide<12>), grid, dim3(256), 0, st, qkv, dctx, dqkv, B, T, N, heads, D, dr);
+      break;
     default: ATT_BWD(0); break;
   }
 #undef ATT_BWD

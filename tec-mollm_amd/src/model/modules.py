@@ -243,21 +243,42 @@ class _PeftGPT2(nn.Module):
         print(f"trainable params: {tr:,} || all params: {al:,} || trainable%: {100 * tr / max(al, 1):.4f}")
 
 
-def _try_load_pretrained_gpt2(trunk: _GPT2Trunk) -> bool:
-    """Mirror of AutoModel.from_pretrained('gpt2') (modules.py:165) when the checkpoint is cached locally."""
-    try:
-        from transformers import AutoModel
-        hf = AutoModel.from_pretrained("gpt2", local_files_only=True)
-    except Exception as e:  # offline box without the checkpoint
-        log.warning("pretrained 'gpt2' weights unavailable (%s): using config initialisation", type(e).__name__)
-        return False
-    sd = hf.state_dict()
+def hf_key_of(own_key: str) -> str:
+    """Name of one of our trunk parameters inside a plain transformers GPT2Model state dict: peft wraps c_attn, so
+    `attn.c_attn.base_layer.{weight,bias}` here is `attn.c_attn.{weight,bias}` there (modules.py:177-186)."""
+    return own_key.replace("attn.c_attn.base_layer.", "attn.c_attn.")
+
+
+def copy_hf_gpt2_weights(trunk: _GPT2Trunk, hf_state: dict) -> int:
+    """Copy a transformers GPT2Model state dict into the trunk (first `len(trunk.h)` blocks, modules.py:170).
+    Every non-LoRA parameter of the trunk MUST be found with the same shape: a silent partial copy would train LoRA on
+    top of a half-random backbone.  Returns the number of tensors copied."""
     own = trunk.state_dict()
-    for k in own:
-        src = k.replace("attn.c_attn.base_layer.", "attn.c_attn.")
-        if src in sd and sd[src].shape == own[k].shape:
-            own[k].copy_(sd[src])
-    return True
+    missing, wrong, n = [], [], 0
+    for k, dst in own.items():
+        if ".lora_A." in k or ".lora_B." in k:
+            continue
+        src = hf_state.get(hf_key_of(k))
+        if src is None:
+            missing.append(k)
+        elif tuple(src.shape) != tuple(dst.shape):
+            wrong.append((k, tuple(src.shape), tuple(dst.shape)))
+        else:
+            dst.copy_(src)
+            n += 1
+    if missing or wrong:
+        raise RuntimeError(f"GPT-2 checkpoint does not cover the trunk: missing {missing[:5]} (+{max(len(missing) - 5, 0)}), "
+                           f"shape mismatches {wrong[:5]}")
+    return n
+
+
+def _load_pretrained_gpt2(trunk: _GPT2Trunk) -> None:
+    """AutoModel.from_pretrained('gpt2') exactly as the reference does (modules.py:165): it downloads the checkpoint or
+    fails loudly.  A machine without the checkpoint (and without network) therefore raises here; pass
+    model_config['load_pretrained_gpt2'] = False to ask for config-style initialisation explicitly."""
+    from transformers import AutoModel
+    hf = AutoModel.from_pretrained("gpt2")
+    copy_hf_gpt2_weights(trunk, hf.state_dict())
 
 
 class LLMBackbone(nn.Module):
@@ -269,7 +290,7 @@ class LLMBackbone(nn.Module):
         trunk = _GPT2Trunk(num_layers_to_keep, include_wte=include_wte)
         if load_pretrained:
             with torch.no_grad():
-                _try_load_pretrained_gpt2(trunk)
+                _load_pretrained_gpt2(trunk)
         self.num_layers = num_layers_to_keep
         self.model = _PeftGPT2(trunk)
         self._freeze_parameters()

@@ -80,7 +80,8 @@ def error_word(device: torch.device) -> DeviceErrorWord:
 def check_device_errors(device=None, sync: bool = True) -> None:
     """Raise if any kernel launched so far reported an error (waits for the read-back when sync=True)."""
     if device is not None:
-        error_word(device).poll(sync)
+        if torch.device(device).type == "cuda":
+            error_word(device).poll(sync)
         return
     for w in list(_words.values()):
         w.poll(sync)

@@ -62,6 +62,11 @@ class DropPlan:
         return drop(self.p, ops.splitmix64(self.base_seed * 1000003 + site), ld)
 
 
+def _lib_error(msg: str):
+    from ._lib import TecmError
+    return TecmError(msg)
+
+
 def _empty(*shape, like: torch.Tensor) -> torch.Tensor:
     return torch.empty(*shape, device=like.device, dtype=torch.float32)
 
@@ -288,7 +293,9 @@ def _frozen_copy(W: torch.Tensor, kind: str) -> Optional[torch.Tensor]:
       "nk16"  W^T as [N][K] bf16, "kn16"  W as [K][N] bf16 -- bf16 mode: the weight operand of the forward / backward
               GEMMs is staged by a pure copy at half the bytes (TecmGemm::io_bf16), rounded once here instead of
               once per tile load.
-    Trainable weights return None: their storage is updated by the fused optimizer behind torch's version counter."""
+    Trainable weights return None: their storage is updated by the fused optimizer behind torch's version counter.
+    A write through `W.data` (which bumps no version counter) is NOT seen: call `invalidate_frozen_copies()` after
+    editing frozen weights that way (load_state_dict, copy_ and every other torch op on W itself are picked up)."""
     if W.requires_grad:
         return None
     key = (id(W), kind)
@@ -309,6 +316,11 @@ def _frozen_copy(W: torch.Tensor, kind: str) -> Optional[torch.Tensor]:
         raise ValueError(kind)
     _NK_CACHE[key] = (weakref.ref(W), W._version, W.data_ptr(), out)
     return out
+
+
+def invalidate_frozen_copies() -> None:
+    """Drop every cached transposed / bf16 copy of the frozen GPT-2 weights (see _frozen_copy)."""
+    _NK_CACHE.clear()
 
 
 def _frozen_nk(W: torch.Tensor) -> Optional[torch.Tensor]:
@@ -336,9 +348,20 @@ class GPT2StackFn(torch.autograd.Function):
     params per layer: ln1_w, ln1_b, Wqkv(768,2304), bqkv, loraA(32,768), loraB(2304,32), Wo, bo,
                       ln2_w, ln2_b, Wfc, bfc, Wproj, bproj      then lnf_w, lnf_b."""
     PER_LAYER = 14
+    FROZEN_SLOTS = {2: "attn.c_attn.base_layer.weight", 3: "attn.c_attn.base_layer.bias", 6: "attn.c_proj.weight",
+                    7: "attn.c_proj.bias", 10: "mlp.c_fc.weight", 11: "mlp.c_fc.bias", 12: "mlp.c_proj.weight",
+                    13: "mlp.c_proj.bias"}
 
     @staticmethod
     def forward(ctx, h0, n_layers: int, plan: DropPlan, *params):
+        # The backward below only forms the gradients the reference trains (freeze rule modules.py:195-203: lora_, ln_,
+        # wpe).  A base weight switched to requires_grad=True would silently get no gradient: refuse instead.
+        for i in range(n_layers):
+            for slot, name in GPT2StackFn.FROZEN_SLOTS.items():
+                if params[i * GPT2StackFn.PER_LAYER + slot].requires_grad:
+                    raise _lib_error(f"h.{i}.{name} has requires_grad=True: the MI355X path computes gradients for the "
+                                     "LoRA, LayerNorm and wpe parameters only (the reference's freeze rule, "
+                                     "modules.py:195-203); freeze the GPT-2 base weights")
         B, T, N, D = h0.shape
         M = B * T * N
         KE = D + LORA_R

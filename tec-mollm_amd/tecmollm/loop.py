@@ -32,9 +32,11 @@ def train_one_epoch(ts: TrainStep, dataset, edge_index: torch.Tensor, batch_size
         x, tf, y = dataset.batch(chunk)
         total += ts.step(x, tf, edge_index, edge_weight, y)
         nb += 1
-    if nb % ts.accumulation_steps != 0:
-        ts.finish_accumulation()
-    return float(total) / max(nb, 1)
+    ts.finish_accumulation()                       # trailing partial cycle (train.py:117-126); a no-op when none is open
+    from .devcheck import check_device_errors
+    mean = float(total) / max(nb, 1)               # the epoch's one host synchronisation
+    check_device_errors(edge_index.device, sync=True)
+    return mean
 
 
 @torch.no_grad()

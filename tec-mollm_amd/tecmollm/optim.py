@@ -53,7 +53,9 @@ class FlatAdamW:
     """AdamW(lr, betas, eps, weight_decay) with fused global-norm clipping over flat buffers (HIP only)."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 1e-2):
+                 weight_decay: float = 1e-2, grad_tail: int = 0):
+        """grad_tail: extra fp32 slots behind the gradients in the same allocation (`flat_grad_ext`), so that a few
+        control words ride in the data-parallel all-reduce of the gradient (tecmollm/train.py: rank-divergence check)."""
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("FlatAdamW needs at least one trainable parameter")
@@ -67,7 +69,8 @@ class FlatAdamW:
         n = sum(self.sizes)
         self.n = n
         self.flat_param = torch.empty(n, device=dev, dtype=torch.float32)
-        self.flat_grad = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.flat_grad_ext = torch.zeros(n + int(grad_tail), device=dev, dtype=torch.float32)
+        self.flat_grad = self.flat_grad_ext[:n]
         self.exp_avg = torch.zeros(n, device=dev, dtype=torch.float32)
         self.exp_avg_sq = torch.zeros(n, device=dev, dtype=torch.float32)
         self._partials = torch.empty(_lib.TECM_NORM_BLOCKS, device=dev, dtype=torch.float64)

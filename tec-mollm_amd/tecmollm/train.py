@@ -19,17 +19,28 @@ import torch
 import torch.distributed as dist
 
 
-def flatten_grads(params: Iterable[torch.nn.Parameter]) -> torch.Tensor:
-    """Allocate one flat gradient buffer and make every p.grad a view into it."""
+def flatten_grads(params: Iterable[torch.nn.Parameter], tail: int = 0) -> torch.Tensor:
+    """Allocate one flat gradient buffer (plus `tail` control slots) and make every p.grad a view into it."""
     params = list(params)
     total = sum(p.numel() for p in params)
-    flat = torch.zeros(total, device=params[0].device, dtype=params[0].dtype)
+    flat = torch.zeros(total + tail, device=params[0].device, dtype=params[0].dtype)
     o = 0
     for p in params:
         n = p.numel()
         p.grad = flat[o:o + n].view_as(p)
         o += n
     return flat
+
+
+def broadcast_parameters(model: torch.nn.Module, src: int = 0, group=None) -> int:
+    """What the DDP constructor does once (train.py:354): every parameter and buffer of rank `src` replaces the
+    other ranks' copy, so the ranks start identical whatever their seeds were.  Returns the bytes broadcast."""
+    n = 0
+    with torch.no_grad():
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, src=src, group=group)
+            n += t.numel() * t.element_size()
+    return n
 
 
 def allreduce_mean_(flat: torch.Tensor, world_size: int, group=None) -> torch.Tensor:
@@ -56,10 +67,20 @@ class TrainStep:
 
     def __init__(self, model: torch.nn.Module, lr: float = 1e-4, weight_decay: float = 1e-2, max_norm: float = 1.0,
                  accumulation_steps: int = 1, world_size: int = 1, group=None, fused_huber: bool = True,
-                 optimizer: str = "native"):
+                 optimizer: str = "native", broadcast_init: bool = True, check_divergence: bool = True):
         if optimizer not in ("native", "torch"):
             raise ValueError("optimizer must be 'native' or 'torch'")
         self.model = model
+        self.rank = dist.get_rank(group) if world_size > 1 else 0
+        if world_size > 1 and dist.get_world_size(group) != world_size:
+            raise ValueError(f"world_size={world_size} but the process group has {dist.get_world_size(group)} ranks")
+        if world_size > 1 and broadcast_init:
+            broadcast_parameters(model, 0, group)              # before the flat buffers copy the parameters
+        # rank-divergence check: 2 fp32 slots per rank ride behind the gradient in the SAME all-reduce (rank r fills
+        # its own pair with the checksum of its parameters, zeros elsewhere; adding zeros is exact, so after the sum
+        # every rank holds every checksum) -- no extra collective, no host synchronisation
+        self.check_divergence = bool(check_divergence) and world_size > 1
+        tail = 2 * world_size if self.check_divergence else 0
         self.params: List[torch.nn.Parameter] = [p for p in model.parameters() if p.requires_grad]
         self.max_norm = max_norm
         self.accumulation_steps = accumulation_steps
@@ -69,11 +90,13 @@ class TrainStep:
         self.native = optimizer == "native"
         if self.native:
             from .optim import CosineWarmRestarts, FlatAdamW
-            self.optimizer = FlatAdamW(self.params, lr=lr, weight_decay=weight_decay)
+            self.optimizer = FlatAdamW(self.params, lr=lr, weight_decay=weight_decay, grad_tail=tail)
             self.flat_grad = self.optimizer.flat_grad
+            self.flat_grad_ext = self.optimizer.flat_grad_ext
             self.scheduler = CosineWarmRestarts(lr, T_0=10, T_mult=2, eta_min=1e-7)
         else:
-            self.flat_grad = flatten_grads(self.params)
+            self.flat_grad_ext = flatten_grads(self.params, tail)
+            self.flat_grad = self.flat_grad_ext[:self.flat_grad_ext.numel() - tail]
             self.optimizer = torch.optim.AdamW(self.params, lr=lr, weight_decay=weight_decay,
                                                fused=self.params[0].is_cuda)
             self.scheduler = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(self.optimizer, T_0=10, T_mult=2,
@@ -98,22 +121,60 @@ class TrainStep:
         (loss / self.accumulation_steps).backward()
         if self.native:
             self.optimizer.absorb_grads()
-        self._micro += 1
-        if self._micro % self.accumulation_steps == 0:
+        self._micro += 1                               # micro-batches since the last optimizer step (train.py:92: (i+1) % acc
+        if self._micro >= self.accumulation_steps:     # counted per epoch there: `finish_accumulation` restarts the count)
             self.finish_accumulation()
         return loss.detach()
 
+    # ------------------------------------------------------------------ data-parallel exchange
+    def _param_checksum(self) -> torch.Tensor:
+        if self.native:
+            return self.optimizer.flat_param.sum(dtype=torch.float64)
+        return torch.stack([p.detach().sum(dtype=torch.float64) for p in self.params]).sum()
+
+    def _allreduce_grads(self) -> None:
+        """The path's ONE collective per optimizer step (train.py:354 semantics): SUM of the flat gradient, with the
+        per-rank parameter checksums in its tail."""
+        if self.world_size == 1:
+            return
+        if not self.check_divergence:
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            return
+        n = self.flat_grad.numel()
+        tail = self.flat_grad_ext[n:]
+        c = self._param_checksum()
+        hi = c.float()
+        lo = (c - hi.double()).float()
+        tail.zero_()
+        tail[2 * self.rank:2 * self.rank + 2] = torch.stack([hi, lo])
+        dist.all_reduce(self.flat_grad_ext, op=dist.ReduceOp.SUM, group=self.group)
+        pairs = tail.view(self.world_size, 2)
+        diverged = (pairs != pairs[0]).any()
+        if tail.is_cuda:
+            from . import devcheck
+            errs = devcheck.error_word(tail.device)
+            errs.poll()
+            errs.word.bitwise_or_(diverged.to(torch.int32) * devcheck.RANKS_DIVERGED)
+            errs.post()
+        elif bool(diverged):
+            raise RuntimeError(f"data-parallel ranks no longer hold identical parameters: checksums {pairs.tolist()}")
+
     def finish_accumulation(self) -> None:
         """The boundary of an accumulation cycle (also train.py:117-126 for a trailing partial cycle):
-        all-reduce, clip, AdamW, zero_grad, scheduler."""
+        all-reduce, clip, AdamW, zero_grad, scheduler.  A call with nothing accumulated is a no-op (the reference
+        only flushes a trailing PARTIAL cycle)."""
+        if self._micro == 0:
+            return
+        self._micro = 0
         if self.native:
-            if self.world_size > 1:
-                dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            self._allreduce_grads()
             self.optimizer.step(lr=self.scheduler.lr, max_norm=self.max_norm, grad_scale=1.0 / self.world_size,
                                 zero_grad=True)
         else:
-            allreduce_mean_(self.flat_grad, self.world_size, self.group)
+            self._allreduce_grads()
+            if self.world_size > 1:
+                self.flat_grad.div_(self.world_size)
             clip_flat_(self.flat_grad, self.max_norm)
             self.optimizer.step()
-            self.flat_grad.zero_()
+            self.flat_grad_ext.zero_()
         self.scheduler.step()

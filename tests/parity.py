@@ -110,11 +110,11 @@ def device_masks(cfg: dict, B: int, ei: torch.Tensor, base_seed: int, gat_graphs
     slot = np.empty(order.size, dtype=np.int64)
     slot[order] = slot_sorted
     d_ns = dst[nonself]
-    # oracle edge order: batched_edge_index -> (edge e, graph g) at e*G + g, self loops of the INPUT removed, then one
+    # oracle edge order: batched_edge_index -> (graph g, edge e) at g*E + e, self loops of the INPUT removed, then one
     # self loop per row 0..M-1
     g_ids = np.arange(Gedges, dtype=np.int64)
-    row_e = (d_ns[:, None] + g_ids[None, :] * N).reshape(-1)
-    slot_e = np.repeat(slot, Gedges)
+    row_e = (g_ids[:, None] * N + d_ns[None, :]).reshape(-1)
+    slot_e = np.tile(slot, Gedges)
     M = Gtot * N
     row_l = np.arange(M, dtype=np.int64)
     node_l = row_l % N

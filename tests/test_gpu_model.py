@@ -512,3 +512,16 @@ def test_out_of_range_time_index_is_rejected_not_clamped(dev):
     tfeat[7, 1] = 366.0
     with pytest.raises(IndexError, match="day-of-year"):
         SlidingWindowSamplerDataset.from_tensors(X, Y, tfeat, 16, 12, device=dev)
+
+
+def test_unfreezing_a_gpt2_base_weight_is_refused(dev):
+    """modules.py:195-203 trains only lora_/ln_/wpe inside GPT-2; the HIP backward forms exactly those gradients, so a
+    base weight with requires_grad=True must raise instead of silently receiving no gradient."""
+    from tecmollm import TecmError
+    cfg = R.default_config(L_in=16, L_out=12, num_nodes=12, llm_layers=1)
+    model = build_model(cfg, R.init_params(cfg, seed=1), dev).eval()
+    x, tf, _ = R.synthetic_batch(1, 16, 12, 6, 12, seed=2)
+    ei = R.grid_graph(3, 4, threshold_km=170.0)[0].to(dev)
+    model.llm_backbone.trunk.h[0].mlp.c_fc.weight.requires_grad_(True)
+    with pytest.raises(TecmError, match="mlp.c_fc.weight"):
+        model(x.to(dev), tf.to(dev), ei)

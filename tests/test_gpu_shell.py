@@ -315,6 +315,96 @@ def test_model_trains_under_the_reference_ddp_wrapper(dev):
         torch.testing.assert_close(out[0][k], g, rtol=2e-4, atol=1e-6, msg=k)
 
 
+# ------------------------------------------------------------------------------------ the product's own DP step
+def _native_dp_worker(rank, world, port, out, mismatch):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import tecmollm
+        from oracle import ref_cpu as R
+        from tecmollm.train import TrainStep
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        cfg = R.default_config(L_in=16, L_out=12, num_nodes=6, llm_layers=1)
+        # rank 1 is BUILT from other weights: TrainStep's initial broadcast (train.py:354) must make the ranks equal
+        model = _model(cfg, 3 + (rank if not mismatch else 10 * rank), dev).eval()
+        ts = TrainStep(model, lr=1e-3, world_size=world, broadcast_init=not mismatch)
+        x, tf, ei, y = _inputs(cfg, 4, (2, 3), 7, dev)
+        sl = slice(2 * rank, 2 * rank + 2)
+        try:
+            for _ in range(3):
+                ts.step(x[sl], tf[sl], ei, None, y[sl])
+            tecmollm.check_device_errors(dev, sync=True)
+            out[rank] = ("ok", ts.optimizer.flat_param.detach().cpu(), int(ts.optimizer.flat_grad_ext.numel() - ts.optimizer.n))
+        except RuntimeError as e:
+            out[rank] = ("diverged", str(e))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_native_train_step_two_ranks_equals_single_process_on_the_global_batch(dev):
+    """The product's own data-parallel path on the real model (two ranks share this GPU over gloo; RCCL runs the same
+    code with backend nccl): flat gradient buffer, ONE all-reduce per optimizer step with the parameter checksums in its
+    tail, the 1/world mean folded into the fused clip + AdamW kernel.  Three steps on the two halves of a batch must
+    equal three single-process steps on the whole batch (Huber mean => mean of the per-rank gradients)."""
+    import socket
+    import torch.multiprocessing as mp
+    from oracle import ref_cpu as R
+    from tecmollm.train import TrainStep
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_native_dp_worker, args=(2, port, out, False), nprocs=2, join=True)
+    assert out[0][0] == "ok" and out[1][0] == "ok", (out[0], out[1])
+    assert torch.equal(out[0][1], out[1][1])                       # ranks stay bit-identical
+    assert out[0][2] == 4                                          # 2 checksum slots per rank ride in the all-reduce
+    cfg = R.default_config(L_in=16, L_out=12, num_nodes=6, llm_layers=1)
+    model = _model(cfg, 3, dev).eval()
+    ts = TrainStep(model, lr=1e-3, world_size=1)
+    x, tf, ei, y = _inputs(cfg, 4, (2, 3), 7, dev)
+    for _ in range(3):
+        ts.step(x, tf, ei, None, y)
+    single = ts.optimizer.flat_param.detach().cpu()
+    torch.testing.assert_close(out[0][1], single, rtol=1e-4, atol=1e-6)
+    moved = float((single - torch.cat([p.detach().flatten().cpu() for p in _model(cfg, 3, dev).parameters()
+                                       if p.requires_grad])).abs().max())
+    assert moved > 1e-4                                            # the three steps really updated the parameters
+
+
+def test_native_train_step_reports_diverged_ranks(dev):
+    """Without the initial broadcast, ranks built from different weights are caught by the checksum tail of the first
+    gradient all-reduce (device error word -> RuntimeError at the next check, no synchronisation inside the step)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_native_dp_worker, args=(2, port, out, True), nprocs=2, join=True)
+    assert out[0][0] == "diverged" and out[1][0] == "diverged", (out[0], out[1])
+    assert "identical parameters" in out[0][1]
+
+
+def test_bench_py_starts_its_own_ranks(dev):
+    """`python bench.py --gpus 2` with no torchrun around it must measure 2 ranks (here over gloo on the one GPU of the
+    box; on an N-GPU node the same launcher runs RCCL): n_gpus = 2, the collective saw 2 ranks, global batch 2 x B."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TECM_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "1", "--no-kernel-timing"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 2 and line["config"]["parallelism"] == "dp2"
+    d = line["config"]["dist"]
+    assert d["world_size"] == 2 and d["allreduce_of_ones"] == 2.0 and d["launcher"] == "bench.py"
+    assert d["param_checksum_min_eq_max"] is True and line["value"] > 0
+
+
 # ------------------------------------------------------------------------------------ epoch loops
 def test_epoch_loops_train_and_validate_on_a_learnable_series(dev):
     """train_one_epoch / validate (train.py:52-168) over the device dataset: a smooth synthetic series is learnable,

@@ -77,6 +77,56 @@ def test_state_dict_keys_and_freeze_rule_match_reference_names():
     model.llm_backbone.model.gradient_checkpointing_enable()
 
 
+def test_gpt2_trunk_keys_equal_transformers_gpt2model_keys():
+    """test.py:175-190 loads checkpoints with strict=True, so the trunk must expose exactly the parameter names of the
+    transformers GPT2Model the reference wraps (modules.py:165-170), modulo peft's c_attn -> c_attn.base_layer rename
+    and the added lora_A/lora_B; persistent buffers included."""
+    from transformers import GPT2Config, GPT2Model
+    from src.model.modules import LLMBackbone, hf_key_of
+    with torch.device("meta"):
+        hf = GPT2Model(GPT2Config())
+    hf_keys = {k for k in hf.state_dict() if not k.startswith("h.") or int(k.split(".")[1]) < 3}
+    bb = LLMBackbone(3, include_wte=True, load_pretrained=False)
+    own = {k for k in bb.trunk.state_dict()}
+    lora = {k for k in own if ".lora_A." in k or ".lora_B." in k}
+    assert lora == {f"h.{i}.attn.c_attn.lora_{ab}.default.weight" for i in range(3) for ab in "AB"}
+    assert {hf_key_of(k) for k in own - lora} == hf_keys
+    shapes_hf = {k: tuple(v.shape) for k, v in hf.state_dict().items()}
+    for k, v in bb.trunk.state_dict().items():
+        if k not in lora:
+            assert tuple(v.shape) == shapes_hf[hf_key_of(k)], k
+
+
+def test_pretrained_gpt2_copy_is_complete_or_raises():
+    """A partial copy of the GPT-2 checkpoint must raise (the reference's from_pretrained either loads everything or
+    fails, modules.py:165): every non-LoRA trunk tensor is copied, a missing or mis-shaped key is an error, and the
+    default constructor does not fall back to random weights when the checkpoint cannot be had."""
+    from transformers import GPT2Config, GPT2Model
+    from src.model.modules import LLMBackbone, copy_hf_gpt2_weights
+    torch.manual_seed(0)
+    hf = GPT2Model(GPT2Config(n_layer=3, vocab_size=64))
+    bb = LLMBackbone(3, include_wte=False, load_pretrained=False)
+    sd = hf.state_dict()
+    with torch.no_grad():
+        n = copy_hf_gpt2_weights(bb.trunk, sd)
+    assert n == len([k for k in bb.trunk.state_dict() if "lora_" not in k])
+    assert torch.equal(bb.trunk.h[2].attn.c_attn.base_layer.weight, sd["h.2.attn.c_attn.weight"])
+    assert torch.equal(bb.trunk.wpe.weight, sd["wpe.weight"])
+    broken = {k: v for k, v in sd.items() if k != "h.1.mlp.c_fc.bias"}
+    with pytest.raises(RuntimeError, match="h.1.mlp.c_fc.bias"):
+        copy_hf_gpt2_weights(bb.trunk, broken)
+    broken = dict(sd)
+    broken["ln_f.weight"] = torch.zeros(5)
+    with pytest.raises(RuntimeError, match="ln_f.weight"):
+        copy_hf_gpt2_weights(bb.trunk, broken)
+    try:
+        full = LLMBackbone(3, include_wte=False)             # load_pretrained defaults to True, like the reference
+    except Exception as e:                                   # offline box: loud, never a silent random backbone
+        assert "gpt2" in str(e).lower() or "offline" in str(e).lower() or "connect" in str(e).lower(), e
+    else:
+        assert float(full.trunk.wpe.weight.abs().max()) > 0.2     # the real checkpoint (config init is N(0, 0.02))
+
+
 def test_graph_csr_and_windows():
     from tecmollm import graph
     ei, _ = R.grid_graph()
@@ -200,6 +250,84 @@ def test_data_parallel_step_two_ranks_equals_single_rank_on_global_batch():
     assert torch.allclose(out[0], single, rtol=1e-5, atol=1e-6)
 
 
+def _sync_worker(rank, world, port, out, broadcast_init):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tecmollm.train import TrainStep
+        torch.manual_seed(100 + rank)                      # the ranks start from DIFFERENT weights
+        model = _Toy()
+        ts = TrainStep(model, world_size=world, fused_huber=False, optimizer="torch", broadcast_init=broadcast_init)
+        g = torch.Generator().manual_seed(7)
+        X, Y = torch.randn(4, 5, 9, 6, generator=g), torch.randn(4, 12, 9, 1, generator=g)
+        sl = slice(rank * 2, rank * 2 + 2)
+        try:
+            for _ in range(2):
+                ts.step(X[sl], None, None, None, Y[sl])
+            out[rank] = ("ok", torch.cat([p.detach().flatten() for p in model.parameters()]))
+        except RuntimeError as e:
+            out[rank] = ("diverged", str(e))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rank_divergence_is_detected_and_initial_broadcast_prevents_it():
+    """train.py:354: the DDP constructor broadcasts rank 0's parameters.  TrainStep does the same (broadcast_init), and
+    every optimizer step carries the per-rank parameter checksums in the tail of the ONE gradient all-reduce: ranks
+    that started from different weights are caught on the first step when the broadcast is switched off."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_sync_worker, args=(2, _free_port(), out, True), nprocs=2, join=True)
+    assert out[0][0] == "ok" and out[1][0] == "ok" and torch.equal(out[0][1], out[1][1])
+    out2 = mgr.dict()
+    mp.spawn(_sync_worker, args=(2, _free_port(), out2, False), nprocs=2, join=True)
+    assert out2[0][0] == "diverged" and out2[1][0] == "diverged"
+    assert "identical parameters" in out2[0][1]
+
+
+def test_accumulation_boundaries_restart_every_epoch_like_the_reference_loop():
+    """train.py:92-126 counts (i + 1) % accumulation_steps PER EPOCH and flushes a trailing partial cycle: with 10
+    batches and accumulation 4 every epoch makes 2 full updates + 1 flush = 3 optimizer and scheduler steps, and
+    epoch 2 starts a fresh cycle (it must not fire after 2 batches because epoch 1 left 2 over)."""
+    from tecmollm.loop import train_one_epoch
+    from tecmollm.train import TrainStep
+
+    class _DS:
+        def __init__(self, n):
+            g = torch.Generator().manual_seed(3)
+            self.X, self.Y = torch.randn(n, 5, 9, 6, generator=g), torch.randn(n, 12, 9, 1, generator=g)
+
+        def __len__(self):
+            return len(self.X)
+
+        def batch(self, idx):
+            return self.X[idx], None, self.Y[idx]
+
+    torch.manual_seed(0)
+    model = _Toy()
+    ts = TrainStep(model, accumulation_steps=4, fused_huber=False, optimizer="torch")
+    fired = []
+    orig = ts.optimizer.step
+    ts.optimizer.step = lambda *a, **k: (fired.append(ts._seen), orig(*a, **k))[1]
+    ts._seen = 0
+    step0 = ts.step
+
+    def counting_step(*a):
+        ts._seen += 1
+        return step0(*a)
+    ts.step = counting_step
+    ds = _DS(10)
+    ei = torch.zeros(2, 0, dtype=torch.int64)
+    for _ in range(3):
+        train_one_epoch(ts, ds, ei, batch_size=1)
+    # optimizer steps after micro-batches 4, 8, 10 of every epoch (reference: i+1 in {4, 8} then the trailing flush)
+    assert fired == [4, 8, 10, 14, 18, 20, 24, 28, 30]
+    assert ts.scheduler.last_epoch == 9
+    assert float(ts.flat_grad.abs().sum()) == 0.0
+    ts.finish_accumulation()                               # nothing accumulated: no spurious AdamW / scheduler step
+    assert len(fired) == 9 and ts.scheduler.last_epoch == 9
+
+
 def test_accumulation_fires_optimizer_on_boundary_only():
     from tecmollm.train import TrainStep
     torch.manual_seed(0)
@@ -294,6 +422,23 @@ def test_grid_graph_matches_reference_graph_constructor(golden_dir):
     assert np.array_equal(ei_o.numpy(), g["full_edge_index"].astype(np.int64))
     np.testing.assert_allclose(ew_o.numpy(), g["full_edge_weight"], rtol=1e-6)
     assert ei_o.shape[1] == 20924
+
+
+def test_bench_multi_gpu_launcher_fails_loudly_without_gpus():
+    """`python bench.py --gpus 2` starts its own ranks; on a box with fewer than 2 visible GPUs it must exit non-zero
+    with a message instead of silently measuring one device (and without initialising a GPU in the launcher)."""
+    import subprocess
+    import sys
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than 2 GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TECM_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "visible GPUs" in r.stderr and not r.stdout.strip()
+    # under torchrun-style env with a mismatching --gpus the rank refuses as well
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"],
+                       env=dict(env, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
 
 
 def test_synthetic_inputs_do_not_come_from_the_oracle():

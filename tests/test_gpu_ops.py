@@ -335,8 +335,18 @@ def test_huber_and_transpose(dev):
 
 
 # ----------------------------------------------------------------------------- dropout_apply (tec_mollm.py:115)
-@pytest.mark.parametrize("rows,cols,ld,p", [(1000, 768, 768, 0.1), (37, 100, 800, 0.25), (5, 3, 3, 0.5),
-                                            (513, 768, 768, 0.0)])
+def test_dropout_apply_rejects_what_it_cannot_serve(dev):
+    from tecmollm import TecmError, ops
+    src = _rand(8, 6, dev=dev)
+    with pytest.raises(TecmError):
+        ops.dropout_apply(src, 8, 6, ops.drop(0.5, 1, 6))          # rows are not 16-byte friendly
+    src = _rand(8, 8, dev=dev)
+    with pytest.raises(TecmError):
+        ops.dropout_apply(src, 8, 8, ops.drop(0.0, 1, 8))          # p = 0: nothing to drop, callers skip the pass
+
+
+@pytest.mark.parametrize("rows,cols,ld,p", [(1000, 768, 768, 0.1), (37, 100, 800, 0.25), (5, 4, 4, 0.5),
+                                            (513, 768, 768, 0.9)])
 def test_dropout_apply_matches_numpy_mirror(dev, rows, cols, ld, p):
     """tecm_dropout_apply: dst[r][c] = src[r][c] * keep(seed, r*drop.ld + c) / (1 - p), bit for bit against the NumPy
     mirror of the device hash -- the post-LLM F.dropout and the masked gradient of the embd dropout run through it."""

@@ -213,7 +213,7 @@ def test_window_batch_full_grid_and_odd_row_width(dev):
         T = L_in + L_out + 9
         X = rng.standard_normal((T, Hh, Ww, Cc)).astype(np.float32)
         Y = rng.standard_normal((T, Hh, Ww, L_out)).astype(np.float32)
-        TF = rng.integers(0, 12, (T, 4)).astype(np.float32)
+        TF = np.stack([rng.integers(0, hi, T) for hi in (12, 366, 13, 4)], 1).astype(np.float32)
         ref = S.SlidingWindows(X, Y, TF, L_in, L_out, 2)
         ds = SlidingWindowSamplerDataset.from_tensors(torch.from_numpy(X), torch.from_numpy(Y), torch.from_numpy(TF),
                                                       L_in, L_out, 2, device=dev)
@@ -366,7 +366,9 @@ def test_native_train_step_two_ranks_equals_single_process_on_the_global_batch(d
     for _ in range(3):
         ts.step(x, tf, ei, None, y)
     single = ts.optimizer.flat_param.detach().cpu()
-    torch.testing.assert_close(out[0][1], single, rtol=1e-4, atol=1e-6)
+    # three AdamW steps (lr 1e-3) move a parameter by ~3e-3; the two-rank mean adds the two half-batch gradients in a
+    # different order than the single batch, and Adam's g / sqrt(v) amplifies that on near-zero gradients
+    torch.testing.assert_close(out[0][1], single, rtol=1e-3, atol=2e-5)
     moved = float((single - torch.cat([p.detach().flatten().cpu() for p in _model(cfg, 3, dev).parameters()
                                        if p.requires_grad])).abs().max())
     assert moved > 1e-4                                            # the three steps really updated the parameters

@@ -145,7 +145,15 @@ typedef struct TecmSpatial {
    * table sets TECM_BAD_TOD/DOY/YEAR/SEASON, and every output row built from it is NaN -- never a clamped, valid
    * looking embedding.  The caller reads the word back when it next synchronises (tecmollm/devcheck.py). */
   int32_t* err_flag;
+  int32_t flags;                          /* TECM_SPATIAL_*; 0 = the fused stage as TEC_MoLLM.forward runs it */
+  int32_t out_ld;                         /* row pitch of out: 24 (padded, 16-byte rows) in the fused path, >= 22 otherwise */
 } TecmSpatial;
+/* Stand-alone forms of the two modules the kernel fuses (their own `forward` in the reference):
+ *   TECM_SPATIAL_EMBED_ONLY   SpatioTemporalEmbedding.forward (modules.py:230-266): out = cat([x, emb]), no graph work;
+ *   TECM_SPATIAL_NO_RESIDUAL  SpatialEncoder.forward (modules.py:340-359): out = GATv2Conv(h) without `h +`; with
+ *                             Demb = 0 the input rows ARE h (Cin = 22) and no table is read. */
+#define TECM_SPATIAL_EMBED_ONLY 1
+#define TECM_SPATIAL_NO_RESIDUAL 2
 #define TECM_BAD_TOD 1
 #define TECM_BAD_DOY 2
 #define TECM_BAD_YEAR 4

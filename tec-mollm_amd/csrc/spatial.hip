@@ -19,55 +19,19 @@
 // The 22x22 weight gradients are outer products sum_rows dxl^T [h,1]: they run on the f32 matrix cores
 // (one 32x32 accumulator per wave, kept in registers across the block's timesteps); only the (N, Demb)
 // node table sees float atomics (contiguous 256 B per wave instruction).
-#include "common.h"
+#include "spatial_common.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef SP_SKIP
 #define SP_SKIP 0      // experiments only: bit0 skip dense x_l/x_r, bit1 edge phase, bit2 outer products, bit3 embedding grads
 #endif
 
+using namespace tecm_spatial;
+
 namespace {
 
-constexpr float NEG_SLOPE = 0.2f;
-constexpr int C = 22;      // feature channels (Cin + Demb)
-constexpr int H = 2;       // heads
-constexpr int CH = C / H;
-constexpr int CP = 24;     // padded row: 16-byte aligned, column 22 carries the constant 1 of the bias trick
 constexpr int DXP = 25;    // row pitch of the d x_l accumulators: odd, so the per-edge LDS float atomics of a wave (same
                            // column, 64 different rows) hit 64 different banks instead of 8 (measured: the edge phase
                            // of the backward is bound by ds_add_f32 under bank conflicts)
-
-__device__ __forceinline__ int clampi(int v, int hi) { return v < 0 ? 0 : (v >= hi ? hi - 1 : v); }
-
-struct TimeIdx {
-  int tod, doy, year, season;
-  int bad;      // TECM_BAD_* bits: an index outside its table (the reference's nn.Embedding raises, modules.py:255-258)
-};
-__device__ __forceinline__ TimeIdx load_time_idx(const TecmSpatial& d, int b, int t, int node) {
-  const float* p = d.tf + (int64_t)b * d.tf_sb + (int64_t)t * d.tf_sl + (int64_t)node * d.tf_sn;
-  TimeIdx ti;
-  const int tod = (int)p[0], doy = (int)p[d.tf_sf];     // .long() truncation, modules.py:250-253
-  const int year = (int)p[2 * d.tf_sf], season = (int)p[3 * d.tf_sf];
-  ti.bad = ((unsigned)tod >= 12u ? TECM_BAD_TOD : 0) | ((unsigned)doy >= 366u ? TECM_BAD_DOY : 0) |
-           ((unsigned)year >= (unsigned)d.year_rows ? TECM_BAD_YEAR : 0) | ((unsigned)season >= 4u ? TECM_BAD_SEASON : 0);
-  // clamped only so that the table reads below stay inside their allocations; a bad index never yields a value
-  ti.tod = clampi(tod, 12);
-  ti.doy = clampi(doy, 366);
-  ti.year = clampi(year, d.year_rows);
-  ti.season = clampi(season, 4);
-  return ti;
-}
-// ((tod + doy) + year) + season -- the exact association of modules.py:260.  An out-of-range index is reported through
-// the device error word and turns the embedding into NaN: it is rejected, not repaired.
-__device__ __forceinline__ float temporal_emb(const TecmSpatial& d, const TimeIdx& ti, int k) {
-  const int D = d.Demb;
-  if (ti.bad) {
-    atomicOr(d.err_flag, ti.bad);
-    return __builtin_nanf("");
-  }
-  return ((d.tod_tab[ti.tod * D + k] + d.doy_tab[ti.doy * D + k]) + d.year_tab[ti.year * D + k]) +
-         d.season_tab[ti.season * D + k];
-}
 
 // h = cat([x, node_emb + temporal_emb])  (modules.py:261-264)
 __device__ __forceinline__ void build_h(const TecmSpatial& d, const float* xrow, int node, const float* temb_lds,
@@ -156,8 +120,6 @@ __device__ __forceinline__ void dense_rows(float* OUT, const float* A, int beg, 
   }
 }
 
-__device__ __forceinline__ float lrelu(float s) { return s > 0.f ? s : NEG_SLOPE * s; }
-
 __device__ __forceinline__ void load_row(const float* row, float (&v)[C]) {
   const float4* p = reinterpret_cast<const float4*>(row);
 #pragma unroll
@@ -182,21 +144,6 @@ __device__ __forceinline__ void store_row(float* row, const float (&v)[C], float
   }
 }
 
-// the CH = 11 channels of head hh out of a 24-float row (16-byte aligned): head 0 = floats 0..10, head 1 = 11..21
-__device__ __forceinline__ void load_head(const float* row, int hh, float (&v)[CH]) {
-  static_assert(CH == 11, "head slicing is written for 11 channels per head");
-  const float4* p = reinterpret_cast<const float4*>(row);
-  if (hh == 0) {
-    const float4 a = p[0], b = p[1], c = p[2];
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-    v[8] = c.x; v[9] = c.y; v[10] = c.z;
-  } else {
-    const float4 a = p[2], b = p[3], c = p[4], e = p[5];
-    v[0] = a.w; v[1] = b.x; v[2] = b.y; v[3] = b.z; v[4] = b.w; v[5] = c.x; v[6] = c.y; v[7] = c.z;
-    v[8] = c.w; v[9] = e.x; v[10] = e.y;
-  }
-}
-
 __device__ __forceinline__ void logits(const float (&xlj)[C], const float (&xr)[C], const float (&att)[C],
                                        float (&e)[H]) {
 #pragma unroll
@@ -215,111 +162,6 @@ __device__ __forceinline__ void build_window(const TecmSpatial& d, float* hw, in
     float h[C];
     build_h(d, d.x + (grow + lo + w) * d.Cin, lo + w, temb_p, b, t, h);
     store_row(hw + w * CP, h, 1.0f, 0.f);
-  }
-}
-
-// ------------------------------------------------------------------------------------------ forward
-__global__ __launch_bounds__(256) void spatial_fwd_kernel(const TecmSpatial d) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tile = blockIdx.x;
-  const int b = blockIdx.y / d.L, t = blockIdx.y - b * d.L;
-  const bool use_edges = (t * d.B + b) < d.graphs_with_edges;
-  const int n0 = tile * d.tile_nodes;
-  const int n1 = min(d.N, n0 + d.tile_nodes);
-  const int lo = use_edges ? d.tile_lo[tile] : n0;
-  const int hi = use_edges ? d.tile_hi[tile] : n1;
-  const int W = hi - lo;
-  const int wm4 = (d.win_max + 3) & ~3;
-  float* hw = smem;                                    // [wm4][CP]  [h | 1 | 0]
-  float* xlw = hw + wm4 * CP;                          // [wm4][CP]  x_l of the window
-  float* xrw = xlw + wm4 * CP;                         // [tile_nodes][CP]  x_r of the tile, later the output tile
-  float* temb = xrw + d.tile_nodes * CP;               // [32]
-  MatsLds mats;
-  stage_mats(d, temb + 32, mats, false);
-  // CSR slice of this tile, window-relative, in LDS: the edge loop must not chase global memory per edge
-  int* eptr = reinterpret_cast<int*>(temb + 32 + 2 * KM_FLOATS);   // [tile_nodes + 1]
-  int* ecol = eptr + d.tile_nodes + 1;                             // [tile_edges_max]
-  if (use_edges) {
-    const int ebase = d.rowptr[n0];
-    for (int q = tid; q <= n1 - n0; q += 256) eptr[q] = d.rowptr[n0 + q] - ebase;
-    const int ne = d.rowptr[n1] - ebase;
-    for (int q = tid; q < ne; q += 256) ecol[q] = d.colidx[ebase + q] - lo;
-  }
-  const bool tf_uniform = d.tf_sn == 0;
-  const int64_t grow = ((int64_t)b * d.L + t) * d.N;   // first row of this graph
-  if (tf_uniform && tid < d.Demb) {
-    const TimeIdx ti = load_time_idx(d, b, t, 0);
-    temb[tid] = temporal_emb(d, ti, tid);
-  }
-  float att[C], bias[C];
-#pragma unroll
-  for (int c = 0; c < C; ++c) { att[c] = d.att[c]; bias[c] = d.bias[c]; }
-  __syncthreads();
-  build_window(d, hw, 0, W, lo, grow, tf_uniform ? temb : nullptr, b, t);
-  __syncthreads();
-  dense_rows(xlw, hw, 0, W, mats.WlT, wave, lane);                          // x_l for the whole window
-  dense_rows(xrw - (n0 - lo) * CP, hw, n0 - lo, n1 - lo, mats.WrT, wave, lane);   // x_r for the tile
-  __syncthreads();
-
-  const int i = n0 + tid;
-  if (i < n1) {
-    const int wi = i - lo;
-    float xr[C], xls[C];
-    load_row(xrw + tid * CP, xr);
-    load_row(xlw + wi * CP, xls);
-    float m[H], z[H], acc[C];
-#pragma unroll
-    for (int hh = 0; hh < H; ++hh) { m[hh] = -INFINITY; z[hh] = 0.f; }
-#pragma unroll
-    for (int c = 0; c < C; ++c) acc[c] = 0.f;
-    const uint32_t dth = d.alpha_drop.p > 0.f ? tecm_drop_thresh(d.alpha_drop.p) : 0u;
-    const float dinv = d.alpha_drop.p > 0.f ? 1.0f / (1.0f - d.alpha_drop.p) : 1.0f;
-    const int64_t rowi = (int64_t)(t * d.B + b) * d.N + i;     // row in the reference's (L*B*N) flattening
-    const int e0 = use_edges ? eptr[tid] : 0;
-    const int deg = use_edges ? eptr[tid + 1] - e0 : 0;
-    for (int s = 0; s <= deg; ++s) {
-      float xlj[C];
-      if (s == deg) {
-#pragma unroll
-        for (int c = 0; c < C; ++c) xlj[c] = xls[c];
-      } else {
-        load_row(xlw + ecol[e0 + s] * CP, xlj);
-      }
-      float e[H];
-      logits(xlj, xr, att, e);
-#pragma unroll
-      for (int hh = 0; hh < H; ++hh) {
-        const float mn = fmaxf(m[hh], e[hh]);
-        const float corr = __expf(m[hh] - mn);      // exp(-inf) = 0 on the first edge
-        const float p = __expf(e[hh] - mn);
-        float pm = p;
-        if (dth) pm *= tecm_drop_mult(d.alpha_drop.seed, (uint64_t)((rowi * H + hh) * d.alpha_drop.ld + s), dth, dinv);
-        z[hh] = z[hh] * corr + p;
-        m[hh] = mn;
-#pragma unroll
-        for (int c = 0; c < CH; ++c) acc[hh * CH + c] = acc[hh * CH + c] * corr + pm * xlj[hh * CH + c];
-      }
-    }
-    float h[C], o[C];
-    load_row(hw + wi * CP, h);
-#pragma unroll
-    for (int hh = 0; hh < H; ++hh) {
-      const float inv = 1.0f / (z[hh] + 1e-16f);
-#pragma unroll
-      for (int c = 0; c < CH; ++c) {
-        const int k = hh * CH + c;
-        o[k] = h[k] + (acc[k] * inv + bias[k]);
-      }
-    }
-    store_row(xrw + tid * CP, o, 0.f, 0.f);           // this thread's x_r row is dead: reuse it for the output
-  }
-  __syncthreads();
-  {
-    const int nf4 = (n1 - n0) * CP / 4;
-    float4* dst = reinterpret_cast<float4*>(d.out + (grow + n0) * CP);
-    const float4* src = reinterpret_cast<const float4*>(xrw);
-    for (int q = tid; q < nf4; q += 256) dst[q] = src[q];
   }
 }
 
@@ -683,48 +525,7 @@ __global__ __launch_bounds__(256) void spatial_bwd_kernel(const TecmSpatial d, c
   }
 }
 
-int check_common(const char* who, const TecmSpatial& d) {
-  TECM_REQUIRE(d.B > 0 && d.L > 0 && d.N > 0 && d.Cin > 0 && d.Demb > 0 && d.H > 0, TECM_E_ARG, "%s: bad shape", who);
-  TECM_REQUIRE(d.Cin + d.Demb == C && d.H == H, TECM_E_ARG,
-               "%s: built for C = Cin + Demb = 22 channels and 2 heads (got C=%d H=%d)", who, d.Cin + d.Demb, d.H);
-  TECM_REQUIRE(d.Demb <= 32, TECM_E_ARG, "%s: Demb must be <= 32", who);
-  TECM_REQUIRE(d.x && d.tf && d.node_tab && d.tod_tab && d.doy_tab && d.year_tab && d.season_tab && d.Wl && d.bl &&
-                   d.Wr && d.br && d.att && d.bias && d.rowptr && d.colidx && d.tile_lo && d.tile_hi && d.err_flag,
-               TECM_E_ARG, "%s: null pointer", who);
-  TECM_REQUIRE(d.num_tiles > 0 && d.tile_nodes > 0 && d.tile_nodes <= 256 &&
-                   (int64_t)d.num_tiles * d.tile_nodes >= d.N && d.win_max >= 1,
-               TECM_E_ARG, "%s: bad node tiling", who);
-  TECM_REQUIRE(d.year_rows > 0, TECM_E_ARG, "%s: year_rows must be positive", who);
-  TECM_REQUIRE(d.tile_edges_max >= 0, TECM_E_ARG, "%s: tile_edges_max must be the max edge count of a tile", who);
-  return TECM_OK;
-}
-
-constexpr int kLdsBudget = 160 * 1024;
-
 }  // namespace
-
-extern "C" int tecm_spatial_fwd(const TecmSpatial* dp, void* stream) {
-  TECM_REQUIRE(dp != nullptr, TECM_E_ARG, "tecm_spatial_fwd: null descriptor");
-  const TecmSpatial& d = *dp;
-  const int rc = check_common("tecm_spatial_fwd", d);
-  if (rc) return rc;
-  TECM_REQUIRE(d.out != nullptr && tecm_aligned(d.out, 16), TECM_E_ALIGN, "tecm_spatial_fwd: out must be 16-byte aligned");
-  const int wm4 = (d.win_max + 3) & ~3;
-  const size_t lds = sizeof(float) * ((size_t)2 * wm4 * CP + (size_t)d.tile_nodes * CP + 32 + 2 * KM_FLOATS +
-                                      d.tile_nodes + 1 + d.tile_edges_max);
-  TECM_REQUIRE(lds <= (size_t)kLdsBudget, TECM_E_LDS,
-               "tecm_spatial_fwd: neighbour window of %d rows needs %zu B of LDS (> 160 KiB); renumber the graph "
-               "(e.g. RCM) or shrink tile_nodes", d.win_max, lds);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        kLdsBudget);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(spatial_fwd_kernel, dim3(d.num_tiles, d.B * d.L), dim3(256), lds, (hipStream_t)stream, d);
-  TECM_CHECK_LAUNCH("tecm_spatial_fwd");
-  return TECM_OK;
-}
 
 extern "C" int tecm_spatial_bwd(const TecmSpatial* dp, const TecmSpatialGrads* gp, void* stream) {
   TECM_REQUIRE(dp != nullptr && gp != nullptr, TECM_E_ARG, "tecm_spatial_bwd: null descriptor");

@@ -62,6 +62,7 @@ class TecmSpatial(C.Structure):
         ("alpha_drop", TecmDrop),
         ("out", c_f32p),
         ("err_flag", C.c_void_p),
+        ("flags", C.c_int32), ("out_ld", C.c_int32),
     ]
 
 

@@ -115,6 +115,7 @@ class SpatialFn(torch.autograd.Function):
         if sp is not None:
             d.alpha_drop = sp
         d.err_flag = devcheck.error_word(x.device).ptr()
+        d.flags, d.out_ld = 0, CP
         return d
 
     @staticmethod

@@ -34,3 +34,21 @@ for _ in range(5):
     e[0].record(); o = run(); e[1].record(); o.backward(go); e[2].record(); torch.cuda.synchronize()
     tf_ += e[0].elapsed_time(e[1]); tb_ += e[1].elapsed_time(e[2])
 print(f"spatial fwd {tf_/5*1e3:.0f} us   bwd (incl. partial reductions) {tb_/5*1e3:.0f} us", flush=True)
+import ctypes
+from tecmollm import _lib
+h = ctypes.CDLL(_lib.LIB_PATH)
+for sym, names in (("tecm_debug_spf_stamps", ["prologue", "stage", "dense-wait", "edge-wait", "store", "dense-own", "pf-commit", "edge-own", "e:xr", "e:loop", "e:out"]),
+                   ("tecm_debug_spb_stamps", ["prologue", "stage", "dense", "B1", "B2", "outer", "flush"])):
+    if hasattr(h, sym):
+        buf = (ctypes.c_ulonglong * 16)()
+        getattr(h, sym)(buf, 1)
+        with torch.no_grad():
+            for _ in range(4):
+                run()
+        if sym.endswith("spb_stamps"):
+            for _ in range(4):
+                run().backward(go)
+        torch.cuda.synchronize()
+        getattr(h, sym)(buf, 0)
+        tot = sum(buf[:8]) or 1
+        print(sym, {n: f"{buf[i] / tot:.2f}" for i, n in enumerate(names)}, "cycles(100MHz ticks?) total", tot, flush=True)

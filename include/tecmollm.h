@@ -166,7 +166,8 @@ typedef struct TecmSpatialGrads {
   float* d_tod_tab; float* d_doy_tab; float* d_year_tab; float* d_season_tab;   /* atomics: zero before call */
   float* partials; int64_t partial_ld;    /* (num_blocks, partial_ld) per-block sums of
                                              [dWl(C*C) dbl(C) dWr(C*C) dbr(C) datt(C) dbias(C)] */
-  int32_t t_chunk; int32_t num_blocks;    /* blocks = num_tiles * B * ceil(L / t_chunk) */
+  int32_t t_chunk; int32_t num_blocks;    /* num_blocks = tecm_spatial_bwd_blocks(d): the grid the library launches
+                                             (persistent blocks over contiguous (tile, graph) ranges); t_chunk unused */
   /* the tile's edges grouped by SOURCE (d x_l is gathered per source row, no atomics): for tile k with window
    * [lo, hi) and edge segment [rowptr[n0], rowptr[n1]) of the by-target CSR,
    *   src_ptr[src_ptr_off[k] + w] .. src_ptr[src_ptr_off[k] + w + 1]   (w = j - lo, 0 <= w < hi - lo)
@@ -175,6 +176,8 @@ typedef struct TecmSpatialGrads {
   const int32_t* src_ptr; const int32_t* src_col; const int32_t* src_ptr_off;
 } TecmSpatialGrads;
 int tecm_spatial_bwd(const TecmSpatial* d, const TecmSpatialGrads* g, void* stream);
+/* Number of blocks (= rows of TecmSpatialGrads.partials) tecm_spatial_bwd will launch for `d`; negative = TECM_E_*. */
+int tecm_spatial_bwd_blocks(const TecmSpatial* d);
 
 /* ------------------------------------------------------------------ stage a-4 normalisation
  * nn.GroupNorm(1, C) + nn.GELU() (modules.py:28-29) for the three parallel branches at once.

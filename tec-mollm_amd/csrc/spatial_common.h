@@ -49,6 +49,27 @@ __device__ __forceinline__ float temporal_emb(const TecmSpatial& d, const TimeId
 
 __device__ __forceinline__ float lrelu(float s) { return s > 0.f ? s : NEG_SLOPE * s; }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr float LOG2E = 1.4426950408889634f;
+
+// LDS rows of x_l / x_r / dout (24 floats) are laid out per HEAD so that a (node, head) thread reads exactly three
+// aligned float4:   [ head 0: channels 0..10 | u0 | head 1: channels 11..21 | u1 ]
+// where, for x_l / x_r, u_h = sum_c att[h][c] * row[h][c] comes out of the same MFMA as two extra weight columns.
+// With lrelu(s) = 0.6 s + 0.4 |s| the GATv2 logit of edge j -> i is
+//      e = 0.6 (u_l[j] + u_r[i]) + 0.4 sum_c att_c |x_l[j,c] + x_r[i,c]|
+// -- two VALU operations per channel (add, fma with |.| modifier) instead of four.
+__device__ __forceinline__ int slot_of(int ch) { return ch + (ch >= CH ? 1 : 0); }
+// channel of an LDS slot: -1 for the two u slots and the padding
+__device__ __forceinline__ int chan_of(int sl) { return sl < CH ? sl : (sl == CH ? -1 : (sl < 2 * CH + 1 ? sl - 1 : -1)); }
+
+// The descriptor is the first kernel argument: rarely executed paths (tile switch, per-node time features, block
+// prologue) read it through the kernarg segment inside NOINLINE helpers, so that their two dozen pointers are not kept
+// in scalar registers (or spilled to VGPR lanes) across the per-item phases.  Call from the KERNEL body only and hand
+// the pointer down.
+__device__ __forceinline__ const char* kernarg_base() {
+  return (const char*)__builtin_amdgcn_kernarg_segment_ptr();             // C cast: drops the constant address space
+}
+
 // the CH = 11 channels of head hh out of a 24-float row (16-byte aligned): head 0 = floats 0..10, head 1 = 11..21
 __device__ __forceinline__ void load_head(const float* row, int hh, float (&v)[CH]) {
   static_assert(CH == 11, "head slicing is written for 11 channels per head");

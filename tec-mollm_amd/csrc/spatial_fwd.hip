@@ -68,22 +68,8 @@ __device__ __forceinline__ f32x16 splat16(float v) {
   return a;
 }
 
-// LDS rows of x_l / x_r (24 floats) are laid out per HEAD so that a (node, head) thread reads exactly three aligned
-// float4:   [ head 0: channels 0..10 | u0 | head 1: channels 11..21 | u1 ],   u_h = sum_c att[h][c] * row[h][c]
-// (the u columns come out of the same MFMA as two extra weight columns).  With lrelu(s) = 0.6 s + 0.4 |s| the GATv2
-// logit of edge j -> i becomes   e = 0.6 (u_l[j] + u_r[i]) + 0.4 sum_c att_c |x_l[j,c] + x_r[i,c]|
-// -- two VALU operations per channel (add, fma with |.| modifier) instead of four.
-__device__ __forceinline__ int slot_of(int ch) { return ch + (ch >= CH ? 1 : 0); }
-// channel of an LDS slot: -1 for the two u slots and the padding
-__device__ __forceinline__ int chan_of(int sl) { return sl < CH ? sl : (sl == CH ? -1 : (sl < 2 * CH + 1 ? sl - 1 : -1)); }
-
-constexpr float LOG2E = 1.4426950408889634f;
-
-// The descriptor is the first kernel argument: rarely executed paths (tile switch, per-node time features, block
-// prologue) read it through the kernarg segment inside NOINLINE helpers, so that their two dozen pointers are not kept
-// in scalar registers (or spilled to VGPR lanes) across the per-item phases.
-__device__ __forceinline__ const TecmSpatial* kernarg_desc() {     // call from the KERNEL body only
-  return (const TecmSpatial*)__builtin_amdgcn_kernarg_segment_ptr();      // C cast: drops the constant address space
+__device__ __forceinline__ const TecmSpatial* kernarg_desc() {
+  return reinterpret_cast<const TecmSpatial*>(kernarg_base());
 }
 
 struct TileState {
@@ -188,8 +174,6 @@ __device__ __attribute__((noinline)) void block_prologue(const TecmSpatial* dp, 
     }
   }
 }
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Phase 2 for one head (compile time): online softmax over the in-edges + the implicit self loop, four slots per
 // step with ONE rescale of the accumulators per step; logits pre-scaled by log2(e) so the exponentials are bare

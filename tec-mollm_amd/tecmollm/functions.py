@@ -127,9 +127,9 @@ class SpatialFn(torch.autograd.Function):
         dout = dout.contiguous()
         d = SpatialFn._desc(x, tf, node_tab, tod_tab, doy_tab, year_tab, season_tab, Wl, bl, Wr, br, att, bias, meta,
                             ctx.heads, ctx.R, ctx.plan, B, L, N, Cin, Demb)
-        t_chunk = 8
-        nchunks = (L + t_chunk - 1) // t_chunk
-        nblocks = meta.num_tiles * B * nchunks
+        nblocks = lib().tecm_spatial_bwd_blocks(C.byref(d))     # persistent blocks over contiguous (tile, graph) ranges
+        if nblocks <= 0:
+            check(nblocks, "tecm_spatial_bwd_blocks")
         Cc = C_FEAT
         pld = 2 * Cc * Cc + 4 * Cc
         partials = _empty(nblocks, pld, like=x)
@@ -140,7 +140,7 @@ class SpatialFn(torch.autograd.Function):
         g.d_node_tab, g.d_tod_tab, g.d_doy_tab = d_node.data_ptr(), d_tod.data_ptr(), d_doy.data_ptr()
         g.d_year_tab, g.d_season_tab = d_year.data_ptr(), d_season.data_ptr()
         g.partials, g.partial_ld = partials.data_ptr(), pld
-        g.t_chunk, g.num_blocks = t_chunk, nblocks
+        g.t_chunk, g.num_blocks = 0, nblocks
         g.src_ptr, g.src_col = meta.src_ptr.data_ptr(), meta.src_col.data_ptr()
         g.src_ptr_off = meta.src_ptr_off.data_ptr()
         check(lib().tecm_spatial_bwd(C.byref(d), C.byref(g), stream_ptr()), "tecm_spatial_bwd")

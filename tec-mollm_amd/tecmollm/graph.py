@@ -64,8 +64,6 @@ def tile_windows(rowptr: np.ndarray, colidx: np.ndarray, num_nodes: int, tile_no
 
 
 CP = 24
-DXP = 25            # row pitch of the backward's d x_l accumulators (csrc/spatial.hip)
-KM_FLOATS = CP * 32
 
 
 def by_source_lists(rowptr: np.ndarray, colidx: np.ndarray, num_nodes: int, tile_nodes: int, lo: np.ndarray,
@@ -94,12 +92,30 @@ def by_source_lists(rowptr: np.ndarray, colidx: np.ndarray, num_nodes: int, tile
     return np.concatenate(ptrs), src_col, np.asarray(offs, dtype=np.int32)
 
 
+MAXI = 40           # items a persistent block may own (csrc/spatial_fwd.hip, spatial_bwd.hip)
+SCR_FWD, SCR_BWD = 1192, 1448
+RED_FLOATS = 8 * 8 * 4 * 64
+MAX_WINDOW = 512    # the backward's by-source pass: two rounds of 256 rows
+
+
+def _r4(n: int) -> int:
+    return (n + 3) & ~3
+
+
+def lds_bytes_fwd(win: int, tile_nodes: int, tile_edges: int = 0) -> int:
+    """Dynamic LDS of spatial_fwd_kernel (must match csrc/spatial_fwd.hip:tecm_spatial_fwd_lds): two item slots."""
+    P, wm4 = win | 1, _r4(win)
+    return 4 * (2 * (_r4(C_FEAT * P) + wm4 * CP + tile_nodes * CP) + MAXI * 96 + tile_nodes + 1 + tile_edges + SCR_FWD)
+
+
 def lds_bytes_bwd(win: int, tile_nodes: int, demb: int = 16, tile_edges: int = 0) -> int:
-    """Dynamic LDS of spatial_bwd_kernel (must match csrc/spatial.hip:tecm_spatial_bwd)."""
-    wm4 = (win + 3) & ~3
-    floats = (2 * wm4 * CP + wm4 * DXP + 2 * tile_nodes * CP + wm4 * demb + 64 + CP + 5 * KM_FLOATS + tile_nodes + 1 +
-              2 * tile_edges + wm4 + 1 + tile_nodes * 6 + CP)
-    return 4 * max(floats, 8192 + 64)
+    """Dynamic LDS of spatial_bwd_kernel (must match csrc/spatial_bwd.hip:make_map / red_offset)."""
+    P, wm4 = win | 1, _r4(win)
+    T, E = tile_nodes, tile_edges
+    scr = (_r4((C_FEAT + 1) * P) + wm4 * CP + 2 * T * CP + (E + T) * 4 + _r4(demb * P) + MAXI * 32 + MAXI * 4)
+    total = scr + SCR_BWD + (T + 1) + E + (wm4 + 1) + E
+    red = 0 if scr >= RED_FLOATS else total
+    return 4 * max(total, red + RED_FLOATS)
 
 
 def build(edge_index: torch.Tensor, num_nodes: int, device: torch.device, demb: int = 16) -> GraphMeta:
@@ -113,7 +129,8 @@ def build(edge_index: torch.Tensor, num_nodes: int, device: torch.device, demb: 
         wmax = int((hi - lo).max())
         bounds = np.minimum(np.arange(lo.size + 1) * tn, num_nodes)
         emax = int(np.diff(rowptr[bounds]).max())
-        if lds_bytes_bwd(wmax, tn, demb, emax) <= LDS_BYTES - 4096:
+        if (max(lds_bytes_bwd(wmax, tn, demb, emax), lds_bytes_fwd(wmax, tn, emax)) <= LDS_BYTES
+                and wmax <= MAX_WINDOW):
             chosen = (tn, lo, hi, wmax, emax)
             break
     if chosen is None:

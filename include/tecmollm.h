@@ -172,7 +172,7 @@ typedef struct TecmSpatialGrads {
    * [lo, hi) and edge segment [rowptr[n0], rowptr[n1]) of the by-target CSR,
    *   src_ptr[src_ptr_off[k] + w] .. src_ptr[src_ptr_off[k] + w + 1]   (w = j - lo, 0 <= w < hi - lo)
    * index, relative to rowptr[n0], the entries of src_col that leave source j; an entry is
-   * ((target - n0) << 16) | slot, slot = position of the edge in its target's CSR row. */
+   * ((target - n0) << 16) | pos, pos = position of the edge inside the tile's by-target segment (e - rowptr[n0]). */
   const int32_t* src_ptr; const int32_t* src_col; const int32_t* src_ptr_off;
 } TecmSpatialGrads;
 int tecm_spatial_bwd(const TecmSpatial* d, const TecmSpatialGrads* g, void* stream);

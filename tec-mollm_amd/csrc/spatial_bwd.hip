@@ -27,7 +27,8 @@ constexpr int MAXI = 40;       // items one block may own (host sizes the grid a
 constexpr int NPX = 4;         // float2 registers per thread: x rows of the next item
 constexpr int NPG = 2;         // float4 registers per thread: dout rows of the next item
 constexpr int HR = C + 1;      // rows of hT: [x (Cin) | ones | emb (Demb)]
-constexpr int SRC_R = 2;       // by-source rounds a thread may own ((window rows) <= SRC_R * 256)
+constexpr int SRC_R_MAX = 2;   // by-source rounds a thread may own ((window rows) <= SRC_R * 256); 1 when the host
+                               // tiles the graph so that every window has <= 256 rows (the regular grid does)
 
 struct BwdArgs {               // the kernel's single by-value argument: kernarg offset 0
   TecmSpatial d;
@@ -38,11 +39,11 @@ struct BwdArgs {               // the kernel's single by-value argument: kernarg
 // prologue scratch (floats, relative to map.scr)
 constexpr int SCR_WL = 0, SCR_WR = C * C, SCR_ATT = 2 * C * C, SCR_BL = SCR_ATT + 32, SCR_BR = SCR_BL + 32,
               SCR_UW = SCR_BR + 32, SCR_BIASL = SCR_UW + 4 * 32, SCR_BIASR = SCR_BIASL + 32, SCR_CS = SCR_BIASR + 32,
-              SCR_BSUM = SCR_CS + 3 * 32, SCR_DATT = SCR_BSUM + 2 * 32, SCR_FLOATS = SCR_DATT + 32;
+              SCR_BSUM = SCR_CS + 2 * 8 * 96, SCR_DATT = SCR_BSUM + 2 * 32, SCR_FLOATS = SCR_DATT + 32;
 
 struct Map {                   // LDS map, float offsets into smem (ints share the same 4-byte cells)
   int P, wm4, hT_sz;
-  int hT, nodeT, xl, xr, gt, ea, tb, ti, scr, eptr, ecol, sptr, scol, total;
+  int hT, nodeT, xl, xr, gt, ea, rsum, gsum, tb, ti, scr, eptr, ecol, sptr, scol, total;
 };
 __host__ __device__ inline Map make_map(const TecmSpatial& d) {
   Map m;
@@ -56,7 +57,9 @@ __host__ __device__ inline Map make_map(const TecmSpatial& d) {
   m.gt = m.xr + T * CP;                        // [T][CP]   dout rows of the tile (head-sliced)
   m.ea = m.gt + T * CP;                        // [E + T][2 heads][2]   per edge: (e, dalpha) then (alpha~, de)
   m.nodeT = m.ea + (E + T) * 4;                // [Demb][P] static node-embedding rows of the window
-  m.tb = m.nodeT + ((d.Demb * m.P + 3) & ~3);  // [MAXI][32] temporal embedding per item
+  m.rsum = m.nodeT + ((d.Demb * m.P + 3) & ~3);   // [T][CP] sum over the tile's graphs of d x_r (node-table gradient)
+  m.gsum = m.rsum + T * CP;                    // [T][CP] ... of dout
+  m.tb = m.gsum + T * CP;                      // [MAXI][32] temporal embedding per item
   m.ti = m.tb + MAXI * 32;                     // [MAXI][4]  time indices per item (ints)
   m.scr = m.ti + MAXI * 4;                     // prologue scratch + small per-item vectors
   m.eptr = m.scr + SCR_FLOATS;                 // [T + 1]     CSR slice of the tile (by target)
@@ -106,9 +109,9 @@ struct TileState {
 // ---------------------------------------------------------------------------------------- out-of-line helpers
 // Block prologue: weights through LDS scratch (coalesced global reads only), u weights, slot-ordered bias vectors,
 // per-item temporal embeddings and time indices.
-__device__ __attribute__((noinline)) void bwd_prologue(const BwdArgs* ap, int it0, int nit, float* smem, Map m,
-                                                       bool tf_uniform) {
+__device__ __attribute__((noinline)) void bwd_prologue(const BwdArgs* ap, int it0, int nit, float* smem, bool tf_uniform) {
   const TecmSpatial& d = ap->d;
+  const Map m = make_map(d);            // rebuilt here: a struct argument of an out-of-line call would go through scratch
   const int tid = threadIdx.x, Demb = d.Demb;
   const int scr = m.scr;
   for (int i = tid; i < C * C; i += BT) {
@@ -155,11 +158,12 @@ __device__ __attribute__((noinline)) void bwd_prologue(const BwdArgs* ap, int it
     smem[scr + (mm ? SCR_BIASR : SCR_BIASL) + sl] = v;
   }
   if (tid < 2 * 32 + 32) smem[scr + SCR_BSUM + tid] = 0.f;   // bias-gradient and d att block sums (SCR_BSUM, SCR_DATT)
+  // (per-item column sums SCR_CS: [item parity][wave][3][32], fully rewritten by phase C of every item)
 }
 
-__device__ __attribute__((noinline)) TileState bwd_tile_switch(const BwdArgs* ap, int tile, float* smem, Map m,
-                                                               bool tf_uniform) {
+__device__ __attribute__((noinline)) TileState bwd_tile_switch(const BwdArgs* ap, int tile, float* smem, bool tf_uniform) {
   const TecmSpatial& d = ap->d;
+  const Map m = make_map(d);
   const TecmSpatialGrads& g = ap->g;
   const int tid = threadIdx.x;
   int* eptr = reinterpret_cast<int*>(smem + m.eptr);
@@ -182,6 +186,7 @@ __device__ __attribute__((noinline)) TileState bwd_tile_switch(const BwdArgs* ap
   const int pbase = g.src_ptr_off[tile];
   for (int r = tid; r <= W; r += BT) sptr[r] = g.src_ptr[pbase + r];
   for (int r = tid; r < W; r += BT) smem[m.hT + d.Cin * m.P + r] = 1.0f;          // the ones row
+  for (int r = tid; r < 2 * d.tile_nodes * CP; r += BT) smem[m.rsum + r] = 0.f;    // d x_r and dout sums of this tile
   if (tf_uniform) {                                          // static node-embedding rows of the window
     const int Demb = d.Demb;
     for (int i = tid; i < W * Demb; i += BT) {
@@ -194,8 +199,9 @@ __device__ __attribute__((noinline)) TileState bwd_tile_switch(const BwdArgs* ap
 
 // per-node time features (general path): embedding rows of the window for this graph
 __device__ __attribute__((noinline)) void bwd_stage_emb_rows(const BwdArgs* ap, int b, int t, int lo, int wa, int wb,
-                                                             float* smem, Map m) {
+                                                             float* smem) {
   const TecmSpatial& d = ap->d;
+  const Map m = make_map(d);
   const int Demb = d.Demb;
   for (int i = threadIdx.x; i < (wb - wa) * Demb; i += BT) {
     const int w = wa + i / Demb, e = i % Demb;
@@ -206,7 +212,7 @@ __device__ __attribute__((noinline)) void bwd_stage_emb_rows(const BwdArgs* ap, 
 
 // embedding part of d h for one row:  sum_a d x_l[w, a] Wl[a, Cin+e]  (+ tile rows: d x_r . Wr + dout)
 __device__ __forceinline__ float demb_of_row(const float* smem, const Map& m, int Cin, int w, int ta, int tb, int e,
-                                             bool residual) {
+                                             bool residual, int xr_base, int gt_base) {
   const float* Wl = smem + m.scr + SCR_WL + Cin + e;
   const float* Wr = smem + m.scr + SCR_WR + Cin + e;
   const float* xlr = smem + m.xl + w * CP;
@@ -214,23 +220,24 @@ __device__ __forceinline__ float demb_of_row(const float* smem, const Map& m, in
 #pragma unroll
   for (int a = 0; a < C; ++a) v = fmaf(xlr[slot_of(a)], Wl[a * C], v);
   if (w >= ta && w < tb) {
-    const float* xrr = smem + m.xr + (w - ta) * CP;
+    const float* xrr = smem + xr_base + (w - ta) * CP;
 #pragma unroll
     for (int a = 0; a < C; ++a) v = fmaf(xrr[slot_of(a)], Wr[a * C], v);
-    if (residual) v += smem[m.gt + (w - ta) * CP + slot_of(Cin + e)];
+    if (residual) v += smem[gt_base + (w - ta) * CP + slot_of(Cin + e)];
   }
   return v;
 }
 
 // per-node time features: the temporal tables get d h[w, Cin:] row by row (general path, once per item)
 __device__ __attribute__((noinline)) void bwd_temporal_per_node(const BwdArgs* ap, int b, int t, int lo, int wa, int wb,
-                                                                int ta, int tb, const float* smem, Map m, bool residual) {
+                                                                int ta, int tb, const float* smem, bool residual) {
   const TecmSpatial& d = ap->d;
+  const Map m = make_map(d);
   const TecmSpatialGrads& g = ap->g;
   const int Demb = d.Demb;
   for (int i = threadIdx.x; i < (wb - wa) * Demb; i += BT) {
     const int w = wa + i / Demb, e = i % Demb;
-    const float v = demb_of_row(smem, m, d.Cin, w, ta, tb, e, residual);
+    const float v = demb_of_row(smem, m, d.Cin, w, ta, tb, e, residual, m.xr, m.gt);      // this item's d x_r, dout
     const TimeIdx ti = load_time_idx(d, b, t, lo + w);
     atomicAdd(&g.d_tod_tab[ti.tod * Demb + e], v);
     atomicAdd(&g.d_doy_tab[ti.doy * Demb + e], v);
@@ -241,12 +248,14 @@ __device__ __attribute__((noinline)) void bwd_temporal_per_node(const BwdArgs* a
 
 // node table: the rows of x_l / x_r / gt hold  sum over the tile's graphs  of d x_l / d x_r / dout at this point
 __device__ __attribute__((noinline)) void bwd_node_table(const BwdArgs* ap, int lo, int W, int ta, int tb,
-                                                         const float* smem, Map m, bool residual) {
+                                                         const float* smem, bool residual) {
   const TecmSpatial& d = ap->d;
+  const Map m = make_map(d);
   const int Demb = d.Demb;
   for (int i = threadIdx.x; i < W * Demb; i += BT) {
     const int w = i / Demb, e = i - w * Demb;
-    atomicAdd(&ap->g.d_node_tab[(int64_t)(lo + w) * Demb + e], demb_of_row(smem, m, d.Cin, w, ta, tb, e, residual));
+    atomicAdd(&ap->g.d_node_tab[(int64_t)(lo + w) * Demb + e],
+              demb_of_row(smem, m, d.Cin, w, ta, tb, e, residual, m.rsum, m.gsum));           // the tile's sums
   }
 }
 
@@ -265,6 +274,7 @@ __device__ __forceinline__ void store12(float* p, const float (&v)[CH], float la
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+template <int SRC_R>
 __global__ __launch_bounds__(BT, 2) void spatial_bwd_kernel(const BwdArgs args) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const TecmSpatial& d = args.d;
@@ -288,31 +298,23 @@ __global__ __launch_bounds__(BT, 2) void spatial_bwd_kernel(const BwdArgs args) 
   const bool tf_uniform = Demb > 0 && d.tf_sn == 0;
   const bool residual = !(d.flags & TECM_SPATIAL_NO_RESIDUAL);
 
-  bwd_prologue(ap, it0, nit, smem, m, tf_uniform);
+  bwd_prologue(ap, it0, nit, smem, tf_uniform);
   __syncthreads();
-  // MFMA B operands of the recomputation (32x32x2): lane (c31, kq) holds column c31 of the slot-ordered W^T, k = 2s + kq
+  // MFMA B operands of the recomputation (32x32x2): lane (c31, kq) reads column c31 of the slot-ordered W^T,
+  // k = 2s + kq, from the LDS scratch for every task (registers are the scarce resource of this kernel)
   const int c31 = lane & 31, kq = lane >> 5;
-  float bwl[C / 2], bwr[C / 2];
-  int arow[C / 2];                                           // hT row of k = 2s + kq (the ones row sits at index Cin)
+  int wl_off, wr_off;
+  bool w_on;
   {
     const int ch = chan_of(c31);
     const bool is_u = c31 == CH || c31 == 2 * CH + 1;
-    const int ol = ch >= 0 ? SCR_WL + ch * C : SCR_UW + (c31 == CH ? 0 : 1) * 32;
-    const int orr = ch >= 0 ? SCR_WR + ch * C : SCR_UW + (c31 == CH ? 2 : 3) * 32;
-#pragma unroll
-    for (int s = 0; s < C / 2; ++s) {
-      const int k = 2 * s + kq;
-      bwl[s] = (ch >= 0 || is_u) ? smem[m.scr + ol + k] : 0.f;
-      bwr[s] = (ch >= 0 || is_u) ? smem[m.scr + orr + k] : 0.f;
-      arow[s] = (k + (k >= Cin ? 1 : 0)) * P;
-    }
+    wl_off = m.scr + (ch >= 0 ? SCR_WL + ch * C : SCR_UW + (c31 == CH ? 0 : 1) * 32) + kq;
+    wr_off = m.scr + (ch >= 0 ? SCR_WR + ch * C : SCR_UW + (c31 == CH ? 2 : 3) * 32) + kq;
+    w_on = ch >= 0 || is_u;
   }
-  float att[CH], att4[CH];
+  float att[CH];
 #pragma unroll
-  for (int c = 0; c < CH; ++c) {
-    att[c] = smem[m.scr + SCR_ATT + hh * CH + c];
-    att4[c] = (0.4f * LOG2E) * att[c];
-  }
+  for (int c = 0; c < CH; ++c) att[c] = smem[m.scr + SCR_ATT + hh * CH + c];
   const uint32_t dth = d.alpha_drop.p > 0.f ? tecm_drop_thresh(d.alpha_drop.p) : 0u;
   const float dinv = d.alpha_drop.p > 0.f ? 1.0f / (1.0f - d.alpha_drop.p) : 1.0f;
   const bool even_cin = (Cin & 1) == 0;
@@ -329,10 +331,10 @@ __global__ __launch_bounds__(BT, 2) void spatial_bwd_kernel(const BwdArgs args) 
   float dbl_acc[2] = {0.f, 0.f}, dbr_acc[2] = {0.f, 0.f};    // bias gradients (the ones row, moved out per item)
   float datt[CH];                                            // d att of head hh
   float DXL[SRC_R][CH];                                      // sum over the tile's graphs of d x_l, rows tid&255 + 256 r
-  float DXR[CH], GS[CH];                                     // ... of d x_r and dout for (tile node, head) (pair lane 0)
+                                                             // (the sums of d x_r and dout live in LDS: m.rsum, m.gsum)
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
-    datt[c] = 0.f; DXR[c] = 0.f; GS[c] = 0.f;
+    datt[c] = 0.f;
 #pragma unroll
     for (int r = 0; r < SRC_R; ++r) DXL[r][c] = 0.f;
   }
@@ -361,14 +363,8 @@ __global__ __launch_bounds__(BT, 2) void spatial_bwd_kernel(const BwdArgs args) 
 #pragma unroll
       for (int c = 0; c < CH; ++c) DXL[r][c] = 0.f;
     }
-    if (sub == 0 && tn < T && n0 + tn < n1) {
-      store12(smem + m.xr + tn * CP + hh * 12, DXR, 0.f);
-      store12(smem + m.gt + tn * CP + hh * 12, GS, 0.f);
-    }
-#pragma unroll
-    for (int c = 0; c < CH; ++c) { DXR[c] = 0.f; GS[c] = 0.f; }
     __syncthreads();
-    bwd_node_table(ap, lo, W, ta, tb, smem, m, residual);
+    bwd_node_table(ap, lo, W, ta, tb, smem, residual);
     __syncthreads();
   };
 
@@ -378,7 +374,7 @@ __global__ __launch_bounds__(BT, 2) void spatial_bwd_kernel(const BwdArgs args) 
       flush_tile();
       __syncthreads();
       cur_tile = it.tile;
-      const TileState ts = bwd_tile_switch(ap, it.tile, smem, m, tf_uniform);
+      const TileState ts = bwd_tile_switch(ap, it.tile, smem, tf_uniform);
       n0 = __builtin_amdgcn_readfirstlane(ts.n0);
       n1 = __builtin_amdgcn_readfirstlane(ts.n1);
       lo = __builtin_amdgcn_readfirstlane(ts.lo);
@@ -422,12 +418,12 @@ __global__ __launch_bounds__(BT, 2) void spatial_bwd_kernel(const BwdArgs args) 
     }
     if (Demb > 0) {
       if (tf_uniform) {
-        for (int i = tid; i < (wb - wa) * Demb; i += BT) {
-          const int e = i / (wb - wa), w = wa + i - e * (wb - wa);
-          smem[m.hT + (Cin + 1 + e) * P + w] = smem[m.nodeT + e * P + w] + smem[m.tb + q * 32 + e];
+        for (int e = wave; e < Demb; e += BT / 64) {        // a wave per embedding row: no division, scalar temb
+          const float te = smem[m.tb + q * 32 + e];
+          for (int w = wa + lane; w < wb; w += 64) smem[m.hT + (Cin + 1 + e) * P + w] = smem[m.nodeT + e * P + w] + te;
         }
       } else {
-        bwd_stage_emb_rows(ap, it.b, it.t, lo, wa, wb, smem, m);
+        bwd_stage_emb_rows(ap, it.b, it.t, lo, wa, wb, smem);
       }
     }
     {
@@ -455,7 +451,6 @@ __global__ __launch_bounds__(BT, 2) void spatial_bwd_kernel(const BwdArgs args) 
         if (c + 3 < C) dst[slot_of(c + 3)] = v.w;
       }
     }
-    if (tid < 3 * 32) smem[m.scr + SCR_CS + tid] = 0.f;      // this item's column sums
     __syncthreads();
     SPB_T(1);
 
@@ -468,21 +463,26 @@ __global__ __launch_bounds__(BT, 2) void spatial_bwd_kernel(const BwdArgs args) 
         const int rend = isr ? tb : wb;
         f32x16 acc = splat16(smem[m.scr + (isr ? SCR_BIASR : SCR_BIASL) + c31]);
         const int row = min(r0 + c31, rend - 1);
-        float av[C / 2];
+        float av[C / 2], bv[C / 2];
+        const int wo = isr ? wr_off : wl_off;
 #pragma unroll
-        for (int s = 0; s < C / 2; ++s) av[s] = smem[m.hT + arow[s] + row];
-        if (isr) {
-#pragma unroll
-          for (int s = 0; s < C / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bwr[s], acc, 0, 0, 0);
-        } else {
-#pragma unroll
-          for (int s = 0; s < C / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bwl[s], acc, 0, 0, 0);
+        for (int s = 0; s < C / 2; ++s) {
+          const int k = 2 * s + kq;                          // hT row of input k: the ones row sits at index Cin
+          av[s] = smem[m.hT + (k + (k >= Cin ? 1 : 0)) * P + row];
+          bv[s] = w_on ? smem[wo + 2 * s] : 0.f;
         }
+#pragma unroll
+        for (int s = 0; s < C / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
         const int oo = (isr ? m.xr - ta * CP : m.xl) + (r0 + 4 * kq) * CP + c31;
         if (c31 < CP) {
+          if (r0 + 32 <= rend) {
 #pragma unroll
-          for (int e = 0; e < 16; ++e)
-            if (r0 + 4 * kq + (e & 3) + 8 * (e >> 2) < rend) smem[oo + ((e & 3) + 8 * (e >> 2)) * CP] = acc[e];
+            for (int e = 0; e < 16; ++e) smem[oo + ((e & 3) + 8 * (e >> 2)) * CP] = acc[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+              if (r0 + 4 * kq + (e & 3) + 8 * (e >> 2) < rend) smem[oo + ((e & 3) + 8 * (e >> 2)) * CP] = acc[e];
+          }
         }
       }
     }
@@ -517,6 +517,7 @@ __global__ __launch_bounds__(BT, 2) void spatial_bwd_kernel(const BwdArgs args) 
       }
     }
 
+
     // ---- phase B1: by target.  Lane pair (sub = 0 / 1) of (tile node tn, head hh) takes the even / odd slots.
     float dxr[CH];
 #pragma unroll
@@ -540,19 +541,26 @@ __global__ __launch_bounds__(BT, 2) void spatial_bwd_kernel(const BwdArgs args) 
         const int pos = s < deg ? e0 + s : E + tn;
         float a[CH + 1];
         load12(smem + m.xl + j * CP + hh * 12, a);
-        float e = fmaf(0.6f * LOG2E, a[CH], base), da = 0.f;
+        // e = log2(e) * (0.6 (u_l + u_r) + 0.4 sum_c att_c |x_l[j,c] + x_r[i,c]|); even / odd channels in separate chains
+        float t0 = 0.f, u0 = 0.f, da = 0.f, db = 0.f;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-          e = fmaf(att4[c], fabsf(a[c] + xr[c]), e);
-          da = fmaf(gv[c], a[c], da);
+          if (c & 1) {
+            u0 = fmaf(att[c], fabsf(a[c] + xr[c]), u0);
+            db = fmaf(gv[c], a[c], db);
+          } else {
+            t0 = fmaf(att[c], fabsf(a[c] + xr[c]), t0);
+            da = fmaf(gv[c], a[c], da);
+          }
         }
-        float mult = 1.0f;
-        if (dth) mult = tecm_drop_mult(d.alpha_drop.seed, dbase + s, dth, dinv);
-        *reinterpret_cast<float2*>(smem + m.ea + (pos * 2 + hh) * 2) = make_float2(e, da * mult);
+        const float e = fmaf(0.4f * LOG2E, t0 + u0, fmaf(0.6f * LOG2E, a[CH], base));
+        da += db;
+        if (dth) da *= tecm_drop_mult(d.alpha_drop.seed, dbase + s, dth, dinv);
+        *reinterpret_cast<float2*>(smem + m.ea + (pos * 2 + hh) * 2) = make_float2(e, da);
         const float mn = fmaxf(mx, e);
         const float corr = __builtin_amdgcn_exp2f(mx - mn), pw = __builtin_amdgcn_exp2f(e - mn);
         z = z * corr + pw;
-        num = num * corr + pw * (da * mult);
+        num = num * corr + pw * da;
         mx = mn;
       }
       // pair combine: the even lane always owns slot 0, so the common maximum is finite
@@ -586,11 +594,18 @@ __global__ __launch_bounds__(BT, 2) void spatial_bwd_kernel(const BwdArgs args) 
       }
 #pragma unroll
       for (int c = 0; c < CH; ++c) dxr[c] += swap1(dxr[c]);  // both lanes now hold d x_r[i, head]
-      if (sub == 0) {
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-          DXR[c] += dxr[c];
-          if (residual) GS[c] += gv[c];
+      if (sub == 0) {                                        // the tile's running sums (node-table gradient), in LDS
+        float4* rs = reinterpret_cast<float4*>(smem + m.rsum + tn * CP + hh * 12);
+        float4 r0 = rs[0], r1 = rs[1], r2 = rs[2];
+        r0.x += dxr[0]; r0.y += dxr[1]; r0.z += dxr[2]; r0.w += dxr[3]; r1.x += dxr[4]; r1.y += dxr[5];
+        r1.z += dxr[6]; r1.w += dxr[7]; r2.x += dxr[8]; r2.y += dxr[9]; r2.z += dxr[10];
+        rs[0] = r0; rs[1] = r1; rs[2] = r2;
+        if (residual) {
+          float4* gs = reinterpret_cast<float4*>(smem + m.gsum + tn * CP + hh * 12);
+          float4 g0 = gs[0], g1 = gs[1], g2 = gs[2];
+          g0.x += gv[0]; g0.y += gv[1]; g0.z += gv[2]; g0.w += gv[3]; g1.x += gv[4]; g1.y += gv[5];
+          g1.z += gv[6]; g1.w += gv[7]; g2.x += gv[8]; g2.y += gv[9]; g2.z += gv[10];
+          gs[0] = g0; gs[1] = g1; gs[2] = g2;
         }
       }
     }
@@ -609,17 +624,11 @@ __global__ __launch_bounds__(BT, 2) void spatial_bwd_kernel(const BwdArgs args) 
         const bool self = w >= ta && w < tb;
         const int q0 = it.use_edges ? sptr[w] : 0;
         const int q1 = it.use_edges ? sptr[w + 1] : 0;
+        const int selfc = ((w - ta) << 16) | (E + w - ta);   // the implicit self loop of a tile row: last "edge"
         for (int qq = q0; qq < q1 + (self ? 1 : 0); ++qq) {
-          int tt, pos;
-          if (qq < q1) {
-            const int code = scol[qq];
-            tt = code >> 16;
-            pos = eptr[tt] + (code & 0xffff);
-          } else {                                           // the implicit self loop of a tile row
-            tt = w - ta;
-            pos = E + tt;
-          }
-          const float2 ad = *reinterpret_cast<const float2*>(smem + m.ea + (pos * 2 + hh) * 2);   // (alpha~, de)
+          const int code = qq < q1 ? scol[qq] : selfc;       // (tile target << 16) | position in the edge array
+          const int tt = code >> 16;
+          const float2 ad = *reinterpret_cast<const float2*>(smem + m.ea + ((code & 0xffff) * 2 + hh) * 2);   // (alpha~, de)
           float xr[CH + 1], gv[CH + 1];
           load12(smem + m.xr + tt * CP + hh * 12, xr);
           load12(smem + m.gt + tt * CP + hh * 12, gv);
@@ -644,27 +653,50 @@ __global__ __launch_bounds__(BT, 2) void spatial_bwd_kernel(const BwdArgs args) 
     {
       const int nkl = (wb - wa + 3) >> 2, nkr = (tb - ta + 3) >> 2;
       const int i0 = lane & 15, k4 = lane >> 4;
-      for (int ks = wave; ks < nkl + nkr; ks += BT / 64) {
-        const bool isr = ks >= nkl;
-        const int r0 = isr ? ta + 4 * (ks - nkl) : wa + 4 * ks;
-        const int rend = isr ? tb : wb;
-        const int row = r0 + k4;
-        const bool ok = row < rend;
-        const float a0 = ok ? smem[m.hT + i0 * P + row] : 0.f;
-        const float a1 = (ok && 16 + i0 < HR) ? smem[m.hT + (16 + i0) * P + row] : 0.f;
-        if (!isr) {
-          const float b0 = ok ? smem[m.xl + row * CP + i0] : 0.f;
-          const float b1 = (ok && i0 < CP - 16) ? smem[m.xl + row * CP + 16 + i0] : 0.f;
+      const bool a1_on = 16 + i0 < HR, b1_on = i0 < CP - 16;
+      // window rows: [x | 1 | emb]^T (x) d x_l.  Two loops without branches around the MFMAs (the accumulators stay
+      // in place), software pipelined: the operands of the next k-step are in flight while this one's MFMAs issue.
+      {
+        float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+        auto ldw = [&](int ks, float& x0, float& x1, float& y0, float& y1) {
+          const int row = wa + 4 * ks + k4;
+          const bool ok = row < wb;
+          x0 = ok ? smem[m.hT + i0 * P + row] : 0.f;
+          x1 = (ok && a1_on) ? smem[m.hT + (16 + i0) * P + row] : 0.f;
+          y0 = ok ? smem[m.xl + row * CP + i0] : 0.f;
+          y1 = (ok && b1_on) ? smem[m.xl + row * CP + 16 + i0] : 0.f;
+        };
+        if (wave < nkl) ldw(wave, a0, a1, b0, b1);
+#pragma unroll 1
+        for (int ks = wave; ks < nkl; ks += BT / 64) {
+          float n0_ = 0.f, n1_ = 0.f, m0_ = 0.f, m1_ = 0.f;
+          if (ks + BT / 64 < nkl) ldw(ks + BT / 64, n0_, n1_, m0_, m1_);
           accL[0][0] = MFMA16(a0, b0, accL[0][0]);
           accL[0][1] = MFMA16(a0, b1, accL[0][1]);
           accL[1][0] = MFMA16(a1, b0, accL[1][0]);
           accL[1][1] = MFMA16(a1, b1, accL[1][1]);
-        } else {
+          a0 = n0_; a1 = n1_; b0 = m0_; b1 = m1_;
+        }
+      }
+      // tile rows: [x | 1 | emb]^T (x) d x_r, and the ones row against dout (its column sums)
+      {
+        float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f, g0 = 0.f, g1 = 0.f;
+        auto ldt = [&](int ks, float& x0, float& x1, float& y0, float& y1, float& z0, float& z1) {
+          const int row = ta + 4 * ks + k4;
+          const bool ok = row < tb;
           const int tr = row - ta;
-          const float b0 = ok ? smem[m.xr + tr * CP + i0] : 0.f;
-          const float b1 = (ok && i0 < CP - 16) ? smem[m.xr + tr * CP + 16 + i0] : 0.f;
-          const float g0 = ok ? smem[m.gt + tr * CP + i0] : 0.f;
-          const float g1 = (ok && i0 < CP - 16) ? smem[m.gt + tr * CP + 16 + i0] : 0.f;
+          x0 = ok ? smem[m.hT + i0 * P + row] : 0.f;
+          x1 = (ok && a1_on) ? smem[m.hT + (16 + i0) * P + row] : 0.f;
+          y0 = ok ? smem[m.xr + tr * CP + i0] : 0.f;
+          y1 = (ok && b1_on) ? smem[m.xr + tr * CP + 16 + i0] : 0.f;
+          z0 = ok ? smem[m.gt + tr * CP + i0] : 0.f;
+          z1 = (ok && b1_on) ? smem[m.gt + tr * CP + 16 + i0] : 0.f;
+        };
+        if (wave < nkr) ldt(wave, a0, a1, b0, b1, g0, g1);
+#pragma unroll 1
+        for (int ks = wave; ks < nkr; ks += BT / 64) {
+          float n0_ = 0.f, n1_ = 0.f, m0_ = 0.f, m1_ = 0.f, h0_ = 0.f, h1_ = 0.f;
+          if (ks + BT / 64 < nkr) ldt(ks + BT / 64, n0_, n1_, m0_, m1_, h0_, h1_);
           const float as = Cin < 16 ? a0 : a1;               // the row tile that holds the ones row
           accR[0][0] = MFMA16(a0, b0, accR[0][0]);
           accR[0][1] = MFMA16(a0, b1, accR[0][1]);
@@ -672,6 +704,7 @@ __global__ __launch_bounds__(BT, 2) void spatial_bwd_kernel(const BwdArgs args) 
           accR[1][1] = MFMA16(a1, b1, accR[1][1]);
           accG[0] = MFMA16(as, g0, accG[0]);
           accG[1] = MFMA16(as, g1, accG[1]);
+          a0 = n0_; a1 = n1_; b0 = m0_; b1 = m1_; g0 = h0_; g1 = h1_;
         }
       }
       // the ones row (hT row Cin): per-item column sums -> LDS, bias gradients -> registers, then cleared
@@ -687,9 +720,10 @@ __global__ __launch_bounds__(BT, 2) void spatial_bwd_kernel(const BwdArgs args) 
               else          { vl = accL[1][ct][rg]; accL[1][ct][rg] = 0.f; vr = accR[1][ct][rg]; accR[1][ct][rg] = 0.f; }
               const float vg = accG[ct][rg];
               accG[ct][rg] = 0.f;
-              atomicAdd(&smem[m.scr + SCR_CS + 0 * 32 + ct * 16 + i0], vl);
-              atomicAdd(&smem[m.scr + SCR_CS + 1 * 32 + ct * 16 + i0], vr);
-              atomicAdd(&smem[m.scr + SCR_CS + 2 * 32 + ct * 16 + i0], vg);
+              const int cso = m.scr + SCR_CS + ((q & 1) * 8 + wave) * 96 + ct * 16 + i0;   // this wave's partial sums
+              smem[cso + 0 * 32] = vl;                       // (LDS float atomics run at about a lane per 3.5 clk)
+              smem[cso + 1 * 32] = vr;
+              smem[cso + 2 * 32] = vg;
               dbl_acc[ct] += vl;
               dbr_acc[ct] += vr;
             }
@@ -700,29 +734,48 @@ __global__ __launch_bounds__(BT, 2) void spatial_bwd_kernel(const BwdArgs args) 
     __syncthreads();
     SPB_T(5);
 
-    // ---- temporal tables: d temb_g = sum_n d h[n, Cin:]  from the column sums of d x_l, d x_r, dout
+    // ---- temporal tables: d temb_g = sum_n d h[n, Cin:]  from the column sums of d x_l, d x_r, dout.  A dozen
+    //      threads; the others go on to stage the next item (the column sums are double buffered by item parity and
+    //      cleared here for the item after next, two barriers ahead of their next use)
     if (Demb > 0) {
       if (tf_uniform) {
-        if (tid < Demb) {
-          const int e = tid;
-          const float* csl = smem + m.scr + SCR_CS;
-          float v = residual ? csl[2 * 32 + slot_of(Cin + e)] : 0.f;
+        float* csl = smem + m.scr + SCR_CS + (q & 1) * 8 * 96;
+        if (wave == 0) {
+          // the eight waves' partial column sums -> row 0 (same wave reads it next: program order suffices)
+          for (int k = lane; k < 96; k += 64) {
+            float v = 0.f;
 #pragma unroll
-          for (int a = 0; a < C; ++a) {
-            v = fmaf(csl[slot_of(a)], smem[m.scr + SCR_WL + a * C + Cin + e], v);
-            v = fmaf(csl[32 + slot_of(a)], smem[m.scr + SCR_WR + a * C + Cin + e], v);
+            for (int w8 = 0; w8 < BT / 64; ++w8) v += csl[w8 * 96 + k];
+            csl[k] = v;
           }
+          // four lanes per embedding column e: lane part p sums 11 of the 44 terms (matrix p >> 1, half p & 1)
           const int* tix = reinterpret_cast<const int*>(smem + m.ti + q * 4);
-          atomicAdd(&gr.d_tod_tab[tix[0] * Demb + e], v);
-          atomicAdd(&gr.d_doy_tab[tix[1] * Demb + e], v);
-          atomicAdd(&gr.d_year_tab[tix[2] * Demb + e], v);
-          atomicAdd(&gr.d_season_tab[tix[3] * Demb + e], v);
+          for (int e0 = 0; e0 < Demb; e0 += 16) {
+            const int e = e0 + (lane >> 2), p4 = lane & 3;
+            float v = 0.f;
+            if (e < Demb) {
+              const float* cs = csl + (p4 >> 1) * 32;
+              const float* W = smem + m.scr + ((p4 >> 1) ? SCR_WR : SCR_WL) + Cin + e;
+              const int abeg = (p4 & 1) * CH;
+#pragma unroll
+              for (int a = 0; a < CH; ++a) v = fmaf(cs[slot_of(abeg + a)], W[(abeg + a) * C], v);
+              if (p4 == 0 && residual) v += csl[2 * 32 + slot_of(Cin + e)];
+            }
+            v += swap1(v);
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+            if (e < Demb && p4 == 0) {
+              atomicAdd(&gr.d_tod_tab[tix[0] * Demb + e], v);
+              atomicAdd(&gr.d_doy_tab[tix[1] * Demb + e], v);
+              atomicAdd(&gr.d_year_tab[tix[2] * Demb + e], v);
+              atomicAdd(&gr.d_season_tab[tix[3] * Demb + e], v);
+            }
+          }
         }
       } else {
-        bwd_temporal_per_node(ap, it.b, it.t, lo, wa, wb, ta, tb, smem, m, residual);
+        bwd_temporal_per_node(ap, it.b, it.t, lo, wa, wb, ta, tb, smem, residual);
+        __syncthreads();                                     // the rows it read are restaged right away
       }
     }
-    __syncthreads();                                         // hT / x_l / x_r / gt / column sums are free again
     SPB_T(6);
   }
 
@@ -819,9 +872,9 @@ extern "C" int tecm_spatial_bwd(const TecmSpatial* dp, const TecmSpatialGrads* g
   TECM_REQUIRE(g.num_blocks == nblk, TECM_E_ARG, "tecm_spatial_bwd: num_blocks must be %d = tecm_spatial_bwd_blocks() (got %d)",
                (int)nblk, g.num_blocks);
   TECM_REQUIRE(g.partial_ld >= 2 * C * C + 4 * C, TECM_E_ARG, "tecm_spatial_bwd: partial_ld must be >= %d", 2 * C * C + 4 * C);
-  TECM_REQUIRE(d.win_max <= SRC_R * 256, TECM_E_LDS,
+  TECM_REQUIRE(d.win_max <= SRC_R_MAX * 256, TECM_E_LDS,
                "tecm_spatial_bwd: neighbour window of %d rows exceeds %d; renumber the graph (e.g. RCM) or shrink tile_nodes",
-               d.win_max, SRC_R * 256);
+               d.win_max, SRC_R_MAX * 256);
   const Map m = make_map(d);
   size_t floats = (size_t)m.total;
   if (floats < (size_t)red_offset(m) + RED_FLOATS) floats = (size_t)red_offset(m) + RED_FLOATS;
@@ -831,7 +884,9 @@ extern "C" int tecm_spatial_bwd(const TecmSpatial* dp, const TecmSpatialGrads* g
                "(e.g. RCM) or shrink tile_nodes", d.win_max, lds);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_bwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        kLdsBudget);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         kLdsBudget);
     attr_set = true;
   }
@@ -839,7 +894,10 @@ extern "C" int tecm_spatial_bwd(const TecmSpatial* dp, const TecmSpatialGrads* g
   args.d = d;
   args.g = g;
   args.total = (int)((int64_t)d.B * d.L * d.num_tiles);
-  hipLaunchKernelGGL(spatial_bwd_kernel, dim3((unsigned)nblk), dim3(BT), lds, (hipStream_t)stream, args);
+  if (d.win_max <= 256)
+    hipLaunchKernelGGL(spatial_bwd_kernel<1>, dim3((unsigned)nblk), dim3(BT), lds, (hipStream_t)stream, args);
+  else
+    hipLaunchKernelGGL(spatial_bwd_kernel<2>, dim3((unsigned)nblk), dim3(BT), lds, (hipStream_t)stream, args);
   TECM_CHECK_LAUNCH("tecm_spatial_bwd");
   return TECM_OK;
 }

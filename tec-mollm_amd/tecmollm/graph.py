@@ -72,9 +72,6 @@ def by_source_lists(rowptr: np.ndarray, colidx: np.ndarray, num_nodes: int, tile
     row instead of scattering it with atomics).  Returns (src_ptr, src_col, src_ptr_off) as in include/tecmollm.h."""
     deg = np.diff(rowptr).astype(np.int64)
     tgt = np.repeat(np.arange(num_nodes, dtype=np.int64), deg)           # target of every CSR entry
-    slot = np.arange(colidx.size, dtype=np.int64) - np.repeat(rowptr[:-1].astype(np.int64), deg)
-    if slot.size and slot.max() >= (1 << 16):
-        raise ValueError("a node has more than 65535 in-edges")
     src_col = np.zeros(max(colidx.size, 1), dtype=np.int32)
     ptrs, offs, pos = [], [], 0
     for k in range(lo.size):
@@ -82,7 +79,11 @@ def by_source_lists(rowptr: np.ndarray, colidx: np.ndarray, num_nodes: int, tile
         e0, e1 = int(rowptr[n0]), int(rowptr[n1])
         w = colidx[e0:e1].astype(np.int64) - int(lo[k])
         order = np.argsort(w, kind="stable")
-        src_col[e0:e1] = (((tgt[e0:e1][order] - n0) << 16) | slot[e0:e1][order]).astype(np.int32)
+        if e1 - e0 >= (1 << 16):
+            raise ValueError("a tile has more than 65535 in-edges")
+        # (tile target << 16) | position of the edge inside the tile's by-target segment: the kernel's per-edge LDS
+        # array is indexed by that position, so the by-source pass needs no second lookup
+        src_col[e0:e1] = (((tgt[e0:e1][order] - n0) << 16) | order).astype(np.int32)
         W = int(hi[k] - lo[k])
         p = np.zeros(W + 1, dtype=np.int64)
         np.add.at(p, w + 1, 1)
@@ -93,7 +94,7 @@ def by_source_lists(rowptr: np.ndarray, colidx: np.ndarray, num_nodes: int, tile
 
 
 MAXI = 40           # items a persistent block may own (csrc/spatial_fwd.hip, spatial_bwd.hip)
-SCR_FWD, SCR_BWD = 1192, 1448
+SCR_FWD, SCR_BWD = 1192, 2888
 RED_FLOATS = 8 * 8 * 4 * 64
 MAX_WINDOW = 512    # the backward's by-source pass: two rounds of 256 rows
 
@@ -112,7 +113,7 @@ def lds_bytes_bwd(win: int, tile_nodes: int, demb: int = 16, tile_edges: int = 0
     """Dynamic LDS of spatial_bwd_kernel (must match csrc/spatial_bwd.hip:make_map / red_offset)."""
     P, wm4 = win | 1, _r4(win)
     T, E = tile_nodes, tile_edges
-    scr = (_r4((C_FEAT + 1) * P) + wm4 * CP + 2 * T * CP + (E + T) * 4 + _r4(demb * P) + MAXI * 32 + MAXI * 4)
+    scr = (_r4((C_FEAT + 1) * P) + wm4 * CP + 4 * T * CP + (E + T) * 4 + _r4(demb * P) + MAXI * 32 + MAXI * 4)
     total = scr + SCR_BWD + (T + 1) + E + (wm4 + 1) + E
     red = 0 if scr >= RED_FLOATS else total
     return 4 * max(total, red + RED_FLOATS)
@@ -122,17 +123,26 @@ def build(edge_index: torch.Tensor, num_nodes: int, device: torch.device, demb: 
     ei = edge_index.detach().cpu().numpy()
     rowptr, colidx = csr_by_target(ei, num_nodes)
     deg = np.diff(rowptr)
-    chosen = None
-    for tn in (128, 64, 32, 16, 8, 4, 2, 1):          # largest tile whose backward window fits the LDS
-        tn = min(tn, 256)
+    # Largest tile (<= 128 target nodes: two threads per (node, head)) whose kernels fit the LDS.  Windows of at most 256
+    # rows are preferred -- the backward's by-source pass then is one round per item and keeps its d x_l sums in half
+    # the registers -- as long as that costs less than a quarter of the tile (the 41 x 71 grid: 110 nodes, 256 rows).
+    chosen, wide = None, None
+    for tn in (128, 120, 112, 110, 104, 96, 80, 64, 48, 32, 16, 8, 4, 2, 1):
         lo, hi = tile_windows(rowptr, colidx, num_nodes, tn)
         wmax = int((hi - lo).max())
         bounds = np.minimum(np.arange(lo.size + 1) * tn, num_nodes)
         emax = int(np.diff(rowptr[bounds]).max())
         if (max(lds_bytes_bwd(wmax, tn, demb, emax), lds_bytes_fwd(wmax, tn, emax)) <= LDS_BYTES
                 and wmax <= MAX_WINDOW):
-            chosen = (tn, lo, hi, wmax, emax)
-            break
+            if wide is None:
+                wide = (tn, lo, hi, wmax, emax)
+            if wmax <= 256:
+                chosen = (tn, lo, hi, wmax, emax)
+                break
+            if tn < 0.75 * wide[0]:
+                break
+    if chosen is None or chosen[0] < 0.75 * wide[0]:
+        chosen = wide
     if chosen is None:
         raise ValueError(
             "graph bandwidth too large for the 160 KiB LDS neighbour window even with 1-node tiles; "

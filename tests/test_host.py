@@ -141,7 +141,7 @@ def test_graph_csr_and_windows():
         c = col[rowptr[n0]:rowptr[n1]]
         assert lo[k] <= min(n0, c.min()) and hi[k] >= max(n1, c.max() + 1)
     meta = graph.build(ei, 2911, torch.device("cpu"))
-    assert meta.tile_nodes == 128 and meta.max_deg == 10 and meta.num_edges == 20924
+    assert meta.tile_nodes == 112 and meta.win_max <= 256 and meta.max_deg == 10 and meta.num_edges == 20924
     assert graph.lds_bytes_bwd(meta.win_max, meta.tile_nodes) <= 160 * 1024
 
 
@@ -376,7 +376,7 @@ def test_native_train_step_refuses_cpu_parameters():
 
 def test_by_source_lists_are_a_permutation_of_each_tile_segment():
     """Every by-target CSR entry of a tile appears exactly once in the tile's by-source lists, under its source row,
-    carrying its (target, slot) -- what the backward's gather pass relies on."""
+    carrying its (tile target, position in the tile's by-target segment) -- what the backward's gather pass relies on."""
     from tecmollm import graph as G
     ei, _ = R.grid_graph(7, 9, threshold_km=900.0)
     rowptr, col = G.csr_by_target(ei.numpy(), 63)
@@ -393,9 +393,10 @@ def test_by_source_lists_are_a_permutation_of_each_tile_segment():
             for w in range(W):
                 for q in range(ptr[w], ptr[w + 1]):
                     code = int(sc[e0 + q])
-                    t_rel, slot = code >> 16, code & 0xFFFF
-                    e = int(rowptr[n0 + t_rel]) + slot                  # the by-target entry this refers to
+                    t_rel, pos = code >> 16, code & 0xFFFF
+                    e = e0 + pos                                         # the by-target entry this refers to
                     assert e0 <= e < e1 and int(col[e]) == int(lo[k]) + w
+                    assert rowptr[n0 + t_rel] <= e < rowptr[n0 + t_rel + 1]   # ... and it really enters that target
                     seen.add(e)
             assert seen == set(range(e0, e1))
 

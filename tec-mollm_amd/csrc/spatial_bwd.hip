@@ -830,6 +830,45 @@ __global__ __launch_bounds__(BT, 2) void spatial_bwd_kernel(const BwdArgs args) 
   }
 }
 
+// Backward of the stand-alone SpatioTemporalEmbedding.forward (modules.py:230-266): out = cat([x, emb]), so
+// d table[idx] += dout[..., Cin:] summed over the rows that looked idx up.  One block = 256 nodes of one graph (b, t):
+// the node table takes one atomic per (row, column), the four temporal tables one per (block, column) after a
+// reduction in LDS when the time features are constant over the nodes, one per row otherwise.
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const TecmSpatial d, const TecmSpatialGrads g) {
+  __shared__ float tsum[32];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int n = blockIdx.x * 256 + tid;
+  const int gm = blockIdx.y, b = gm / d.L, t = gm - b * d.L;
+  const int Demb = d.Demb;
+  const bool uni = d.tf_sn == 0;
+  if (tid < 32) tsum[tid] = 0.f;
+  __syncthreads();
+  const bool on = n < d.N;
+  const float* row = g.dout + ((int64_t)gm * d.N + (on ? n : 0)) * d.out_ld + d.Cin;
+  TimeIdx ti = load_time_idx(d, b, t, uni ? 0 : (on ? n : 0));
+  for (int e = 0; e < Demb; ++e) {
+    const float v = on ? row[e] : 0.f;
+    if (on) atomicAdd(&g.d_node_tab[(int64_t)n * Demb + e], v);
+    if (uni) {
+      const float sw = wave_sum(v);
+      if (lane == 0) atomicAdd(&tsum[e], sw);
+    } else if (on) {
+      atomicAdd(&g.d_tod_tab[ti.tod * Demb + e], v);
+      atomicAdd(&g.d_doy_tab[ti.doy * Demb + e], v);
+      atomicAdd(&g.d_year_tab[ti.year * Demb + e], v);
+      atomicAdd(&g.d_season_tab[ti.season * Demb + e], v);
+    }
+  }
+  __syncthreads();
+  if (uni && tid < Demb) {
+    const float v = tsum[tid];
+    atomicAdd(&g.d_tod_tab[ti.tod * Demb + tid], v);
+    atomicAdd(&g.d_doy_tab[ti.doy * Demb + tid], v);
+    atomicAdd(&g.d_year_tab[ti.year * Demb + tid], v);
+    atomicAdd(&g.d_season_tab[ti.season * Demb + tid], v);
+  }
+}
+
 }  // namespace
 
 #ifdef SPB_STAMPS
@@ -861,7 +900,14 @@ extern "C" int tecm_spatial_bwd(const TecmSpatial* dp, const TecmSpatialGrads* g
   const TecmSpatialGrads& g = *gp;
   const int rc = check_common("tecm_spatial_bwd", d);
   if (rc) return rc;
-  TECM_REQUIRE(!(d.flags & TECM_SPATIAL_EMBED_ONLY), TECM_E_ARG, "tecm_spatial_bwd: embed-only mode has no graph backward");
+  if (d.flags & TECM_SPATIAL_EMBED_ONLY) {                   // stand-alone SpatioTemporalEmbedding: table gradients only
+    TECM_REQUIRE(d.Demb > 0 && d.Demb <= 32 && g.dout && d.out_ld >= C, TECM_E_ARG, "tecm_spatial_bwd(embed only): bad arguments");
+    TECM_REQUIRE(g.d_node_tab && g.d_tod_tab && g.d_doy_tab && g.d_year_tab && g.d_season_tab, TECM_E_ARG,
+                 "tecm_spatial_bwd(embed only): null table gradient");
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3((d.N + 255) / 256, d.B * d.L), dim3(256), 0, (hipStream_t)stream, d, g);
+    TECM_CHECK_LAUNCH("tecm_spatial_bwd(embed only)");
+    return TECM_OK;
+  }
   TECM_REQUIRE(g.dout && g.partials, TECM_E_ARG, "tecm_spatial_bwd: null pointer");
   TECM_REQUIRE(d.Demb == 0 || (g.d_node_tab && g.d_tod_tab && g.d_doy_tab && g.d_year_tab && g.d_season_tab), TECM_E_ARG,
                "tecm_spatial_bwd: null table gradient");

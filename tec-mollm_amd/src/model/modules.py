@@ -351,9 +351,16 @@ class SpatioTemporalEmbedding(nn.Module):
         return (self.node_embedding.weight, self.tod_embedding.weight, self.doy_embedding.weight,
                 self.year_embedding.weight, self.season_embedding.weight)
 
-    def forward(self, x, time_features):
-        raise NotImplementedError("SpatioTemporalEmbedding is fused with GATv2 + residual in the MI355X path: "
-                                  "call TEC_MoLLM.forward (or tecmollm.functions.SpatialFn)")
+    def forward(self, x: torch.Tensor, time_features: torch.Tensor) -> torch.Tensor:
+        """Reference signature (modules.py:230-266): x (B, L, N, C_in), time_features (B, L, N, 4) -> (B, L, N, C_in +
+        d_emb).  Stand-alone use only: TEC_MoLLM.forward runs this fused with GATv2 + residual in one kernel."""
+        _need_cuda(x, "x")
+        _need_cuda(time_features, "time_features")
+        if x.dim() != 4 or time_features.shape != (*x.shape[:3], 4):
+            raise ValueError("x must be (B, L, N, C_in) and time_features (B, L, N, 4)")
+        if x.shape[2] != self.node_embedding.num_embeddings:
+            raise ValueError(f"x has {x.shape[2]} nodes, the node table {self.node_embedding.num_embeddings}")
+        return F_.EmbedFn.apply(x, time_features, *self.tables())
 
 
 class _GATv2Params(nn.Module):
@@ -380,14 +387,26 @@ class SpatialEncoder(nn.Module):
         self.heads = heads
         self.dropout = dropout
         self.output_channels = out_channels * heads
+        # "reference": a single-graph edge_index only connects rows 0..N-1 of the flattened (G*N) input, i.e. graph 0
+        # (what the reference computes); "per_timestep": every graph of the batch
+        self.gat_graphs = "reference"
 
     def params(self):
         g = self.gat_conv
         return (g.lin_l.weight, g.lin_l.bias, g.lin_r.weight, g.lin_r.bias, g.att, g.bias)
 
-    def forward(self, x, edge_index, edge_weight=None):
-        raise NotImplementedError("SpatialEncoder is fused with the embedding + residual in the MI355X path: "
-                                  "call TEC_MoLLM.forward (or tecmollm.functions.SpatialFn)")
+    def forward(self, x: torch.Tensor, edge_index: torch.Tensor, edge_weight: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Reference signature (modules.py:340-359): x (num_graphs, N, C_in) -> (num_graphs, N, heads * out_channels);
+        edge_weight is ignored as in the reference.  Stand-alone use only (TEC_MoLLM.forward fuses this with the
+        embedding and the residual); gradients reach the GATv2 parameters, x must not require grad."""
+        _need_cuda(x, "x")
+        if x.dim() != 3 or x.shape[2] != self.output_channels:
+            raise ValueError(f"x must be (num_graphs, N, {self.output_channels})")
+        G, N, _ = x.shape
+        meta = graph_.get(edge_index, N, x.device, 0)
+        plan = make_plan(self, self.dropout, precision="fp32")
+        R = 1 if self.gat_graphs == "reference" else G
+        return F_.GatFn.apply(x, *self.params(), meta, self.heads, R, plan)
 
 
 class PredictionHead(nn.Module):

@@ -67,6 +67,7 @@ class TEC_MoLLM(nn.Module):
             d_emb=cfg["d_emb"], num_nodes=self.num_nodes, num_years=cfg.get("num_years", 13))
         self.spatial_encoder = SpatialEncoder(in_channels=c_spatial, out_channels=cfg["spatial_out_channels"],
                                               heads=cfg["spatial_heads"])
+        self.spatial_encoder.gat_graphs = self.gat_graphs
         self.temporal_encoder = TemporalEncoder(in_channels=c_spatial, channel_list=cfg["temporal_channel_list"],
                                                 strides=cfg["temporal_strides"], patch_len=cfg["patch_len"],
                                                 d_llm=cfg["d_llm"])

@@ -102,13 +102,15 @@ class SpatialFn(torch.autograd.Function):
         d.num_tiles, d.tile_nodes, d.win_max = meta.num_tiles, meta.tile_nodes, meta.win_max
         d.tile_edges_max = meta.tile_edges_max
         d.x = x.data_ptr()
-        d.tf = tf.data_ptr()
-        d.tf_sb, d.tf_sl, d.tf_sn, d.tf_sf = tf.stride()
+        if tf is not None:
+            d.tf = tf.data_ptr()
+            d.tf_sb, d.tf_sl, d.tf_sn, d.tf_sf = tf.stride()
         for name, t in (("node_tab", node_tab), ("tod_tab", tod_tab), ("doy_tab", doy_tab), ("year_tab", year_tab),
                         ("season_tab", season_tab), ("Wl", Wl), ("bl", bl), ("Wr", Wr), ("br", br), ("att", att),
                         ("bias", bias)):
-            setattr(d, name, t.data_ptr())
-        d.year_rows = year_tab.shape[0]
+            if t is not None:
+                setattr(d, name, t.data_ptr())
+        d.year_rows = year_tab.shape[0] if year_tab is not None else 0
         d.rowptr, d.colidx = meta.rowptr.data_ptr(), meta.colidx.data_ptr()
         d.tile_lo, d.tile_hi = meta.tile_lo.data_ptr(), meta.tile_hi.data_ptr()
         sp = plan.spec(SITE_GAT, meta.max_deg + 1)
@@ -155,6 +157,115 @@ class SpatialFn(torch.autograd.Function):
         #                                                         all 24 padded columns: the float4 reduction path
         return (None, None, d_node, d_tod, d_doy, d_year, d_season, dWl, dbl, dWr, dbr, datt, dbias,
                 None, None, None, None)
+
+
+class EmbedFn(torch.autograd.Function):
+    """Stand-alone SpatioTemporalEmbedding.forward (modules.py:230-266): (B, L, N, C_in) -> (B, L, N, C_in + d_emb),
+    the embed-only mode of the fused spatial kernel.  Needs no graph: the node tiling fields are placeholders."""
+
+    @staticmethod
+    def forward(ctx, x, tf, node_tab, tod_tab, doy_tab, year_tab, season_tab):
+        B, L, N, Cin = x.shape
+        Demb = node_tab.shape[1]
+        x = x.contiguous()
+        out = _empty(B, L, N, Cin + Demb, like=x)
+        d = EmbedFn._desc(x, tf, node_tab, tod_tab, doy_tab, year_tab, season_tab, B, L, N, Cin, Demb)
+        d.out = out.data_ptr()
+        errs = devcheck.error_word(x.device)
+        errs.poll()
+        check(lib().tecm_spatial_fwd(C.byref(d), stream_ptr()), "tecm_spatial_fwd(embed only)")
+        errs.post()
+        ctx.save_for_backward(x, tf, node_tab, tod_tab, doy_tab, year_tab, season_tab)
+        return out
+
+    @staticmethod
+    def _desc(x, tf, node_tab, tod_tab, doy_tab, year_tab, season_tab, B, L, N, Cin, Demb) -> TecmSpatial:
+        d = TecmSpatial()
+        d.B, d.L, d.N, d.Cin, d.Demb, d.H = B, L, N, Cin, Demb, 2
+        d.graphs_with_edges, d.num_tiles, d.tile_nodes, d.win_max, d.tile_edges_max = 0, N, 1, 1, 0
+        d.x = x.data_ptr()
+        d.tf = tf.data_ptr()
+        d.tf_sb, d.tf_sl, d.tf_sn, d.tf_sf = tf.stride()
+        for name, t in (("node_tab", node_tab), ("tod_tab", tod_tab), ("doy_tab", doy_tab), ("year_tab", year_tab),
+                        ("season_tab", season_tab)):
+            setattr(d, name, t.data_ptr())
+        # the graph / GAT fields are not read in this mode; point them at a live buffer to satisfy the null checks
+        for name in ("Wl", "bl", "Wr", "br", "att", "bias", "rowptr", "colidx", "tile_lo", "tile_hi"):
+            setattr(d, name, node_tab.data_ptr())
+        d.year_rows = year_tab.shape[0]
+        d.err_flag = devcheck.error_word(x.device).ptr()
+        d.flags, d.out_ld = 1, Cin + Demb                     # TECM_SPATIAL_EMBED_ONLY
+        return d
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, tf, node_tab, tod_tab, doy_tab, year_tab, season_tab = ctx.saved_tensors
+        B, L, N, Cin = x.shape
+        Demb = node_tab.shape[1]
+        dout = dout.contiguous()
+        d = EmbedFn._desc(x, tf, node_tab, tod_tab, doy_tab, year_tab, season_tab, B, L, N, Cin, Demb)
+        grads = [torch.zeros_like(t) for t in (node_tab, tod_tab, doy_tab, year_tab, season_tab)]
+        g = TecmSpatialGrads()
+        g.dout = dout.data_ptr()
+        g.d_node_tab, g.d_tod_tab, g.d_doy_tab, g.d_year_tab, g.d_season_tab = (t.data_ptr() for t in grads)
+        check(lib().tecm_spatial_bwd(C.byref(d), C.byref(g), stream_ptr()), "tecm_spatial_bwd(embed only)")
+        dx = dout[..., :Cin] if ctx.needs_input_grad[0] else None
+        return (dx, None, *grads)
+
+
+class GatFn(torch.autograd.Function):
+    """Stand-alone SpatialEncoder.forward (modules.py:340-359): x (G, N, 22) -> GATv2Conv(x) (G, N, 22), no residual,
+    no embedding: the fused kernels with Demb = 0 (the input rows ARE h) and TECM_SPATIAL_NO_RESIDUAL.  Gradients for
+    the GATv2 parameters; the input itself gets none (the fused path never needs d x), so x must not require grad."""
+
+    @staticmethod
+    def forward(ctx, x, Wl, bl, Wr, br, att, bias, meta: GraphMeta, heads: int, graphs_with_edges: int, plan: DropPlan):
+        G, N, Cc = x.shape
+        x = x.contiguous()
+        out = _empty(G, 1, N, CP, like=x)
+        d = GatFn._desc(x, Wl, bl, Wr, br, att, bias, meta, heads, graphs_with_edges, plan)
+        d.out = out.data_ptr()
+        check(lib().tecm_spatial_fwd(C.byref(d), stream_ptr()), "tecm_spatial_fwd(GAT only)")
+        ctx.save_for_backward(x, Wl, bl, Wr, br, att, bias)
+        ctx.meta, ctx.heads, ctx.R, ctx.plan = meta, heads, graphs_with_edges, plan
+        return out.view(G, N, CP)[..., :C_FEAT]
+
+    @staticmethod
+    def _desc(x, Wl, bl, Wr, br, att, bias, meta, heads, R, plan) -> TecmSpatial:
+        G, N, Cc = x.shape
+        d = SpatialFn._desc(x, None, None, None, None, None, None, Wl, bl, Wr, br, att, bias, meta, heads, R, plan,
+                            G, 1, N, Cc, 0)
+        d.flags = 2                                           # TECM_SPATIAL_NO_RESIDUAL
+        return d
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, Wl, bl, Wr, br, att, bias = ctx.saved_tensors
+        G, N, Cc = x.shape
+        if ctx.needs_input_grad[0]:
+            raise _lib_error("SpatialEncoder.forward: the input needs no gradient in the MI355X path (x must not require grad)")
+        dpad = torch.zeros(G, 1, N, CP, device=x.device, dtype=torch.float32)
+        dpad[..., :Cc] = dout.reshape(G, 1, N, Cc)
+        d = GatFn._desc(x, Wl, bl, Wr, br, att, bias, ctx.meta, ctx.heads, ctx.R, ctx.plan)
+        nblocks = lib().tecm_spatial_bwd_blocks(C.byref(d))
+        if nblocks <= 0:
+            check(nblocks, "tecm_spatial_bwd_blocks")
+        pld = 2 * Cc * Cc + 4 * Cc
+        partials = _empty(nblocks, pld, like=x)
+        g = TecmSpatialGrads()
+        g.dout, g.partials, g.partial_ld, g.num_blocks = dpad.data_ptr(), partials.data_ptr(), pld, nblocks
+        meta = ctx.meta
+        g.src_ptr, g.src_col, g.src_ptr_off = meta.src_ptr.data_ptr(), meta.src_col.data_ptr(), meta.src_ptr_off.data_ptr()
+        check(lib().tecm_spatial_bwd(C.byref(d), C.byref(g), stream_ptr()), "tecm_spatial_bwd(GAT only)")
+        s = colsum(partials, pld, nblocks, 1, 1, pld)[0]
+        o = 0
+        dWl = s[o:o + Cc * Cc].view(Cc, Cc); o += Cc * Cc
+        dbl = s[o:o + Cc]; o += Cc
+        dWr = s[o:o + Cc * Cc].view(Cc, Cc); o += Cc * Cc
+        dbr = s[o:o + Cc]; o += Cc
+        datt = s[o:o + Cc].view_as(att)
+        dbias = colsum(dpad, CP, G * N, 1, 1, CP)[0, :Cc]
+        return (None, dWl, dbl, dWr, dbr, datt, dbias, None, None, None, None)
 
 
 # ============================================================================ stage a-4

@@ -530,3 +530,64 @@ def test_unfreezing_a_gpt2_base_weight_is_refused(dev):
     model.llm_backbone.trunk.h[0].mlp.c_fc.weight.requires_grad_(True)
     with pytest.raises(TecmError, match="mlp.c_fc.weight"):
         model(x.to(dev), tf.to(dev), ei)
+
+
+# ----------------------------------------------------------------------------- the two fused modules on their own
+def test_standalone_spatio_temporal_embedding_forward_backward(dev):
+    """SpatioTemporalEmbedding.forward with the reference's signature and shapes (modules.py:230-266): bit-exact
+    output (index gather + the reference's association of the four temporal sums), table gradients vs autograd of the
+    oracle; both the stride-0 expanded time features of train.py:65 and per-node ones."""
+    from src.model.modules import SpatioTemporalEmbedding
+    B, L, N = 2, 5, 37
+    cfg = R.default_config(num_nodes=N)
+    p = R.init_params(cfg, seed=3)
+    mod = SpatioTemporalEmbedding(16, N, 13)
+    mod.load_state_dict({k[len(R.P_EMB):]: v for k, v in p.items() if k.startswith(R.P_EMB)})
+    mod = mod.to(dev)
+    x, tf, _ = R.synthetic_batch(B, L, N, 6, 12, seed=4)
+    g = torch.Generator().manual_seed(5)
+    tf_node = torch.stack([torch.randint(0, hi, (B, L, N), generator=g) for hi in (12, 366, 13, 4)], -1).float()
+    gout = torch.randn(B, L, N, 22, generator=g)
+    for tfc, tfd in ((tf, tf[:, :, 0, :].contiguous().to(dev).unsqueeze(-2).expand(B, L, N, 4)), (tf_node, tf_node.to(dev))):
+        pr = {k: v.clone().requires_grad_(True) for k, v in p.items() if k.startswith(R.P_EMB)}
+        ref = R.embed(x, tfc, pr)
+        out = mod(x.to(dev), tfd)
+        assert out.shape == (B, L, N, 22) and torch.equal(out.cpu(), ref.detach())
+        names = [R.P_EMB + f"{n}_embedding.weight" for n in ("node", "tod", "doy", "year", "season")]
+        gref = torch.autograd.grad(ref, [pr[n] for n in names], gout)
+        ghip = torch.autograd.grad(out, [mod.node_embedding.weight, mod.tod_embedding.weight, mod.doy_embedding.weight,
+                                         mod.year_embedding.weight, mod.season_embedding.weight], gout.to(dev))
+        for n, a, b in zip(names, ghip, gref):
+            assert rel_err(a, b) < 1e-5, n
+
+
+@pytest.mark.parametrize("mode", ["reference", "per_timestep"])
+def test_standalone_spatial_encoder_forward_backward(dev, mode):
+    """SpatialEncoder.forward with the reference's signature (modules.py:340-359): x (num_graphs, N, 22) ->
+    GATv2Conv output (no residual), parameter gradients vs the oracle; a single-graph edge_index reaches only graph 0
+    in the reference's literal mode."""
+    from src.model.modules import SpatialEncoder
+    G, grid = 7, (9, 15)
+    N = grid[0] * grid[1]
+    cfg = R.default_config(num_nodes=N)
+    p = R.init_params(cfg, seed=6)
+    enc = SpatialEncoder(22, 11, 2).eval()
+    enc.load_state_dict({k[len("spatial_encoder."):]: v for k, v in p.items() if k.startswith(R.P_GAT)})
+    enc = enc.to(dev)
+    enc.gat_graphs = mode
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(G, N, 22, generator=g)
+    ei, _ = R.grid_graph(*grid)
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items() if k.startswith(R.P_GAT)}
+    bei = R.batched_edge_index(ei, N, 1 if mode == "reference" else G)
+    ref = R.gatv2_conv(x.reshape(-1, 22), bei, pr, 2).view(G, N, 22)
+    out = enc(x.to(dev), ei.to(dev))
+    assert out.shape == (G, N, 22) and rel_err(out, ref) < TOL and elem_err(out, ref) < 1.0
+    names = [R.P_GAT + n for n in ("lin_l.weight", "lin_l.bias", "lin_r.weight", "lin_r.bias", "att", "bias")]
+    gout = torch.randn(G, N, 22, generator=g)
+    gref = torch.autograd.grad(ref, [pr[n] for n in names], gout)
+    ghip = torch.autograd.grad(out, list(enc.params()), gout.to(dev))
+    for n, a, b in zip(names, ghip, gref):
+        assert rel_err(a, b) < TOL, n
+    with pytest.raises(Exception):
+        enc(x.to(dev).requires_grad_(True), ei.to(dev)).sum().backward()   # d x is not part of the MI355X path

@@ -33,7 +33,7 @@ extern "C" {
 #define TECM_E_LAUNCH (-3)     /* hipGetLastError() != hipSuccess after the launch       */
 #define TECM_E_LDS (-4)        /* problem does not fit the 160 KiB LDS budget            */
 
-#define TECM_ABI_VERSION 4
+#define TECM_ABI_VERSION 5
 int tecm_abi_version(void);
 /* Human-readable text for the last error on this thread (host pointer, never NULL). */
 const char* tecm_last_error(void);
@@ -197,23 +197,27 @@ int tecm_groupnorm_gelu_bwd(const float* dact, int32_t dstride, const float* y, 
 
 /* ------------------------------------------------------------------ stage a-6 pieces
  * nn.LayerNorm(768, eps=1e-5) of GPT2Block / ln_f (modeling_gpt2.py:262-310, :620). */
+/* y (fp32) and / or y16 (bf16, RNE): the bf16 copy feeds a bf16 matrix-core GEMM (BASELINE configs[2]) that would
+ * round the fp32 value in its loader anyway -- same bits, half the bytes; either pointer may be NULL, not both. */
 int tecm_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y,
-                       int64_t ldy, float* stats /* (M,2) mean,rstd */, int64_t M, int32_t D, float eps,
-                       void* stream);
+                       int64_t ldy, void* y16, int64_t ldy16, float* stats /* (M,2) mean,rstd */, int64_t M, int32_t D,
+                       float eps, void* stream);
 /* dx = dres (optional) + LN'(dy).  Optional second output dx_masked = dropout(dx, mask_drop): the
  * residual-stream gradient is consumed twice in GPT2Block's backward, once as is (residual path) and
  * once through the resid dropout in front of a GEMM; emitting the masked copy here costs one extra
  * store instead of one hash per element per GEMM column tile.  dgb_partials (num_blocks, 2*D);
  * dx == NULL only queries *num_blocks. */
+/* masked_bf16 != 0: dx_masked is a bf16 (M, D) matrix (its only reader is a bf16 GEMM). */
 int tecm_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
-                       const float* stats, const float* dres, float* dx, float* dx_masked,
+                       const float* stats, const float* dres, float* dx, void* dx_masked, int32_t masked_bf16,
                        const TecmDrop* mask_drop, float* dgb_partials, int32_t* num_blocks, int64_t M, int32_t D,
                        void* stream);
 
 /* Causal multi-head self-attention over T tokens per sequence (GPT2Attention, modeling_gpt2.py:54-73,
  * :144-226; all-ones attention_mask tec_mollm.py:111 => pure causal).  qkv: (B,T,N,3*D) time-major
  * rows, ctx: (B,T,N,D).  head_dim = D/heads must be 64.  Dropout on the probabilities. */
-int tecm_attention_fwd(const float* qkv, float* ctx, int32_t B, int32_t T, int32_t N, int32_t heads,
+/* ctx_bf16 != 0: ctx is a bf16 (B,T,N,D) tensor (its only reader, attn.c_proj, is a bf16 GEMM). */
+int tecm_attention_fwd(const float* qkv, void* ctx, int32_t ctx_bf16, int32_t B, int32_t T, int32_t N, int32_t heads,
                        int32_t D, const TecmDrop* prob_drop, void* stream);
 int tecm_attention_bwd(const float* qkv, const float* dctx, float* dqkv, int32_t B, int32_t T, int32_t N,
                        int32_t heads, int32_t D, const TecmDrop* prob_drop, void* stream);
@@ -239,6 +243,9 @@ int tecm_conv_weight_pack(const float* w, float* fwd_pack, float* bwd_pack, int3
 /* inverse of fwd_pack for the weight gradient: dW[co][ci][tap] = dpack[co][tap*Cin+ci]. */
 int tecm_conv_weight_unpack(const float* dpack, float* dw, int32_t Cout, int32_t Cin, int32_t k,
                             void* stream);
+
+/* dst (bf16) [r][c] = round-to-nearest-even(src [r][c]) for a (rows, cols) block; cols % 4 == 0. */
+int tecm_cast_bf16(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int32_t cols, void* stream);
 
 /* dst[r][c] = src[r][c] * keep(seed, r*drop.ld + c) / (1 - p): the counter-based dropout mask every kernel of this
  * library recomputes (F.dropout of tec_mollm.py:115, GPT-2's embd dropout), materialised once where the masked

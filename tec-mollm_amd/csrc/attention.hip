@@ -24,10 +24,18 @@ __device__ __forceinline__ void fma4(float4& acc, float s, const float4& v) {
   acc.x += s * v.x; acc.y += s * v.y; acc.z += s * v.z; acc.w += s * v.w;
 }
 
+// ctx is fp32, or bf16 when its only reader is a bf16 matrix-core GEMM (rounded once here instead of in that loader)
+__device__ __forceinline__ void store_ctx(float* ctx, int ctx_bf16, int64_t off, const float4& o) {
+  if (ctx_bf16)
+    tecm_store_bf16x4(reinterpret_cast<__bf16*>(ctx) + off, o.x, o.y, o.z, o.w);
+  else
+    *reinterpret_cast<float4*>(ctx + off) = o;
+}
+
 // TT > 0: compile-time T with q/k/v held in registers; TT == 0: runtime T <= 32, k/v re-read (L1/L2).
 template <int TT>
 __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ ctx,
-                                                            int B, int Trt, int N, int H, int D, DropA dr) {
+                                                            int ctx_bf16, int B, int Trt, int N, int H, int D, DropA dr) {
   const int T = TT > 0 ? TT : Trt;
   const int sub = threadIdx.x & 15;
   const int64_t item = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
@@ -73,7 +81,7 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restr
         if (dr.thresh) p *= tecm_drop_mult(dr.seed, (uint64_t)(((item * T + i) * T) + j), dr.thresh, dr.inv);
         fma4(o, p, v[j]);
       }
-      *reinterpret_cast<float4*>(ctx + (row0 + (int64_t)i * N) * D + col) = o;
+      store_ctx(ctx, ctx_bf16, (row0 + (int64_t)i * N) * D + col, o);
     }
   } else {
     for (int i = 0; i < T; ++i) {
@@ -98,7 +106,7 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restr
         if (dr.thresh) p *= tecm_drop_mult(dr.seed, (uint64_t)(((item * T + i) * T) + j), dr.thresh, dr.inv);
         fma4(o, p, vj);
       }
-      *reinterpret_cast<float4*>(ctx + (row0 + (int64_t)i * N) * D + col) = o;
+      store_ctx(ctx, ctx_bf16, (row0 + (int64_t)i * N) * D + col, o);
     }
   }
 }
@@ -213,8 +221,9 @@ DropA make_dropa(const TecmDrop* d) {
 
 }  // namespace
 
-extern "C" int tecm_attention_fwd(const float* qkv, float* ctx, int32_t B, int32_t T, int32_t N, int32_t heads,
-                                  int32_t D, const TecmDrop* prob_drop, void* stream) {
+extern "C" int tecm_attention_fwd(const float* qkv, void* ctxv, int32_t ctx_bf16, int32_t B, int32_t T, int32_t N,
+                                  int32_t heads, int32_t D, const TecmDrop* prob_drop, void* stream) {
+  float* ctx = static_cast<float*>(ctxv);
   const int rc = check("tecm_attention_fwd", qkv, ctx, ctx, B, T, N, heads, D);
   if (rc) return rc;
   const int64_t items = (int64_t)B * N * heads;
@@ -222,7 +231,7 @@ extern "C" int tecm_attention_fwd(const float* qkv, float* ctx, int32_t B, int32
   const DropA dr = make_dropa(prob_drop);
   hipStream_t st = (hipStream_t)stream;
 #define ATT_FWD(TT) \
-  hipLaunchKernelGGL((attention_fwd_kernel<TT>), grid, dim3(256), 0, st, qkv, ctx, B, T, N, heads, D, dr)
+  hipLaunchKernelGGL((attention_fwd_kernel<TT>), grid, dim3(256), 0, st, qkv, ctx, (int)ctx_bf16, B, T, N, heads, D, dr)
   switch (T) {
     case 1: ATT_FWD(1); break;
     case 2: ATT_FWD(2); break;

@@ -49,6 +49,14 @@ __device__ __forceinline__ float tecm_drop_mult(uint64_t seed, uint64_t idx, uin
   return tecm_hash24(seed, idx) >= thresh ? inv_keep : 0.0f;
 }
 
+// ------------------------------------------------------------------ bf16 stores (RNE; a plain cast is NaN-safe)
+typedef __bf16 tecm_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void tecm_store_bf16x4(void* dst, float a, float b, float c, float d) {
+  tecm_bf16x4 v;
+  v[0] = (__bf16)a; v[1] = (__bf16)b; v[2] = (__bf16)c; v[3] = (__bf16)d;
+  *reinterpret_cast<tecm_bf16x4*>(dst) = v;                  // 8 bytes
+}
+
 // ------------------------------------------------------------------ activations
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float dgelu_erf(float x) {

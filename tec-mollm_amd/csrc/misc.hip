@@ -92,6 +92,35 @@ __global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restr
 
 }  // namespace
 
+// dst (bf16) [r][c] = round(src [r][c]): a strided block of an fp32 matrix into its bf16 twin (the 32 LoRA columns of
+// the K-extended c_attn operand, written by an fp32 GEMM into a matrix whose other columns the LayerNorm already
+// emitted as bf16)
+namespace {
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, int64_t lds,
+                                                        __bf16* __restrict__ dst, int64_t ldd, int64_t rows, int cols4) {
+  const int64_t total = rows * cols4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / cols4;
+    const int c = 4 * (int)(i - r * cols4);
+    const float4 v = *reinterpret_cast<const float4*>(src + r * lds + c);
+    tecm_store_bf16x4(dst + r * ldd + c, v.x, v.y, v.z, v.w);
+  }
+}
+}  // namespace
+
+extern "C" int tecm_cast_bf16(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int32_t cols,
+                              void* stream) {
+  TECM_REQUIRE(src && dst && rows > 0 && cols > 0, TECM_E_ARG, "tecm_cast_bf16: bad arguments");
+  TECM_REQUIRE(cols % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0 && tecm_aligned(src, 16) && tecm_aligned(dst, 8),
+               TECM_E_ALIGN, "tecm_cast_bf16: rows must be 16-byte (fp32) / 8-byte (bf16) friendly");
+  const int64_t total = rows * (cols / 4);
+  const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, ld_src,
+                     static_cast<__bf16*>(dst), ld_dst, rows, cols / 4);
+  TECM_CHECK_LAUNCH("tecm_cast_bf16");
+  return TECM_OK;
+}
+
 extern "C" int tecm_dropout_apply(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t rows, int32_t cols,
                                   const TecmDrop* drop, void* stream) {
   TECM_REQUIRE(src && dst && drop, TECM_E_ARG, "tecm_dropout_apply: null pointer");

@@ -31,8 +31,8 @@ template <int NCH>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, int64_t ldx,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ y,
-                                                            int64_t ldy, float* __restrict__ stats, int64_t M, int D,
-                                                            float eps) {
+                                                            int64_t ldy, void* __restrict__ y16, int64_t ldy16,
+                                                            float* __restrict__ stats, int64_t M, int D, float eps) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * 4 + wave;
   if (row >= M) return;
@@ -56,7 +56,6 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     }
   }
   const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
-  float* yr = y + row * ldy;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = 4 * (lane + 64 * i);
@@ -68,7 +67,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
       o.y = (v[i].y - mean) * rstd * g.y + b.y;
       o.z = (v[i].z - mean) * rstd * g.z + b.z;
       o.w = (v[i].w - mean) * rstd * g.w + b.w;
-      *reinterpret_cast<float4*>(yr + c) = o;
+      if (y) *reinterpret_cast<float4*>(y + row * ldy + c) = o;
+      // bf16 copy for a bf16 matrix-core GEMM that only ever reads the rounded value (rounded once here)
+      if (y16) tecm_store_bf16x4(static_cast<__bf16*>(y16) + row * ldy16 + c, o.x, o.y, o.z, o.w);
     }
   }
   if (lane == 0) {
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ stats,
                                                             const float* __restrict__ dres, float* __restrict__ dx,
-                                                            float* __restrict__ dxm, DropCtxN odc,
+                                                            float* __restrict__ dxm, int dxm_bf16, DropCtxN odc,
                                                             float* __restrict__ partials, int64_t M, int D) {
   __shared__ float red[4][2 * 4 * 64 * NCH];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -136,7 +137,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             for (int e = 0; e < 4; ++e)
               o[e] *= tecm_drop_mult(odc.seed, (uint64_t)(row * odc.ld + c + e), odc.thresh, odc.inv);
           }
-          *reinterpret_cast<float4*>(dxm + row * (int64_t)D + c) = make_float4(o[0], o[1], o[2], o[3]);
+          if (dxm_bf16)
+            tecm_store_bf16x4(reinterpret_cast<__bf16*>(dxm) + row * (int64_t)D + c, o[0], o[1], o[2], o[3]);
+          else
+            *reinterpret_cast<float4*>(dxm + row * (int64_t)D + c) = make_float4(o[0], o[1], o[2], o[3]);
         }
       }
     }
@@ -748,18 +752,21 @@ int gn_blocks(int64_t S) {
 }  // namespace
 
 extern "C" int tecm_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y,
-                                  int64_t ldy, float* stats, int64_t M, int32_t D, float eps, void* stream) {
-  TECM_REQUIRE(x && gamma && beta && y && stats, TECM_E_ARG, "tecm_layernorm_fwd: null pointer");
+                                  int64_t ldy, void* y16, int64_t ldy16, float* stats, int64_t M, int32_t D, float eps,
+                                  void* stream) {
+  TECM_REQUIRE(x && gamma && beta && (y || y16) && stats, TECM_E_ARG, "tecm_layernorm_fwd: null pointer");
+  TECM_REQUIRE(!y16 || (tecm_aligned(y16, 8) && ldy16 % 4 == 0 && ldy16 >= D), TECM_E_ALIGN,
+               "tecm_layernorm_fwd: the bf16 output must be 8-byte aligned with a leading dimension multiple of 4");
   TECM_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAXCH, TECM_E_ARG,
                "tecm_layernorm_fwd: need D %% 4 == 0 and D <= %d (got %d)", 256 * LN_MAXCH, D);
-  TECM_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && tecm_aligned(x, 16) && tecm_aligned(y, 16) &&
+  TECM_REQUIRE(ldx % 4 == 0 && (!y || (ldy % 4 == 0 && tecm_aligned(y, 16))) && tecm_aligned(x, 16) &&
                    tecm_aligned(gamma, 16) && tecm_aligned(beta, 16),
                TECM_E_ALIGN, "tecm_layernorm_fwd: 16-byte alignment required");
   const dim3 grid((unsigned)((M + 3) / 4));
   const int nch = (D + 255) / 256;
   hipStream_t st = (hipStream_t)stream;
 #define LN_FWD(NCH) \
-  hipLaunchKernelGGL((layernorm_fwd_kernel<NCH>), grid, dim3(256), 0, st, x, ldx, gamma, beta, y, ldy, stats, M, D, eps)
+  hipLaunchKernelGGL((layernorm_fwd_kernel<NCH>), grid, dim3(256), 0, st, x, ldx, gamma, beta, y, ldy, y16, ldy16, stats, M, D, eps)
   switch (nch) {
     case 1: LN_FWD(1); break;
     case 2: LN_FWD(2); break;
@@ -772,9 +779,9 @@ extern "C" int tecm_layernorm_fwd(const float* x, int64_t ldx, const float* gamm
 }
 
 extern "C" int tecm_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
-                                  const float* stats, const float* dres, float* dx, float* dx_masked,
-                                  const TecmDrop* mask_drop, float* dgb_partials, int32_t* num_blocks, int64_t M,
-                                  int32_t D, void* stream) {
+                                  const float* stats, const float* dres, float* dx, void* dx_masked,
+                                  int32_t masked_bf16, const TecmDrop* mask_drop, float* dgb_partials,
+                                  int32_t* num_blocks, int64_t M, int32_t D, void* stream) {
   TECM_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAXCH, TECM_E_ARG, "tecm_layernorm_bwd: bad M/D");
   const int nb = ln_blocks(M);
   if (num_blocks) *num_blocks = nb;
@@ -789,7 +796,7 @@ extern "C" int tecm_layernorm_bwd(const float* dy, int64_t lddy, const float* x,
   hipStream_t st = (hipStream_t)stream;
 #define LN_BWD(NCH)                                                                                              \
   hipLaunchKernelGGL((layernorm_bwd_kernel<NCH>), dim3(nb), dim3(256), 0, st, dy, lddy, x, ldx, gamma, stats, dres, \
-                     dx, dx_masked, odc, dgb_partials, M, D)
+                     dx, static_cast<float*>(dx_masked), (int)masked_bf16, odc, dgb_partials, M, D)
   switch (nch) {
     case 1: LN_BWD(1); break;
     case 2: LN_BWD(2); break;

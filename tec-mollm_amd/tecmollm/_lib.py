@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TECM_LIB", os.path.join(_HERE, "libtecmollm_hip.so"))   # override for experiments
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_f32p = C.c_void_p
 
@@ -126,13 +126,14 @@ EXPORTS = {
     "tecm_groupnorm_gelu_bwd": (C.c_int, [c_f32p, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                           C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                           C.c_void_p]),
-    "tecm_layernorm_fwd": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_int64, c_f32p, C.c_int64,
-                                     C.c_int32, C.c_float, C.c_void_p]),
-    "tecm_layernorm_bwd": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
-                                     C.POINTER(TecmDrop), c_f32p, C.POINTER(C.c_int32), C.c_int64, C.c_int32,
+    "tecm_layernorm_fwd": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_void_p, C.c_int64,
+                                     c_f32p, C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
+    "tecm_layernorm_bwd": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p,
+                                     C.c_int32, C.POINTER(TecmDrop), c_f32p, C.POINTER(C.c_int32), C.c_int64, C.c_int32,
                                      C.c_void_p]),
-    "tecm_attention_fwd": (C.c_int, [c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                                     C.POINTER(TecmDrop), C.c_void_p]),
+    "tecm_attention_fwd": (C.c_int, [c_f32p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_int32, C.POINTER(TecmDrop), C.c_void_p]),
+    "tecm_cast_bf16": (C.c_int, [c_f32p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
     "tecm_attention_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                      C.POINTER(TecmDrop), C.c_void_p]),
     "tecm_colsum": (C.c_int, [c_f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, c_f32p, C.c_int64,

@@ -483,41 +483,51 @@ class GPT2StackFn(torch.autograd.Function):
             (ln1w, ln1b, Wqkv, bqkv, lA, lB, Wo, bo, ln2w, ln2b, Wfc, bfc, Wpr,
              bpr) = params[i * GPT2StackFn.PER_LAYER:(i + 1) * GPT2StackFn.PER_LAYER]
             F3, F4 = Wqkv.shape[1], Wfc.shape[1]
-            u = _empty(M, KE, like=h)                       # [ LN1(h) | z = drop(LN1(h)) A^T ]
+            b16 = int(plan.bf16) == ops.PREC_BF16           # bf16 mode: weights and GEMM-only activations live in HBM as bf16
+            WqkvT = _frozen_copy(Wqkv, "nk16" if b16 else "nk32")
+            Wo_f, ldo_f, lay_o = _fwd_weight(Wo, D, D, plan.bf16)
+            Wfc_f, ldfc_f, lay_fc = _fwd_weight(Wfc, D, F4, plan.bf16)
+            Wpr_f, ldpr_f, lay_pr = _fwd_weight(Wpr, F4, D, plan.bf16)
+            # Activations whose ONLY reader is a bf16 GEMM are written as bf16 by their producer (rounded once there
+            # instead of in that GEMM's loader: bit-identical, half the bytes both ways): LN1's output for c_attn, the
+            # attention context for attn.c_proj, LN2's output for c_fc, gelu(c_fc) for mlp.c_proj.
+            a16 = b16 and all(w is not None and w.dtype == torch.bfloat16 for w in (WqkvT, Wo_f, Wfc_f, Wpr_f))
+            u = _empty(M, KE, like=h)                       # [ LN1(h) | z = drop(LN1(h)) A^T ]  (fp32: the LoRA gradients read it)
+            u16 = torch.empty(M, KE, device=h.device, dtype=torch.bfloat16) if a16 else None
             st1 = _empty(M, 2, like=h)
-            ops.layernorm_fwd(h, D, ln1w, ln1b, u, KE, st1, M, D)
+            ops.layernorm_fwd(h, D, ln1w, ln1b, u, KE, st1, M, D, y16=u16, ldy16=KE)
             lspec = plan.spec(site_lora(i), KE)
             gemm(M, LORA_R, D, u, KE, lA, D, u, KE, c_off=D, a_drop=lspec, bf16=plan.bf16)
+            if a16:
+                ops.cast_bf16(u, KE, u16, KE, M, LORA_R, src_off=D, dst_off=D)
             wcat = _empty(KE, F3, like=h)                   # [ W ; (alpha/r) B^T ]  K-extended c_attn (backward operand)
             wcat[:D].copy_(Wqkv)
             ops.transpose_scale(lB, LORA_R, wcat, F3, LORA_R, F3, LORA_SCALE, dst_off=D * F3)
             qkv = _empty(M, F3, like=h)
-            b16 = int(plan.bf16) == ops.PREC_BF16           # bf16 mode: weights (and fc / dA outputs) live in HBM as bf16
-            WqkvT = _frozen_copy(Wqkv, "nk16" if b16 else "nk32")
             if WqkvT is not None:                           # forward operand in [N][K] form: [ W^T | (alpha/r) B ]
                 wcatT = torch.empty(F3, KE, device=h.device, dtype=WqkvT.dtype)
                 wcatT[:, :D].copy_(WqkvT)
                 wcatT[:, D:].copy_(lB.detach() * LORA_SCALE)
                 if b16:                                     # the backward's [KE][F3] operand in bf16 as well
                     wcat = wcat.bfloat16()
-                gemm(M, F3, KE, u, KE, wcatT, KE, qkv, F3, b_layout=B_NK, bias=bqkv, bf16=plan.bf16)
+                gemm(M, F3, KE, u16 if a16 else u, KE, wcatT, KE, qkv, F3, b_layout=B_NK, bias=bqkv, bf16=plan.bf16)
             else:
                 gemm(M, F3, KE, u, KE, wcat, F3, qkv, F3, b_layout=B_KN, bias=bqkv, bf16=plan.bf16)
-            cx = _empty(M, D, like=h)
+            cx = torch.empty(M, D, device=h.device, dtype=torch.bfloat16 if a16 else torch.float32)
             aspec = plan.spec(site_attn(i), 1)
             ops.attention_fwd(qkv, cx, B, T, N, GPT_HEADS, D, aspec)
             h2 = _empty(M, D, like=h)
-            Wo_f, ldo_f, lay_o = _fwd_weight(Wo, D, D, plan.bf16)
             gemm(M, D, D, cx, D, Wo_f, ldo_f, h2, D, b_layout=lay_o, bias=bo, out_drop=plan.spec(site_res1(i), D),
                  residual=(h, D), bf16=plan.bf16)
-            u2 = _empty(M, D, like=h)
             st2 = _empty(M, 2, like=h)
-            ops.layernorm_fwd(h2, D, ln2w, ln2b, u2, D, st2, M, D)
+            if a16:
+                u2 = torch.empty(M, D, device=h.device, dtype=torch.bfloat16)
+                ops.layernorm_fwd(h2, D, ln2w, ln2b, None, D, st2, M, D, y16=u2, ldy16=D)
+            else:
+                u2 = _empty(M, D, like=h)
+                ops.layernorm_fwd(h2, D, ln2w, ln2b, u2, D, st2, M, D)
             a = _empty(M, F4, like=h)
-            Wfc_f, ldfc_f, lay_fc = _fwd_weight(Wfc, D, F4, plan.bf16)
-            Wpr_f, ldpr_f, lay_pr = _fwd_weight(Wpr, F4, D, plan.bf16)
-            # gelu(fc) is only ever read by the c_proj GEMM: in bf16 mode it is written as bf16 (rounded once here
-            # instead of in that GEMM's loader: bit-identical, half the bytes both ways)
+            # gelu(fc) is only ever read by the c_proj GEMM: in bf16 mode it is written as bf16
             f16 = b16 and Wfc_f.dtype == torch.bfloat16 and Wpr_f.dtype == torch.bfloat16
             f = torch.empty(M, F4, device=h.device, dtype=torch.bfloat16 if f16 else torch.float32)
             gemm(M, F4, D, u2, D, Wfc_f, ldfc_f, f, F4, b_layout=lay_fc, bias=bfc, preact=(a, F4), act=ACT_GELU_TANH,
@@ -525,7 +535,8 @@ class GPT2StackFn(torch.autograd.Function):
             h3 = _empty(M, D, like=h)
             gemm(M, D, F4, f, F4, Wpr_f, ldpr_f, h3, D, b_layout=lay_pr, bias=bpr, out_drop=plan.spec(site_res2(i), D),
                  residual=(h2, D), bf16=plan.bf16)
-            saved += [h, u, st1, wcat, qkv, cx, h2, st2, u2, a]
+            del cx, u2, f, u16                              # forward-only buffers: the backward needs none of them
+            saved += [h, u, st1, wcat, qkv, h2, st2, a]
             h = h3
         lnfw, lnfb = params[n_layers * GPT2StackFn.PER_LAYER:]
         out = _empty(B, T, N, D, like=h)
@@ -548,8 +559,18 @@ class GPT2StackFn(torch.autograd.Function):
         lnfw = params[n_layers * GPT2StackFn.PER_LAYER]
         dh = _empty(M, D, like=dout)
         # every LayerNorm backward also emits dropout(dx) for the GEMM that sits behind the next resid dropout
+        b16 = int(plan.bf16) == ops.PREC_BF16
+
+        def masked_buf(sp_, W):
+            """dropout(dx) in front of the GEMM  . W^T : bf16 when that GEMM reads a bf16 copy of the frozen W."""
+            if sp_ is None:
+                return None
+            w16 = b16 and _bwd_weight(W, plan.bf16).dtype == torch.bfloat16
+            return torch.empty(M, D, device=dout.device, dtype=torch.bfloat16 if w16 else torch.float32)
+
         sp = plan.spec(site_res2(n_layers - 1), D)
-        dhm = _empty(M, D, like=dout) if sp is not None else dh
+        last_Wpr = params[(n_layers - 1) * GPT2StackFn.PER_LAYER + 12]
+        dhm = masked_buf(sp, last_Wpr) if sp is not None else dh
         nig = ctx.needs_input_grad                        # (h0, n_layers, plan, *params): params start at index 3
         base_f = 3 + n_layers * GPT2StackFn.PER_LAYER
         dlnfw, dlnfb = ops.layernorm_bwd(dout, D, h_last, D, lnfw, stf, None, dh, M, D,
@@ -559,7 +580,7 @@ class GPT2StackFn(torch.autograd.Function):
         for i in reversed(range(n_layers)):
             (ln1w, ln1b, Wqkv, bqkv, lA, lB, Wo, bo, ln2w, ln2b, Wfc, bfc, Wpr,
              bpr) = params[i * GPT2StackFn.PER_LAYER:(i + 1) * GPT2StackFn.PER_LAYER]
-            h, u, st1, wcat, qkv, cx, h2, st2, u2, a = saved[i * 10:(i + 1) * 10]
+            h, u, st1, wcat, qkv, h2, st2, a = saved[i * 8:(i + 1) * 8]
             F3, F4 = Wqkv.shape[1], Wfc.shape[1]
             # MLP:  h3 = h2 + drop(gelu(u2 Wfc + b) Wpr + b)
             Wpr_b, Wfc_b = _bwd_weight(Wpr, plan.bf16), _bwd_weight(Wfc, plan.bf16)
@@ -572,7 +593,7 @@ class GPT2StackFn(torch.autograd.Function):
             del da
             dh2 = _empty(M, D, like=dh)
             sp = plan.spec(site_res1(i), D)
-            dh2m = dhm if sp is not None else dh2             # dhm is dead once da has been formed
+            dh2m = masked_buf(sp, Wo) if sp is not None else dh2
             pb = 3 + i * GPT2StackFn.PER_LAYER
             dg2, db2 = ops.layernorm_bwd(du2, D, h2, D, ln2w, st2, dh, dh2, M, D,
                                          dx_masked=dh2m if sp is not None else None, mask_drop=sp,
@@ -595,7 +616,7 @@ class GPT2StackFn(torch.autograd.Function):
             gemm(M, D, LORA_R, du, KE, lA, D, du, KE, b_layout=B_KN, a_off=D, out_drop=lspec, accumulate=True, bf16=plan.bf16)
             dhn = _empty(M, D, like=dh)
             sp = plan.spec(site_res2(i - 1), D) if i > 0 else None
-            dhm = _empty(M, D, like=dh) if sp is not None else dhn
+            dhm = masked_buf(sp, params[(i - 1) * GPT2StackFn.PER_LAYER + 12]) if sp is not None else dhn
             dg1, db1 = ops.layernorm_bwd(du, KE, h, D, ln1w, st1, dh2, dhn, M, D,
                                          dx_masked=dhm if sp is not None else None, mask_drop=sp,
                                          need_dgb=nig[pb + 0] or nig[pb + 1])

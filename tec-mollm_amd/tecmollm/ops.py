@@ -237,15 +237,20 @@ def pick_split_k(Mo: int, No: int, K: int, target_blocks: int = 512, min_chunk: 
     return int(s)
 
 
-def layernorm_fwd(x: torch.Tensor, ldx: int, gamma: torch.Tensor, beta: torch.Tensor, y: torch.Tensor, ldy: int,
-                  stats: torch.Tensor, M: int, D: int, eps: float = 1e-5, y_off: int = 0) -> None:
-    check(lib().tecm_layernorm_fwd(x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), _off(y, y_off), ldy,
+def layernorm_fwd(x: torch.Tensor, ldx: int, gamma: torch.Tensor, beta: torch.Tensor, y: Optional[torch.Tensor], ldy: int,
+                  stats: torch.Tensor, M: int, D: int, eps: float = 1e-5, y_off: int = 0,
+                  y16: Optional[torch.Tensor] = None, ldy16: int = 0) -> None:
+    """y (fp32) and / or y16 (bf16 copy for a bf16 matrix-core GEMM, BASELINE configs[2])."""
+    if y16 is not None and y16.dtype != torch.bfloat16:
+        raise _lib.TecmError("layernorm_fwd: y16 must be a bfloat16 tensor")
+    check(lib().tecm_layernorm_fwd(x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(),
+                                   None if y is None else _off(y, y_off), ldy, ptr(y16), ldy16,
                                    stats.data_ptr(), M, D, eps, stream_ptr()), "tecm_layernorm_fwd")
 
 
 def layernorm_bwd_blocks(M: int, D: int) -> int:
     nb = C.c_int32(0)
-    check(lib().tecm_layernorm_bwd(None, 0, None, 0, None, None, None, None, None, None, None, C.byref(nb), M, D,
+    check(lib().tecm_layernorm_bwd(None, 0, None, 0, None, None, None, None, None, 0, None, None, C.byref(nb), M, D,
                                    None), "tecm_layernorm_bwd(query)")
     return nb.value
 
@@ -254,14 +259,16 @@ def layernorm_bwd(dy: torch.Tensor, lddy: int, x: torch.Tensor, ldx: int, gamma:
                   dres: Optional[torch.Tensor], dx: torch.Tensor, M: int, D: int,
                   dx_masked: Optional[torch.Tensor] = None,
                   mask_drop: Optional[TecmDrop] = None, need_dgb: bool = True):
-    """dx = dres + LN'(dy); optional dx_masked = dropout(dx, mask_drop).  Returns (dgamma, dbeta), or (None, None)
-    when need_dgb is False (frozen LayerNorm: the per-block partials are not reduced)."""
+    """dx = dres + LN'(dy); optional dx_masked = dropout(dx, mask_drop) -- fp32, or bf16 when its only reader is a bf16
+    GEMM.  Returns (dgamma, dbeta), or (None, None) when need_dgb is False (frozen LayerNorm: the per-block partials are
+    not reduced)."""
+    m16 = 1 if (dx_masked is not None and dx_masked.dtype == torch.bfloat16) else 0
     nb = layernorm_bwd_blocks(M, D)
     partials = torch.empty(nb, 2 * D, device=dx.device, dtype=torch.float32)
     nbc = C.c_int32(0)
     od = mask_drop if mask_drop is not None else NO_DROP
     check(lib().tecm_layernorm_bwd(dy.data_ptr(), lddy, x.data_ptr(), ldx, gamma.data_ptr(), stats.data_ptr(),
-                                   ptr(dres), dx.data_ptr(), ptr(dx_masked), C.byref(od), partials.data_ptr(),
+                                   ptr(dres), dx.data_ptr(), ptr(dx_masked), m16, C.byref(od), partials.data_ptr(),
                                    C.byref(nbc), M, D, stream_ptr()), "tecm_layernorm_bwd")
     if not need_dgb:
         return None, None
@@ -295,8 +302,8 @@ def groupnorm_gelu_bwd(dact: torch.Tensor, dstride: int, y: torch.Tensor, gamma:
 def attention_fwd(qkv: torch.Tensor, ctx: torch.Tensor, B: int, T: int, N: int, heads: int, D: int,
                   prob_drop: Optional[TecmDrop] = None) -> None:
     pd = prob_drop if prob_drop is not None else NO_DROP
-    check(lib().tecm_attention_fwd(qkv.data_ptr(), ctx.data_ptr(), B, T, N, heads, D, C.byref(pd), stream_ptr()),
-          "tecm_attention_fwd")
+    check(lib().tecm_attention_fwd(qkv.data_ptr(), ctx.data_ptr(), 1 if ctx.dtype == torch.bfloat16 else 0, B, T, N,
+                                   heads, D, C.byref(pd), stream_ptr()), "tecm_attention_fwd")
 
 
 def attention_bwd(qkv: torch.Tensor, dctx: torch.Tensor, dqkv: torch.Tensor, B: int, T: int, N: int, heads: int,
@@ -317,6 +324,13 @@ def colsum(inp: torch.Tensor, ld: int, outer: int, inner: int, nseg: int, Cn: in
     check(lib().tecm_colsum(_off(inp, in_off), ld, outer, inner, nseg, Cn, out.data_ptr(), Cn, 1 if accumulate else 0,
                             scale, C.byref(idr), ws.data_ptr(), stream_ptr()), "tecm_colsum")
     return out
+
+
+def cast_bf16(src: torch.Tensor, lds: int, dst: torch.Tensor, ldd: int, rows: int, cols: int, src_off: int = 0,
+              dst_off: int = 0) -> None:
+    """dst (bf16) [r][dst_off + c] = round(src (fp32) [r][src_off + c]) for c < cols."""
+    check(lib().tecm_cast_bf16(src.data_ptr() + 4 * src_off, lds, dst.data_ptr() + 2 * dst_off, ldd, rows, cols,
+                               stream_ptr()), "tecm_cast_bf16")
 
 
 def dropout_apply(src: torch.Tensor, rows: int, cols: int, spec: TecmDrop, ld: Optional[int] = None) -> torch.Tensor:

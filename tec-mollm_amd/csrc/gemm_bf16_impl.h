@@ -409,6 +409,67 @@ struct StagerSel<true, ROWS, WIN, DROP> {
   using type = TStager<ROWS, WIN, DROP>;
 };
 
+// Epilogue shared by the bf16 kernels: identical to the fp32 kernel's, 32-row slabs per wave through LDS.
+template <int MT, int NT, int WTM, int WTN>
+__device__ __forceinline__ void block_epilogue16(const TecmGemm& g, f32x16 (&acc)[MT][NT], unsigned char* smem_raw, int wave,
+                                                 int lane, int wm, int wn, int64_t m0, int64_t n0) {
+  constexpr int STG_LD = WTN + 4;
+  const int r = lane & 31, h = lane >> 5;
+  const DropCtx odc = make_drop(g.out_drop);
+  const bool split = gridDim.z > 1;
+  float* stg = reinterpret_cast<float*>(smem_raw) + wave * (32 * STG_LD);
+  static_for<MT>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    if (i > 0) __syncthreads();
+    static_for<16>([&](auto ec) {
+      constexpr int e = decltype(ec)::value;
+      static_for<NT>([&](auto jc) {
+        constexpr int jn = decltype(jc)::value;
+        stg[((e & 3) + 8 * (e >> 2) + 4 * h) * STG_LD + jn * 32 + r] = acc[i][jn][e];
+      });
+    });
+    __syncthreads();
+    if (g.io_bf16 & TECM_P0_VEC4) {
+      constexpr int LPR = WTN / 4, RPI = 64 / LPR;
+      const int lcol = (lane % LPR) * 4, lrow = lane / LPR;
+      const EpiCol ecol = epi_col(g, n0 + wn * WTN + lcol);
+      float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (g.bias && ecol.ok) bias4 = *reinterpret_cast<const float4*>(g.bias + ecol.n);
+#pragma unroll 1
+      for (int it = 0; it < 32 / RPI; ++it) {
+        const int rl = it * RPI + lrow;
+        const int64_t m = m0 + wm * WTM + i * 32 + rl;
+        if (m < g.M && ecol.ok) {
+          const float4 v = *reinterpret_cast<const float4*>(&stg[rl * STG_LD + lcol]);
+          if (split) {
+            *reinterpret_cast<float4*>(g.workspace + ((int64_t)blockIdx.z * g.M + m) * g.N + ecol.n) = v;
+          } else {
+            const EpiRow er = epi_row(g, odc, m);
+            epi_vec4(g, odc, er, ecol, bias4, v);
+          }
+        }
+      }
+    } else {
+      const int lcol = lane % WTN, lrow = lane / WTN;     // WTN = 64: one row per iteration
+      const EpiCol ecol = epi_col(g, n0 + wn * WTN + lcol);
+#pragma unroll 1
+      for (int it = 0; it < 32; ++it) {
+        const int rl = it + lrow;
+        const int64_t m = m0 + wm * WTM + i * 32 + rl;
+        if (m < g.M && ecol.ok) {
+          const float v = stg[rl * STG_LD + lcol];
+          if (split) {
+            g.workspace[((int64_t)blockIdx.z * g.M + m) * g.N + ecol.n] = v;
+          } else {
+            const EpiRow er = epi_row(g, odc, m);
+            epi_elem(g, odc, er, ecol, v);
+          }
+        }
+      }
+    }
+  });
+}
+
 template <int ALAY, int BLAY, bool WIN, bool DROP, int ADT = 0, int BDT = 0>      // ADT / BDT: 1 = the operand is bf16 in HBM
 __global__ __launch_bounds__(NTH, 2) void gemm_bf16_kernel(const TecmGemm g, int tiles_m, int tiles_n, int k_chunk) {
   static_assert((ADT == 0 && BDT == 0) || (!WIN && !DROP && ALAY == TECM_A_MK && BLAY == TECM_B_NK),
@@ -532,60 +593,7 @@ __global__ __launch_bounds__(NTH, 2) void gemm_bf16_kernel(const TecmGemm g, int
   for (; k0 + 3 * BK <= kend; k0 += BK) tile(k0, std::true_type{});
   for (; k0 < kend; k0 += BK) tile(k0, std::false_type{});
 
-  // ---- epilogue: identical to the fp32 kernel's, two 32-row slabs per wave through LDS
-  const DropCtx odc = make_drop(g.out_drop);
-  const bool split = gridDim.z > 1;
-  float* stg = reinterpret_cast<float*>(smem_raw) + wave * (32 * STG_LD);
-  static_for<MT>([&](auto ic) {
-    constexpr int i = decltype(ic)::value;
-    if (i > 0) __syncthreads();
-    static_for<16>([&](auto ec) {
-      constexpr int e = decltype(ec)::value;
-      static_for<NT>([&](auto jc) {
-        constexpr int jn = decltype(jc)::value;
-        stg[((e & 3) + 8 * (e >> 2) + 4 * h) * STG_LD + jn * 32 + r] = acc[i][jn][e];
-      });
-    });
-    __syncthreads();
-    if (g.io_bf16 & TECM_P0_VEC4) {
-      constexpr int LPR = WTN / 4, RPI = 64 / LPR;
-      const int lcol = (lane % LPR) * 4, lrow = lane / LPR;
-      const EpiCol ecol = epi_col(g, n0 + wn * WTN + lcol);
-      float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (g.bias && ecol.ok) bias4 = *reinterpret_cast<const float4*>(g.bias + ecol.n);
-#pragma unroll 1
-      for (int it = 0; it < 32 / RPI; ++it) {
-        const int rl = it * RPI + lrow;
-        const int64_t m = m0 + wm * WTM + i * 32 + rl;
-        if (m < g.M && ecol.ok) {
-          const float4 v = *reinterpret_cast<const float4*>(&stg[rl * STG_LD + lcol]);
-          if (split) {
-            *reinterpret_cast<float4*>(g.workspace + ((int64_t)blockIdx.z * g.M + m) * g.N + ecol.n) = v;
-          } else {
-            const EpiRow er = epi_row(g, odc, m);
-            epi_vec4(g, odc, er, ecol, bias4, v);
-          }
-        }
-      }
-    } else {
-      const int lcol = lane % WTN, lrow = lane / WTN;     // WTN = 64: one row per iteration
-      const EpiCol ecol = epi_col(g, n0 + wn * WTN + lcol);
-#pragma unroll 1
-      for (int it = 0; it < 32; ++it) {
-        const int rl = it + lrow;
-        const int64_t m = m0 + wm * WTM + i * 32 + rl;
-        if (m < g.M && ecol.ok) {
-          const float v = stg[rl * STG_LD + lcol];
-          if (split) {
-            g.workspace[((int64_t)blockIdx.z * g.M + m) * g.N + ecol.n] = v;
-          } else {
-            const EpiRow er = epi_row(g, odc, m);
-            epi_elem(g, odc, er, ecol, v);
-          }
-        }
-      }
-    }
-  });
+  block_epilogue16<MT, NT, WTM, WTN>(g, acc, smem_raw, wave, lane, wm, wn, m0, n0);
 }
 
 template <int ALAY, int BLAY, bool WIN, bool DROP, int ADT = 0, int BDT = 0>

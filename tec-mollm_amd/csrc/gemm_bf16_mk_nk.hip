@@ -2,8 +2,14 @@
 // variants whose A and / or B operand already is bf16 in HBM (TecmGemm::io_bf16).
 #include "gemm_bf16_impl.h"
 
+int tecm_gemm16_dma_try(const TecmGemm& g, hipStream_t st);     // gemm_bf16_dma.hip
+
 int tecm_gemm16_dispatch_mk_nk(const TecmGemm& g, bool win, bool drop, hipStream_t st) {
   const bool a16 = g.io_bf16 & TECM_IO_A_BF16, b16 = g.io_bf16 & TECM_IO_B_BF16;
+  if (a16 && b16) {
+    const int served = tecm_gemm16_dma_try(g, st);      // 256 x 256 LDS-DMA kernel when the shape qualifies
+    if (served != 0) return served;
+  }
   if (a16 && b16) return tecm_gemm16::launch<TECM_A_MK, TECM_B_NK, false, false, 1, 1>(g, st);
   if (a16) return tecm_gemm16::launch<TECM_A_MK, TECM_B_NK, false, false, 1, 0>(g, st);
   if (b16) return tecm_gemm16::launch<TECM_A_MK, TECM_B_NK, false, false, 0, 1>(g, st);

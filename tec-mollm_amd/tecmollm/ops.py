@@ -2,6 +2,7 @@
 asynchronously on torch's current stream; tensors are only used as device-memory handles."""
 from __future__ import annotations
 
+import os
 import ctypes as C
 from typing import Optional, Tuple
 
@@ -182,6 +183,11 @@ def _kernel_name(g: TecmGemm, use16: bool = False) -> str:
     if use16:
         win16 = "true" if (g.a_win.enabled or g.b_win.enabled) else "false"
         drp16 = "true" if (g.a_drop.p > 0 or g.b_drop.p > 0) else "false"
+        both16 = (g.io_bf16 & IO_A_BF16) and (g.io_bf16 & IO_B_BF16)
+        # mirrors tecm_gemm16_dma_try (csrc/gemm_bf16_dma.hip); the float4-epilogue condition holds for every bf16 call
+        if (both16 and g.split_k <= 1 and g.N % 4 == 0 and g.K % 32 == 0 and g.K >= 64 and g.M >= 256 and g.N >= 128
+                and os.environ.get("TECM_BF16_DMA", "1")[:1] != "0"):
+            return "gemm_bf16_dma_kernel"
         return f"gemm_bf16_kernel<{g.a_layout},{g.b_layout},{win16},{drp16}>"
     av = _vec(g.A, g.lda, g.a_win, g.a_layout == A_MK, g.K)
     bv = _vec(g.B, g.ldb, g.b_win, g.b_layout == B_NK, g.K)

@@ -138,3 +138,37 @@ def test_bf16_resident_operands_and_output_are_bit_identical(dev, M, N, K):
     assert torch.equal(got16, want.bfloat16()) and torch.equal(pre, pre_w)        # RNE at the store == .bfloat16()
     with pytest.raises(Exception):
         ops.gemm(M, N, K, A16, K, Bn, K, got, N)                                  # fp32 kernel refuses bf16 tensors
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (257, 800, 2304), (700, 132, 96), (1031, 2304, 800), (4099, 768, 3072),
+                                   (513, 3072, 768), (300, 256, 32 * 7)])
+def test_bf16_dma_kernel_matches_the_register_staged_kernel_bit_for_bit(dev, M, N, K, monkeypatch):
+    """The 256x256 LDS-DMA kernel (gemm_bf16_dma.hip: both operands bf16 in HBM) against the 256x128 register-staged
+    kernel on the same tensors: ragged M and N tiles, K tails of 32, single K-tile, every epilogue the GPT-2 stack
+    uses (bias + GELU + pre-activation store + bf16 C; bias + dropout + residual; GELU' from a saved pre-activation)."""
+    from tecmollm import ops
+    A16, B16 = _rand(M, K, dev=dev, seed=1).bfloat16(), _rand(N, K, dev=dev, seed=2, scale=0.05).bfloat16()
+    bias, res, pre_src = _rand(N, dev=dev, seed=4), _rand(M, N, dev=dev, seed=5), _rand(M, N, dev=dev, seed=6)
+
+    def run():
+        outs = []
+        c16, pre = torch.empty(M, N, device=dev, dtype=torch.bfloat16), torch.full((M, N), float("nan"), device=dev)
+        ops.gemm(M, N, K, A16, K, B16, K, c16, N, bias=bias, act=ops.ACT_GELU_TANH, preact=(pre, N), bf16=True)
+        outs += [c16, pre]
+        c = torch.full((M, N), float("nan"), device=dev)
+        ops.gemm(M, N, K, A16, K, B16, K, c, N, bias=bias, out_drop=ops.drop(0.1, 77, N), residual=(res, N), bf16=True)
+        outs.append(c)
+        d16 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        ops.gemm(M, N, K, A16, K, B16, K, d16, N, act=ops.ACT_GELU_TANH, dact_src=(pre_src, N), bf16=True)
+        outs.append(d16)
+        torch.cuda.synchronize()
+        return outs
+
+    monkeypatch.setenv("TECM_BF16_DMA", "0")
+    want = run()
+    monkeypatch.setenv("TECM_BF16_DMA", "1")
+    got = run()
+    for g_, w_ in zip(got, want):
+        assert torch.equal(g_, w_)
+    ref = A16.double() @ B16.double().t()
+    assert _rel(want[1], ref + bias.double()) < TOL

@@ -1,0 +1,403 @@
+// bf16 MFMA GEMM for operands that already live in HBM as bf16, both [row][k] (activations written as bf16 by their
+// producers, cached bf16 copies of the frozen GPT-2 weights): the plain MK x NK contraction behind 7 of the 8 big
+// GPT-2 GEMMs of a layer in bf16 mode (BASELINE configs[2]).  Same descriptor and epilogue as gemm_bf16_impl.h; the
+// operand path is a pure copy, so it is done by LDS-DMA and the tile is sized for it:
+//
+//   * block = 512 threads = 8 waves as 2(m) x 4(n), tile 256 x 256 x 64, ONE block per CU (128 KiB of LDS, up to 256
+//     registers per lane).  A wave owns 128 x 64 = 4 x 2 MFMA tiles (v_mfma_f32_32x32x16_bf16, 128 accumulators) and
+//     per 16-deep k-step issues 6 ds_read_b128 for 8 MFMAs (the 256 x 128 kernel: 4 for 4) -- 0.75 KiB of LDS reads
+//     per MFMA instead of 1 KiB, and 64 KiB of operand per 8.4 MFLOP instead of 48 KiB per 4.2;
+//   * global -> LDS by `global_load_lds_dwordx4` (1 KiB per wave-instruction, no VGPR round trip, no ds_write): a
+//     K-tile is 64 pieces of 8 rows x 128 B; wave w moves pieces 4w..4w+3 of A and of B.  The DMA writes
+//     wave-uniform base + lane * 16, so a tile is stored linearly and the bank-conflict swizzle is applied to the
+//     per-lane SOURCE address and again on the fragment read: 16-byte chunk c of row r sits at position
+//     c ^ ((r >> 1) & 7) -- the four 16-lane groups of a ds_read_b128 ({0-3,12-15,20-27}, ...) then touch 16
+//     distinct 4-bank groups;
+//   * two LDS buffers, one barrier per K-tile: the DMA of tile t+1 is issued before the MFMAs of tile t and retired
+//     by the s_waitcnt vmcnt(0) in front of the barrier that ends tile t;
+//   * K % 64 == 32 (c_attn with its 32 LoRA columns: K = 800): in the last tile the lanes whose source chunk lies
+//     beyond K do not take part in the DMA (it honours EXEC) and store zeros into their slot instead, so the K loop
+//     has one body (a second, shorter body makes the compiler copy the 128 accumulators).
+//
+// Eligibility (tecm_gemm16_dma_try): A and B bf16, plain views, no prologue dropout, split_k <= 1, K % 32 == 0,
+// K >= 64, 16-byte friendly operands, float4 epilogue.  Everything else stays on gemm_bf16_kernel.
+#include <cstdlib>
+#include "gemm_bf16_impl.h"
+
+namespace tecm_gemm16 {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+__device__ __forceinline__ void dma16(const __bf16* src, __bf16* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)lds_wave_base, 16, 0, 0);
+}
+
+// Epilogue straight from the accumulators.  The kernels below issue the MFMA with the operands swapped (B fragment
+// first): the accumulator block then holds the TRANSPOSED 32 x 32 tile -- lane & 31 is the output ROW m, register e is
+// output column (e & 3) + 8 (e >> 2) + 4 (lane >> 5) -- so a lane owns four runs of 4 consecutive columns per tile and
+// stores them as one float4 (or 4 bf16) each: no LDS staging, no barriers, 32 independent groups per lane.  (Same
+// products in the same k order as the staged epilogue's orientation: results are bit-identical.)  With K = 768 the
+// staged, rolled epilogue of gemm_bf16_impl.h cost as much as the whole K loop (ablation in DESIGN.md section 4).
+template <int MT, int NT>
+__device__ __forceinline__ void direct_epilogue16(const TecmGemm& g, f32x16 (&acc)[MT][NT], int lane, int64_t m_base,
+                                                  int64_t n_base) {
+  const DropCtx odc = make_drop(g.out_drop);
+  const int r = lane & 31, h = lane >> 5;
+  EpiCol ec[NT][4];
+  float4 bias4[NT][4];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t n = n_base + j * 32 + 8 * q + 4 * h;
+      ec[j][q] = epi_col(g, n);
+      bias4[j][q] = (g.bias && ec[j][q].ok) ? *reinterpret_cast<const float4*>(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  static_for<MT>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    const int64_t m = m_base + i * 32 + r;
+    if (m < g.M) {
+      const EpiRow er = epi_row(g, odc, m);
+      static_for<NT>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        static_for<4>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          if (ec[j][q].ok)
+            epi_vec4(g, odc, er, ec[j][q], bias4[j][q],
+                     make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]));
+        });
+      });
+    }
+  });
+}
+
+constexpr int DBM = 256, DBN = 256, DBK = 64, DNTH = 512;
+
+__global__ __launch_bounds__(DNTH, 1) void gemm_bf16_dma_kernel(const TecmGemm g, int tiles_m, int tiles_n) {
+  constexpr int WM = 2, WN = 4;
+  constexpr int WTM = DBM / WM, WTN = DBN / WN;        // 128 x 64 per wave
+  constexpr int MT = WTM / 32, NT = WTN / 32;          // 4 x 2
+  constexpr int A_ELEMS = DBM * DBK, B_ELEMS = DBN * DBK, TILE_ELEMS = A_ELEMS + B_ELEMS;   // bf16 elements: 64 KiB
+  constexpr int PIECE = 8 * DBK;                       // 8 rows = 1 KiB
+  __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[2 * TILE_ELEMS * 2];
+  __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);
+  static_assert(2 * TILE_ELEMS * 2 >= 8 * 32 * (WTN + 4) * 4, "epilogue slabs fit in the operand buffers");
+
+  // block -> tile map: XCD-contiguous runs, GROUP_M m-tiles per L2 super-tile (as gemm_bf16_kernel)
+  const int nwg = tiles_m * tiles_n;
+  const int id = blockIdx.x;
+  const int xcd = id & 7, local = id >> 3;
+  const int q8 = nwg >> 3, r8 = nwg & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
+  constexpr int GROUP_M = 4;
+  const int per_group = GROUP_M * tiles_n;
+  const int group = wg / per_group;
+  const int first_m = group * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int in_group = wg - group * per_group;
+  const int tm = first_m + in_group % gsz, tn = in_group / gsz;
+  const int64_t m0 = (int64_t)tm * DBM;
+  const int64_t n0 = (int64_t)tn * DBN;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 31, h = lane >> 5;
+  const int K = (int)g.K;
+  const int ntiles = (K + DBK - 1) / DBK;
+  const bool ktail = (K % DBK) != 0;                   // K % 64 == 32
+
+  // ---- per-lane DMA sources: piece p = 4 * wave + i covers tile rows 8p .. 8p+7; lane -> (row 8p + lane/8, position
+  // lane % 8); the chunk fetched into that position is position ^ swizzle(row)
+  const __bf16* Ah = reinterpret_cast<const __bf16*>(g.A);
+  const __bf16* Bh = reinterpret_cast<const __bf16*>(g.B);
+  const __bf16* asrc[4];
+  const __bf16* bsrc[4];
+  int chunk_of[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    chunk_of[i] = chunk;
+    int64_t gm = m0 + row;
+    gm = gm < g.M ? gm : g.M - 1;                      // clamped rows feed accumulator rows that are never stored
+    int64_t gn = n0 + row;
+    gn = gn < g.N ? gn : g.N - 1;
+    asrc[i] = Ah + gm * g.lda + chunk * 8;
+    bsrc[i] = Bh + gn * g.ldb + chunk * 8;
+  }
+  auto issue_tile = [&](__bf16* buf, bool tail) {
+    __bf16* a_dst = buf + (wave * 4) * PIECE;
+    __bf16* b_dst = buf + A_ELEMS + (wave * 4) * PIECE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (!tail || chunk_of[i] < 4) {
+        dma16(asrc[i], a_dst + i * PIECE);
+        dma16(bsrc[i], b_dst + i * PIECE);
+      } else {                                         // beyond K: the slot the DMA would have filled holds zeros
+        *reinterpret_cast<uint4*>(a_dst + i * PIECE + lane * 8) = make_uint4(0u, 0u, 0u, 0u);
+        *reinterpret_cast<uint4*>(b_dst + i * PIECE + lane * 8) = make_uint4(0u, 0u, 0u, 0u);
+      }
+      asrc[i] += DBK;
+      bsrc[i] += DBK;
+    }
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // fragment addresses (bf16 elements within a tile buffer) and row swizzles
+  int a_off[MT], a_sw[MT], b_off[NT], b_sw[NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int row = wm * WTM + i * 32 + r;
+    a_off[i] = row * DBK;
+    a_sw[i] = (row >> 1) & 7;
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int row = wn * WTN + j * 32 + r;
+    b_off[j] = A_ELEMS + row * DBK;
+    b_sw[j] = (row >> 1) & 7;
+  }
+  auto read_frags = [&](const __bf16* T, int s, bf16x8 (&af)[MT], bf16x8 (&bf)[NT]) {
+    const int c = 2 * s + h;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(T + a_off[i] + ((c ^ a_sw[i]) << 3));
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(T + b_off[j] + ((c ^ b_sw[j]) << 3));
+  };
+  auto do_mfma = [&](const bf16x8 (&af)[MT], const bf16x8 (&bf)[NT]) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+  };
+
+  issue_tile(smem, ktail && ntiles == 1);
+  __syncthreads();                                      // vmcnt(0) + barrier: tile 0 has landed
+
+  bf16x8 fa[2][MT], fb[2][NT];
+  int cur = 0;
+  for (int t = 0; t < ntiles; ++t) {
+    const __bf16* Tc = smem + cur * TILE_ELEMS;
+#ifndef DMA_ABLATE_NOLOAD
+    if (t + 1 < ntiles) issue_tile(smem + (cur ^ 1) * TILE_ELEMS, ktail && t + 2 == ntiles);
+#endif
+    read_frags(Tc, 0, fa[0], fb[0]);
+    static_for<4>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      if constexpr (s < 3) read_frags(Tc, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+      do_mfma(fa[s & 1], fb[s & 1]);
+      // interleave: one LDS read behind each of the first six MFMAs of the step
+#pragma unroll
+      for (int m = 0; m < MT * NT; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                  // 1 MFMA
+        if (s < 3 && m < MT + NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // 1 DS read
+      }
+    });
+    __syncthreads();                                    // DMA of tile t+1 retired, every wave done with tile t
+    cur ^= 1;
+  }
+
+#ifdef DMA_ABLATE_NOEPI                                  // diagnostics (tools/build_variant.py): K loop without the epilogue
+  float keep = 0.f;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) keep += acc[i][j][e];
+  if (keep == 12345.678f) reinterpret_cast<float*>(g.C)[0] = keep;
+#else
+  block_epilogue16<MT, NT, WTM, WTN>(g, acc, smem_raw, wave, lane, wm, wn, m0, n0);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Two blocks per CU: 256 x 128 x 32 tiles, 256 threads = 4 waves as 2(m) x 2(n), the same 128 x 64 wave tile
+// (6 ds_read_b128 per 8 MFMAs), THREE 24 KiB LDS stages (72 KiB per block, 144 KiB per CU).  The two waves a SIMD
+// holds now belong to different blocks: their barriers are independent and the epilogue of one block (256 KiB of
+// accumulators through LDS, GELU / dropout / residual arithmetic, up to 1.3 GB of stores per launch) runs under the
+// K loop of the other -- with K = 768 the loop is only 24 tiles long and a lone block per CU leaves the matrix
+// pipe idle for a third of its life.  Rows are 64 B = 4 chunks; chunk c of row r sits at position c ^ ((r >> 2) & 3)
+// (a ds_read_b128 lane group covers four row quads with distinct swizzles x four rows with distinct bank
+// quarters).  K % 32 == 0 is all the K loop needs.  Pipeline: tile t+2 is put in flight right after the barrier
+// that opens tile t (its buffer was tile t-1's); that barrier is a bare s_barrier behind `s_waitcnt vmcnt(6)` -- a
+// wave waits for ITS six pieces of tile t only, the six of tile t+1 stay in flight across the barrier.
+constexpr int EBM = 256, EBN = 128, EBK = 32, ENTH = 256, ESTAGES = 3;
+
+__global__ __launch_bounds__(ENTH, 2) void gemm_bf16_dma2_kernel(const TecmGemm g, int tiles_m, int tiles_n, int stagger) {
+  constexpr int WM = 2, WN = 2;
+  constexpr int WTM = EBM / WM, WTN = EBN / WN;        // 128 x 64 per wave
+  constexpr int MT = WTM / 32, NT = WTN / 32;          // 4 x 2
+  constexpr int A_ELEMS = EBM * EBK, B_ELEMS = EBN * EBK, TILE_ELEMS = A_ELEMS + B_ELEMS;   // bf16 elements: 24 KiB
+  constexpr int PIECE = 16 * EBK;                      // 16 rows = 1 KiB
+  __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[ESTAGES * TILE_ELEMS * 2];
+  __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 31, h = lane >> 5;
+  const int ntiles = (int)g.K / EBK;
+  const __bf16* Ah = reinterpret_cast<const __bf16*>(g.A);
+  const __bf16* Bh = reinterpret_cast<const __bf16*>(g.B);
+
+  // fragment addresses: every fragment row of this lane is its r plus a multiple of 32 -- one swizzle for all of them
+  int a_off[MT], b_off[NT];
+  const int sw = (r >> 2) & 3;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) a_off[i] = (wm * WTM + i * 32 + r) * EBK;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) b_off[j] = A_ELEMS + (wn * WTN + j * 32 + r) * EBK;
+  const int c0 = ((0 + h) ^ sw) << 3, c1 = ((2 + h) ^ sw) << 3;       // k-steps 0 and 1 of a 32-deep tile
+
+  if (stagger > 0 && (blockIdx.x & 1))
+    for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
+
+  // Persistent block: output tiles blockIdx.x, blockIdx.x + gridDim.x, ...  (gridDim.x is a multiple of 8, so every
+  // tile of a block has the block's XCD and the XCD-contiguous tile map below stays valid).  A block that ends frees
+  // its CU slot only once its stores have been acknowledged, and the next block then starts cold; a persistent block
+  // issues the stores of tile i and goes on to load tile i+1.
+  const int nwg = tiles_m * tiles_n;
+  for (int id = blockIdx.x; id < nwg; id += gridDim.x) {
+    const int xcd = id & 7, local = id >> 3;
+    const int q8 = nwg >> 3, r8 = nwg & 7;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
+    constexpr int GROUP_M = 4;
+    const int per_group = GROUP_M * tiles_n;
+    const int group = wg / per_group;
+    const int first_m = group * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int in_group = wg - group * per_group;
+    const int tm = first_m + in_group % gsz, tn = in_group / gsz;
+    const int64_t m0 = (int64_t)tm * EBM;
+    const int64_t n0 = (int64_t)tn * EBN;
+
+    // ---- DMA sources: a piece is 16 rows; wave w moves A pieces 4w..4w+3 and B pieces 2w, 2w+1 of every K-tile
+    const __bf16* asrc[4];
+    const __bf16* bsrc[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (wave * 4 + i) * 16 + (lane >> 2);
+      const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+      int64_t gm = m0 + row;
+      gm = gm < g.M ? gm : g.M - 1;                    // clamped rows feed accumulator rows that are never stored
+      asrc[i] = Ah + gm * g.lda + chunk * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = (wave * 2 + i) * 16 + (lane >> 2);
+      const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+      int64_t gn = n0 + row;
+      gn = gn < g.N ? gn : g.N - 1;
+      bsrc[i] = Bh + gn * g.ldb + chunk * 8;
+    }
+    auto issue_tile = [&](__bf16* buf) {
+      __bf16* a_dst = buf + (wave * 4) * PIECE;
+      __bf16* b_dst = buf + A_ELEMS + (wave * 2) * PIECE;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        dma16(asrc[i], a_dst + i * PIECE);
+        asrc[i] += EBK;
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        dma16(bsrc[i], b_dst + i * PIECE);
+        bsrc[i] += EBK;
+      }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    issue_tile(smem);
+    if (ntiles > 1) issue_tile(smem + TILE_ELEMS);
+
+    int cur = 0;                                       // stage of tile t
+    for (int t = 0; t < ntiles; ++t) {
+      // the stores of the previous output tile are older than these loads and retire in order: vmcnt(6) covers them
+      if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#ifndef DMA_ABLATE_NOLOAD
+      if (t + 2 < ntiles) {
+        const int nxt = cur == 0 ? 2 : cur - 1;        // (t + 2) % 3: the stage tile t-1 has just vacated
+        issue_tile(smem + nxt * TILE_ELEMS);
+      }
+#endif
+      const __bf16* Tc = smem + cur * TILE_ELEMS;
+      bf16x8 fa0[MT], fb0[NT], fa1[MT], fb1[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) fa0[i] = *reinterpret_cast<const bf16x8*>(Tc + a_off[i] + c0);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) fb0[j] = *reinterpret_cast<const bf16x8*>(Tc + b_off[j] + c0);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) fa1[i] = *reinterpret_cast<const bf16x8*>(Tc + a_off[i] + c1);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) fb1[j] = *reinterpret_cast<const bf16x8*>(Tc + b_off[j] + c1);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb0[j], fa0[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb1[j], fa1[i], acc[i][j], 0, 0, 0);
+      cur = cur == 2 ? 0 : cur + 1;
+    }
+    // every wave is done reading the stages before the next output tile's first pieces are put in flight
+    asm volatile("s_barrier" ::: "memory");
+#ifdef DMA_ABLATE_NOEPI                                  // diagnostics (tools/build_variant.py): K loop without the epilogue
+    float keep = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) keep += acc[i][j][e];
+    if (keep == 12345.678f) reinterpret_cast<float*>(g.C)[0] = keep;
+#else
+    direct_epilogue16<MT, NT>(g, acc, lane, m0 + wm * WTM, n0 + wn * WTN);
+#endif
+  }
+}
+
+}  // namespace tecm_gemm16
+
+// Returns the number of K splits (1) when the DMA kernel served the call, 0 when the call is not eligible.
+int tecm_gemm16_dma_try(const TecmGemm& g, hipStream_t st) {
+  using namespace tecm_gemm16;
+  // diagnostics: TECM_BF16_DMA=0 always uses the register-staged kernel, =2 the one-block-per-CU 256 x 256 kernel
+  const char* sel = std::getenv("TECM_BF16_DMA");
+  if (sel && sel[0] == '0') return 0;
+  const bool both = (g.io_bf16 & TECM_IO_A_BF16) && (g.io_bf16 & TECM_IO_B_BF16);
+  if (!both || !(g.io_bf16 & TECM_P0_VEC4) || g.split_k > 1 || g.K % 32 != 0 || g.K < DBK || g.M < DBM || g.N < DBN / 2)
+    return 0;
+  if (sel && sel[0] == '2') {
+    const int tiles_m = (int)((g.M + DBM - 1) / DBM);
+    const int tiles_n = (int)((g.N + DBN - 1) / DBN);
+    hipLaunchKernelGGL(gemm_bf16_dma_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(DNTH), 0, st, g, tiles_m, tiles_n);
+  } else {
+    const int tiles_m = (int)((g.M + EBM - 1) / EBM);
+    const int tiles_n = (int)((g.N + EBN - 1) / EBN);
+    const char* sg = std::getenv("TECM_DMA_STAGGER");
+    const int stagger = sg ? std::atoi(sg) : 0;
+    const char* pg = std::getenv("TECM_DMA_GRID");      // diagnostics: persistent grid size (multiple of 8)
+    int grid = pg ? std::atoi(pg) : 512;                // 256 CUs x 2 resident blocks
+    if (grid <= 0 || grid > tiles_m * tiles_n) grid = tiles_m * tiles_n;
+    if (grid < tiles_m * tiles_n) grid &= ~7;
+    hipLaunchKernelGGL(gemm_bf16_dma2_kernel, dim3((unsigned)grid), dim3(ENTH), 0, st, g, tiles_m, tiles_n, stagger);
+  }
+  TECM_CHECK_LAUNCH("tecm_gemm_bf16/dma");
+  return 1;
+}

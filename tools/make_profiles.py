@@ -27,6 +27,8 @@ def short(name: str) -> str:
         if m.group(1) == "gemm_bf16_kernel":
             a = a[:4]
         return f"{m.group(1)}<{','.join(a)}>"
+    if "gemm_bf16_dma_kernel" in name:
+        return "gemm_bf16_dma_kernel"
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
     name = re.sub(r"\(.*", "", name)
     return name.split("::")[-1].strip()[:70]

@@ -418,6 +418,29 @@ __device__ __forceinline__ void block_epilogue16(const TecmGemm& g, f32x16 (&acc
   const DropCtx odc = make_drop(g.out_drop);
   const bool split = gridDim.z > 1;
   float* stg = reinterpret_cast<float*>(smem_raw) + wave * (32 * STG_LD);
+  auto stage_slab = [&](auto ic) {                     // 32 accumulator rows of this wave -> its private staging rows
+    constexpr int i = decltype(ic)::value;
+    static_for<16>([&](auto ec) {
+      constexpr int e = decltype(ec)::value;
+      static_for<NT>([&](auto jc) {
+        constexpr int jn = decltype(jc)::value;
+        stg[((e & 3) + 8 * (e >> 2) + 4 * h) * STG_LD + jn * 32 + r] = acc[i][jn][e];
+      });
+    });
+  };
+  const int fmode = tecm_gemm::epi_fast_mode(g);
+  if (fmode >= 0) {
+    // straight-line form (gemm_impl.h): no barriers -- the staging rows are private to the wave, and a
+    // __syncthreads would drain every outstanding store -- and the optional input stream runs one slab ahead
+    constexpr int LPR = WTN / 4, RPI = 64 / LPR;
+    const int lcol = (lane % LPR) * 4, lrow = lane / LPR;
+    const EpiCol ecol = epi_col(g, n0 + wn * WTN + lcol);
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.bias && ecol.ok) bias4 = *reinterpret_cast<const float4*>(g.bias + ecol.n);
+    tecm_gemm::epi_fast_dispatch<MT, 32 / RPI, RPI, STG_LD>(fmode, g, odc, stg, lrow, lcol, m0 + wm * WTM, ecol, bias4,
+                                                             stage_slab);
+    return;
+  }
   static_for<MT>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
     if (i > 0) __syncthreads();

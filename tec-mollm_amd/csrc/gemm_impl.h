@@ -490,6 +490,112 @@ __device__ __forceinline__ void epi_vec4(const TecmGemm& g, const DropCtx& odc, 
   *reinterpret_cast<float4*>(g.C + off) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
+// ---------------------------------------------------------------------------------------- fast epilogue rows
+// gfx9 counts loads AND stores in one counter (vmcnt).  In the generic rolled row loop below every iteration ends in
+// a store and the next one starts with code that MAY load (residual / dact_src / accumulate / row bias behind
+// wave-uniform branches): the compiler has to cover that with `s_waitcnt vmcnt(0)`, which also waits for the
+// previous iteration's store to be acknowledged -- a store round trip per row group, serialised.  (Measured on the
+// bf16 kernels, where it shows most: the epilogue of a K = 768 GEMM cost as much as its whole K loop and did not
+// depend on the bytes written.)  The common cases therefore run through this straight-line form: NIT row groups
+// fully unrolled, the one optional input stream (MODE 1: residual, MODE 2: GELU' source) loaded for ALL groups up
+// front, then LDS read -> arithmetic -> stores back to back with counted waits only.  Element arithmetic is
+// epi_vec4's, expression for expression.
+template <int NIT, int RPI, int MODE>
+__device__ __forceinline__ void epi_fast_load(const TecmGemm& g, int lrow, int64_t mrow0, const EpiCol& ecol,
+                                              float4 (&in)[NIT]) {
+  if constexpr (MODE >= 1 && MODE <= 3) {
+    if (!ecol.ok) return;
+    const float* src = MODE == 1 ? g.residual : (MODE == 2 ? g.dact_src : g.C);
+    const int64_t ld = MODE == 1 ? g.ldr : (MODE == 2 ? g.ldd : g.ldc);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      int64_t m = mrow0 + it * RPI + lrow;
+      m = m < g.M ? m : g.M - 1;                       // clamped: a valid address, the value is not used
+      in[it] = *reinterpret_cast<const float4*>(src + m * ld + ecol.n);
+    }
+  }
+}
+template <int NIT, int RPI, int STG_LD, int MODE>
+__device__ __forceinline__ void epi_fast_rows(const TecmGemm& g, const DropCtx& odc, const float* stg, int lrow, int lcol,
+                                              int64_t mrow0, const EpiCol& ecol, const float4& bias4,
+                                              const float4 (&in)[NIT]) {
+  if (!ecol.ok) return;
+  const int32_t n = ecol.n;
+  const bool c16 = (g.io_bf16 & TECM_IO_C_BF16) != 0;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int rl = it * RPI + lrow;
+    const int64_t m = mrow0 + rl;
+    const float4 v = *reinterpret_cast<const float4*>(&stg[rl * STG_LD + lcol]);
+    const bool row_ok = m < g.M;
+    if constexpr (MODE == 4) {                         // split-K slab: the raw partial sums
+      if (row_ok) *reinterpret_cast<float4*>(g.workspace + ((int64_t)blockIdx.z * g.M + m) * g.N + n) = v;
+      continue;
+    }
+    float o[4] = {v.x * g.alpha + bias4.x, v.y * g.alpha + bias4.y, v.z * g.alpha + bias4.z, v.w * g.alpha + bias4.w};
+    if (g.preact && row_ok) *reinterpret_cast<float4*>(g.preact + m * g.ldp + n) = make_float4(o[0], o[1], o[2], o[3]);
+    if constexpr (MODE == 2) {
+      o[0] *= dgelu_tanh(in[it].x); o[1] *= dgelu_tanh(in[it].y);
+      o[2] *= dgelu_tanh(in[it].z); o[3] *= dgelu_tanh(in[it].w);
+    } else {
+      if (g.act) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = gelu_tanh(o[e]);
+      }
+    }
+    if (odc.thresh) {
+      const int64_t didx = m * odc.ld + n;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] *= tecm_drop_mult(odc.seed, (uint64_t)(didx + e), odc.thresh, odc.inv);
+    }
+    if constexpr (MODE == 1 || MODE == 3) {            // + residual, or + the previous contents of C (accumulate)
+      o[0] += in[it].x; o[1] += in[it].y; o[2] += in[it].z; o[3] += in[it].w;
+    }
+    if (row_ok) {
+      const int64_t off = m * g.ldc + n;
+      if (c16) tecm_store_bf16x4(reinterpret_cast<__bf16*>(g.C) + off, o[0], o[1], o[2], o[3]);
+      else *reinterpret_cast<float4*>(g.C + off) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+// One wave's staged block of SLABS x (NIT * RPI) rows: the input stream of slab s+1 is requested BEFORE the stores
+// of slab s are issued, so that waiting for it does not mean waiting for those stores (vmcnt retires in order).
+// stage(s) parks slab s of the accumulators in the wave's PRIVATE staging rows (no barrier: nobody else reads them).
+template <int SLABS, int NIT, int RPI, int STG_LD, int MODE, typename StageFn>
+__device__ __forceinline__ void epi_fast_block(const TecmGemm& g, const DropCtx& odc, const float* stg, int lrow, int lcol,
+                                               int64_t mrow0, const EpiCol& ecol, const float4& bias4, StageFn&& stage) {
+  float4 in[2][NIT];
+  epi_fast_load<NIT, RPI, MODE>(g, lrow, mrow0, ecol, in[0]);
+  static_for<SLABS>([&](auto sc) {
+    constexpr int sl = decltype(sc)::value;
+    stage(sc);
+    if constexpr (sl + 1 < SLABS)
+      epi_fast_load<NIT, RPI, MODE>(g, lrow, mrow0 + (int64_t)(sl + 1) * NIT * RPI, ecol, in[(sl + 1) & 1]);
+    epi_fast_rows<NIT, RPI, STG_LD, MODE>(g, odc, stg, lrow, lcol, mrow0 + (int64_t)sl * NIT * RPI, ecol, bias4, in[sl & 1]);
+  });
+}
+// which epilogues the straight-line form serves (everything else: the generic loop)
+// MODE: 0 no input stream, 1 residual, 2 GELU' source, 3 accumulate into C, 4 split-K slab store; -1: generic loop
+__device__ __forceinline__ int epi_fast_mode(const TecmGemm& g) {
+  if (!(g.io_bf16 & TECM_P0_VEC4)) return -1;
+  if (gridDim.z > 1) return 4;
+  if (g.c_win.enabled || g.rowbias) return -1;
+  const int streams = (g.residual ? 1 : 0) + (g.dact_src ? 1 : 0) + (g.accumulate ? 1 : 0);
+  if (streams > 1) return -1;
+  return g.residual ? 1 : (g.dact_src ? 2 : (g.accumulate ? 3 : 0));
+}
+// dispatch on the (wave-uniform) mode
+template <int SLABS, int NIT, int RPI, int STG_LD, typename StageFn>
+__device__ __forceinline__ void epi_fast_dispatch(int mode, const TecmGemm& g, const DropCtx& odc, const float* stg, int lrow,
+                                                  int lcol, int64_t mrow0, const EpiCol& ecol, const float4& bias4,
+                                                  StageFn&& stage) {
+  if (mode == 0) epi_fast_block<SLABS, NIT, RPI, STG_LD, 0>(g, odc, stg, lrow, lcol, mrow0, ecol, bias4, stage);
+  else if (mode == 1) epi_fast_block<SLABS, NIT, RPI, STG_LD, 1>(g, odc, stg, lrow, lcol, mrow0, ecol, bias4, stage);
+  else if (mode == 2) epi_fast_block<SLABS, NIT, RPI, STG_LD, 2>(g, odc, stg, lrow, lcol, mrow0, ecol, bias4, stage);
+  else if (mode == 3) epi_fast_block<SLABS, NIT, RPI, STG_LD, 3>(g, odc, stg, lrow, lcol, mrow0, ecol, bias4, stage);
+  else epi_fast_block<SLABS, NIT, RPI, STG_LD, 4>(g, odc, stg, lrow, lcol, mrow0, ecol, bias4, stage);
+}
+
 // ---------------------------------------------------------------------------------------- block epilogue
 // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
 // Each wave parks its WTM x WTN accumulator block in LDS (the operand buffers are dead by now) and walks it
@@ -504,17 +610,18 @@ __device__ __forceinline__ void block_epilogue(const TecmGemm& g, f32x16 (&acc)[
   const DropCtx odc = make_drop(g.out_drop);
   const bool split = gridDim.z > 1;
   float* stg = smem + wave * (WTM * STG_LD);
-  static_for<MT>([&](auto ic) {
-    constexpr int i = decltype(ic)::value;
-    static_for<16>([&](auto ec) {
-      constexpr int e = decltype(ec)::value;
-      static_for<NT>([&](auto jc) {
-        constexpr int jn = decltype(jc)::value;
-        stg[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * STG_LD + jn * 32 + r] = acc[i][jn][e];
+  auto stage_all = [&](auto) {
+    static_for<MT>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      static_for<16>([&](auto ec) {
+        constexpr int e = decltype(ec)::value;
+        static_for<NT>([&](auto jc) {
+          constexpr int jn = decltype(jc)::value;
+          stg[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * STG_LD + jn * 32 + r] = acc[i][jn][e];
+        });
       });
     });
-  });
-  __syncthreads();
+  };
   if (g.io_bf16 & TECM_P0_VEC4) {
     constexpr int LPR = WTN / 4;                       // lanes per row
     constexpr int RPI = 64 / LPR;                      // rows per iteration
@@ -522,6 +629,14 @@ __device__ __forceinline__ void block_epilogue(const TecmGemm& g, f32x16 (&acc)[
     const EpiCol ecol = epi_col(g, n0 + wn * WTN + lcol);
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (g.bias && ecol.ok) bias4 = *reinterpret_cast<const float4*>(g.bias + ecol.n);
+    const int fmode = epi_fast_mode(g);
+    if (fmode >= 0) {
+      // staging rows are private to the wave: no barrier (a __syncthreads here would also drain every store)
+      epi_fast_dispatch<1, WTM / RPI, RPI, STG_LD>(fmode, g, odc, stg, lrow, lcol, m0 + wm * WTM, ecol, bias4, stage_all);
+      return;
+    }
+    stage_all(0);
+    __syncthreads();
 #pragma unroll 1
     for (int it = 0; it < WTM / RPI; ++it) {
       const int rl = it * RPI + lrow;
@@ -537,6 +652,8 @@ __device__ __forceinline__ void block_epilogue(const TecmGemm& g, f32x16 (&acc)[
       }
     }
   } else {
+    stage_all(0);
+    __syncthreads();
     constexpr int RPI = 64 / WTN;                      // 1 (WTN = 64) or 2 (WTN = 32)
     const int lcol = lane % WTN, lrow = lane / WTN;
     const EpiCol ecol = epi_col(g, n0 + wn * WTN + lcol);

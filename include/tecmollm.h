@@ -33,7 +33,7 @@ extern "C" {
 #define TECM_E_LAUNCH (-3)     /* hipGetLastError() != hipSuccess after the launch       */
 #define TECM_E_LDS (-4)        /* problem does not fit the 160 KiB LDS budget            */
 
-#define TECM_ABI_VERSION 5
+#define TECM_ABI_VERSION 6
 int tecm_abi_version(void);
 /* Human-readable text for the last error on this thread (host pointer, never NULL). */
 const char* tecm_last_error(void);
@@ -183,17 +183,21 @@ int tecm_spatial_bwd_blocks(const TecmSpatial* d);
  * nn.GroupNorm(1, C) + nn.GELU() (modules.py:28-29) for the three parallel branches at once.
  * y/act: (B, L, N, CT) time-major with CT = 3*Cout (branch j owns channels [j*Cout,(j+1)*Cout)).
  * stats: (B*N, 3, 2) = mean, rstd per sequence and branch. */
-int tecm_groupnorm_gelu_fwd(const float* y, const float* gamma, const float* beta, float* act,
+/* io_bf16 (BASELINE configs[2] only, 0 otherwise): TECM_GN_OUT_BF16 -- act (forward) / dy (backward) is written as bf16:
+ * its only readers are bf16 matrix-core GEMMs that would round it in their loaders (train.py:68 autocast semantics).
+ * y, the statistics and all arithmetic stay fp32. */
+#define TECM_GN_OUT_BF16 2
+int tecm_groupnorm_gelu_fwd(const void* y, const float* gamma, const float* beta, void* act,
                             float* stats, int32_t B, int32_t L, int32_t N, int32_t Cout, float eps,
-                            void* stream);
+                            int32_t io_bf16, void* stream);
 /* dact is (B, L/dstride, N, CT): the gradient exists only at t % dstride == 0 (stride-s 1x1 conv).
  * dgb_partials: (num_blocks, 3*CT) per-block [dgamma | dbeta | column sums of dy] -- the last third is the
  * gradient of the Conv1d biases in front of the norm (modules.py:27), free here since dy is being written;
  * returns num_blocks via *num_blocks when dy == NULL (query mode, nothing launched). */
-int tecm_groupnorm_gelu_bwd(const float* dact, int32_t dstride, const float* y, const float* gamma,
-                            const float* beta, const float* stats, float* dy, float* dgb_partials,
+int tecm_groupnorm_gelu_bwd(const float* dact, int32_t dstride, const void* y, const float* gamma,
+                            const float* beta, const float* stats, void* dy, float* dgb_partials,
                             int32_t* num_blocks, int32_t B, int32_t L, int32_t N, int32_t Cout,
-                            void* stream);
+                            int32_t io_bf16, void* stream);
 
 /* ------------------------------------------------------------------ stage a-6 pieces
  * nn.LayerNorm(768, eps=1e-5) of GPT2Block / ln_f (modeling_gpt2.py:262-310, :620). */

@@ -140,12 +140,19 @@ static int gemm_entry(const TecmGemm* d, void* stream, int mode) {
   if (io) {
     TECM_REQUIRE(bf16, TECM_E_ARG, "tecm_gemm: bf16 tensors in HBM are served by tecm_gemm_bf16 only");
     if (io & (TECM_IO_A_BF16 | TECM_IO_B_BF16))
-      TECM_REQUIRE(g.a_layout == TECM_A_MK && g.b_layout == TECM_B_NK && !win && !drop && g.K % 8 == 0, TECM_E_ARG,
-                   "tecm_gemm_bf16: bf16 operands need the plain MK x NK contraction with K %% 8 == 0");
-    if (io & TECM_IO_A_BF16)
+      TECM_REQUIRE(!drop, TECM_E_ARG, "tecm_gemm_bf16: bf16 operands take no prologue dropout");
+    // a 16-byte vector of 8 bf16 runs along the operand's contiguous dimension: it must not straddle the end of that
+    // dimension or a window tap
+    if (io & TECM_IO_A_BF16) {
       TECM_REQUIRE(tecm_aligned(g.A, 16) && g.lda % 8 == 0, TECM_E_ALIGN, "tecm_gemm_bf16: bf16 A must be 16-byte friendly");
-    if (io & TECM_IO_B_BF16)
+      TECM_REQUIRE((g.a_layout == TECM_A_MK ? g.K : g.M) % 8 == 0 && (!g.a_win.enabled || g.a_win.Cw % 8 == 0), TECM_E_ARG,
+                   "tecm_gemm_bf16: bf16 A needs its contiguous extent (K for MK, M for KM) and a_win.Cw to be multiples of 8");
+    }
+    if (io & TECM_IO_B_BF16) {
       TECM_REQUIRE(tecm_aligned(g.B, 16) && g.ldb % 8 == 0, TECM_E_ALIGN, "tecm_gemm_bf16: bf16 B must be 16-byte friendly");
+      TECM_REQUIRE((g.b_layout == TECM_B_NK ? g.K : g.N) % 8 == 0 && (!g.b_win.enabled || g.b_win.Cw % 8 == 0), TECM_E_ARG,
+                   "tecm_gemm_bf16: bf16 B needs its contiguous extent (K for NK, N for KN) and b_win.Cw to be multiples of 8");
+    }
     if (io & TECM_IO_C_BF16)
       TECM_REQUIRE(vec4 && !g.residual && !g.accumulate && !g.c_win.enabled && g.split_k <= 1 &&
                        g.act != TECM_ACT_GELU_ERF,

@@ -400,6 +400,303 @@ struct HStager {
   }
 };
 
+// bf16 source, [row][k], with an optional temporal-window view of the rows (decided at run time): the A operand of
+// the strided 1x1 conv (gelu(GroupNorm(.)) written as bf16 by gn_gelu_fwd) and of the conv dX GEMMs (dy written as bf16
+// by gn_gelu_bwd).  Vectors of 8 bf16 never straddle a tap (host: Cw % 8 == 0).
+template <int ROWS>
+struct HStagerW {
+  static constexpr int VPR = BK / 8;
+  static constexpr int NV = ROWS * VPR / NTH;
+  static constexpr int RSTEP = NTH / VPR;
+  static constexpr int NITEMS = NV;
+  uint4 regs[NV];
+  const __bf16* ptr[NV];
+  WinRow wr[NV];
+  uint32_t okbits;
+  int32_t kk, tap, c;
+
+  __device__ __forceinline__ void init(const float* __restrict__ P, const TecmWin& w, int64_t ld, int64_t row0,
+                                       int64_t rows_total, int32_t kbeg, const DropCtx&) {
+    const __bf16* Ph = reinterpret_cast<const __bf16*>(P);
+    const int cv = (threadIdx.x % VPR) * 8;
+    const int r0 = threadIdx.x / VPR;
+    okbits = 0;
+    kk = kbeg + cv;
+    tap = 0;
+    c = 0;
+    if (!w.enabled) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        int64_t row = row0 + r0 + i * RSTEP;
+        row = row < rows_total ? row : rows_total - 1;  // clamped: feeds an accumulator row that is never stored
+        ptr[i] = Ph + row * ld + kbeg + cv;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) wr[i] = win_row(w, row0 + r0 + i * RSTEP, rows_total);
+      tap = kk / w.Cw;
+      c = kk - tap * w.Cw;
+    }
+  }
+  template <int IB, int IE>
+  __device__ __forceinline__ void load_part(const float* __restrict__ P, const TecmWin& w, int64_t ld, int32_t, int32_t klim,
+                                            const DropCtx&) {
+    if constexpr (IB >= IE) return;
+    const __bf16* Ph = reinterpret_cast<const __bf16*>(P);
+    const bool kok = kk < klim;                       // K % 8 == 0: a vector is entirely inside or outside
+    if (!w.enabled) {
+#pragma unroll
+      for (int i = IB; i < IE; ++i) {
+        regs[i] = *reinterpret_cast<const uint4*>(kok ? ptr[i] : Ph);
+        okbits = (okbits & ~(1u << i)) | ((kok ? 1u : 0u) << i);
+        ptr[i] += BK;
+      }
+      if constexpr (IE == NV) kk += BK;
+    } else {
+      const int64_t tapoff = (int64_t)tap * w.N;
+#pragma unroll
+      for (int i = IB; i < IE; ++i) {
+        const int32_t t_in = wr[i].t0 + tap;          // INVALID + tap stays hugely negative
+        const bool ok = kok && t_in >= 0 && t_in < w.Lin;
+        const int64_t row = wr[i].srow + tapoff;
+        regs[i] = *reinterpret_cast<const uint4*>(ok ? Ph + row * ld + c : Ph);
+        okbits = (okbits & ~(1u << i)) | ((ok ? 1u : 0u) << i);
+      }
+      if constexpr (IE == NV) {
+        kk += BK;
+        c += BK;
+        while (c >= w.Cw) { c -= w.Cw; ++tap; }
+      }
+    }
+  }
+  template <int IB, int IE>
+  __device__ __forceinline__ void load_steady(int64_t, const DropCtx&) {
+    if constexpr (IB >= IE) return;
+    if constexpr (IB == 0) okbits = ~0u;
+#pragma unroll
+    for (int i = IB; i < IE; ++i) {
+      regs[i] = *reinterpret_cast<const uint4*>(ptr[i]);
+      ptr[i] += BK;
+    }
+    if constexpr (IE == NV) kk += BK;
+  }
+  template <int IB, int IE>
+  __device__ __forceinline__ void store_part(__bf16* lds, const DropCtx&) {
+    if constexpr (IB >= IE) return;
+    const int cv = (threadIdx.x % VPR) * 8;
+    const int r0 = threadIdx.x / VPR;
+#pragma unroll
+    for (int i = IB; i < IE; ++i) {
+      const uint4 v = ((okbits >> i) & 1u) ? regs[i] : make_uint4(0u, 0u, 0u, 0u);
+      *reinterpret_cast<uint4*>(lds + (r0 + i * RSTEP) * LDH + cv) = v;
+    }
+  }
+  template <int IB, int IE>
+  __device__ __forceinline__ void store_steady(__bf16* lds, const DropCtx&) {
+    if constexpr (IB >= IE) return;
+    const int cv = (threadIdx.x % VPR) * 8;
+    const int r0 = threadIdx.x / VPR;
+#pragma unroll
+    for (int i = IB; i < IE; ++i) *reinterpret_cast<uint4*>(lds + (r0 + i * RSTEP) * LDH + cv) = regs[i];
+  }
+};
+
+// bf16 source whose contiguous dimension is the tile-row index ([k][m] / [k][n]: the weight-gradient forms -- dy
+// written as bf16 by gn_gelu_bwd is the A operand of the conv dW GEMMs, gelu(GroupNorm(.)) the windowed B operand of the
+// 1x1 conv's dW).  One item = k rows (2kp, 2kp+1) x 8 consecutive tile rows: two 16-byte loads, eight ds_write_b32 of
+// (k, k+1) pairs built with v_perm_b32.  Groups of 8 tile rows are entirely in or out (host: M resp. N % 8 == 0) and
+// never straddle a tap (Cw % 8 == 0).
+template <int ROWS>
+struct TStager16 {
+  static constexpr int QPR = ROWS / 8;                // row octets per k pair
+  static constexpr int NI = (BK / 2) * QPR / NTH;     // 2 (A, 256 rows) or 1 (B, 128 rows)
+  static constexpr int KSTEP = NTH / QPR;             // k pairs between a thread's items
+  static constexpr int NITEMS = NI;
+  uint4 lo[NI], hi[NI];
+  const __bf16* ptr[NI];
+  bool inner_ok;
+  uint32_t okbits;                                    // bit 2i: row 2kp valid, bit 2i+1: row 2kp+1 valid
+  int32_t tap, c, inner;
+  int32_t rn[NI], rt[NI], rb[NI];                     // window view: (n, t_out, b) of view row k0 + 2*(kp0 + i*KSTEP)
+
+  __device__ __forceinline__ void init(const float* __restrict__ P, const TecmWin& w, int64_t ld, int32_t kbeg,
+                                       int64_t fixed0, int64_t fixed_lim, const DropCtx&) {
+    const __bf16* Ph = reinterpret_cast<const __bf16*>(P);
+    const int q8 = (threadIdx.x % QPR) * 8;
+    const int kp0 = threadIdx.x / QPR;
+    inner = (int32_t)(fixed0 + q8);
+    inner_ok = inner < fixed_lim;
+    if (!inner_ok) inner = 0;                         // clamped octet (valid address, never stored); WIN: tap/c of column 0
+    okbits = 0;
+    tap = 0;
+    c = 0;
+    if (!w.enabled) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int64_t krow = (int64_t)kbeg + 2 * (kp0 + i * KSTEP);
+        ptr[i] = Ph + krow * ld + inner;
+      }
+    } else {
+      tap = inner / w.Cw;
+      c = inner - tap * w.Cw;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const uint32_t row = (uint32_t)(kbeg + 2 * (kp0 + i * KSTEP));
+        const uint32_t q = row / (uint32_t)w.N;
+        rn[i] = (int32_t)(row - q * (uint32_t)w.N);
+        rb[i] = (int32_t)(q / (uint32_t)w.Lout);
+        rt[i] = (int32_t)(q - (uint32_t)rb[i] * (uint32_t)w.Lout);
+      }
+    }
+  }
+  template <int IB, int IE>
+  __device__ __forceinline__ void load_part(const float* __restrict__ P, const TecmWin& w, int64_t ld, int32_t k0,
+                                            int32_t klim, const DropCtx&) {
+    if constexpr (IB >= IE) return;
+    const __bf16* Ph = reinterpret_cast<const __bf16*>(P);
+    const int kp0 = threadIdx.x / QPR;
+#pragma unroll
+    for (int i = IB; i < IE; ++i) {
+      const int32_t krow = k0 + 2 * (kp0 + i * KSTEP);
+      bool ok0, ok1;
+      if (!w.enabled) {
+        ok0 = inner_ok && krow < klim;
+        ok1 = inner_ok && krow + 1 < klim;
+        lo[i] = *reinterpret_cast<const uint4*>(ok0 ? ptr[i] : Ph);
+        hi[i] = *reinterpret_cast<const uint4*>(ok1 ? ptr[i] + ld : Ph);
+        ptr[i] += (int64_t)BK * ld;
+      } else {
+        int32_t n1 = rn[i] + 1, t1 = rt[i], b1 = rb[i];                    // row krow + 1
+        if (n1 >= w.N) { n1 = 0; if (++t1 >= w.Lout) { t1 = 0; ++b1; } }
+        const int32_t ta = rt[i] * w.stride_t - w.pad + tap, tb = t1 * w.stride_t - w.pad + tap;
+        ok0 = inner_ok && krow < klim && ta >= 0 && ta < w.Lin;
+        ok1 = inner_ok && krow + 1 < klim && tb >= 0 && tb < w.Lin;
+        const int64_t rowa = ((int64_t)rb[i] * w.Lin + ta) * (int64_t)w.N + rn[i];
+        const int64_t rowb = ((int64_t)b1 * w.Lin + tb) * (int64_t)w.N + n1;
+        lo[i] = *reinterpret_cast<const uint4*>(ok0 ? Ph + rowa * ld + c : Ph);
+        hi[i] = *reinterpret_cast<const uint4*>(ok1 ? Ph + rowb * ld + c : Ph);
+        rn[i] += BK;                                                        // next K-tile
+        while (rn[i] >= w.N) {
+          rn[i] -= w.N;
+          if (++rt[i] >= w.Lout) { rt[i] = 0; ++rb[i]; }
+        }
+      }
+      okbits = (okbits & ~(3u << (2 * i))) | ((ok0 ? 1u : 0u) << (2 * i)) | ((ok1 ? 1u : 0u) << (2 * i + 1));
+    }
+  }
+  template <int IB, int IE>
+  __device__ __forceinline__ void load_steady(int64_t ld, const DropCtx&) {
+    if constexpr (IB >= IE) return;
+    if constexpr (IB == 0) okbits = ~0u;
+#pragma unroll
+    for (int i = IB; i < IE; ++i) {
+      lo[i] = *reinterpret_cast<const uint4*>(ptr[i]);
+      hi[i] = *reinterpret_cast<const uint4*>(ptr[i] + ld);
+      ptr[i] += (int64_t)BK * ld;
+    }
+  }
+  __device__ __forceinline__ void put(__bf16* lds, int i, const uint4& a, const uint4& b) {
+    const int q8 = (threadIdx.x % QPR) * 8;
+    const int kp0 = threadIdx.x / QPR;
+    const int kcol = 2 * (kp0 + i * KSTEP);
+    uint32_t* base = reinterpret_cast<uint32_t*>(lds + q8 * LDH + kcol);
+    const uint32_t av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // tile rows 2j and 2j+1 of the octet: (k, k+1) = (low half of a, low half of b) / (high halves)
+      base[(2 * j) * (LDH / 2)] = __builtin_amdgcn_perm(bv[j], av[j], 0x05040100u);
+      base[(2 * j + 1) * (LDH / 2)] = __builtin_amdgcn_perm(bv[j], av[j], 0x07060302u);
+    }
+  }
+  template <int IB, int IE>
+  __device__ __forceinline__ void store_steady(__bf16* lds, const DropCtx&) {
+    if constexpr (IB >= IE) return;
+#pragma unroll
+    for (int i = IB; i < IE; ++i) put(lds, i, lo[i], hi[i]);
+  }
+  template <int IB, int IE>
+  __device__ __forceinline__ void store_part(__bf16* lds, const DropCtx&) {
+    if constexpr (IB >= IE) return;
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int i = IB; i < IE; ++i)
+      put(lds, i, ((okbits >> (2 * i)) & 1u) ? lo[i] : z, ((okbits >> (2 * i + 1)) & 1u) ? hi[i] : z);
+  }
+};
+
+// Plain (no window) bf16 [k][row] source, transposed in registers: one item = 8 k rows x 8 consecutive tile rows --
+// eight 16-byte loads (a wave covers 8 k rows x 128 contiguous bytes per instruction), an 8 x 8 transpose of 16-bit
+// elements with v_perm_b32, eight ds_write_b128 (one per tile row: lanes 0..7 of a group write the 128 contiguous
+// bytes of a row, conflict-free).  TStager16's (k, k+1)-pair writes put all 32 lanes of a ds_write_b32 on ONE bank
+// with this LDS pitch (row * 36 words, rows a multiple of 8 apart): the conv dW GEMMs ran 45 % slower with it than
+// from fp32.  The A operand of those GEMMs (dy, [k][m]) takes this stager.
+template <int ROWS>
+struct TStager8x8 {
+  static constexpr int OCT = ROWS / 8;                // row octets
+  static constexpr int KCH = BK / 8;                  // k chunks of 8
+  static_assert(OCT * KCH <= NTH, "one item per thread at most");
+  static constexpr int NITEMS = 8;                    // the 8 k rows of the item: the pipeline loads them in quarters
+  uint4 L[8];
+  const __bf16* ptr;
+  bool inner_ok, active;
+  uint32_t okbits;
+  int32_t krow0;
+
+  __device__ __forceinline__ void init(const float* __restrict__ P, const TecmWin&, int64_t ld, int32_t kbeg,
+                                       int64_t fixed0, int64_t fixed_lim, const DropCtx&) {
+    const __bf16* Ph = reinterpret_cast<const __bf16*>(P);
+    const int kc = threadIdx.x % KCH, oct = threadIdx.x / KCH;
+    active = oct < OCT;
+    const int64_t inner = fixed0 + oct * 8;
+    inner_ok = active && inner < fixed_lim;
+    krow0 = kbeg + kc * 8;
+    ptr = Ph + (int64_t)krow0 * ld + (inner_ok ? inner : 0);
+    okbits = 0;
+  }
+  template <int IB, int IE>
+  __device__ __forceinline__ void load_part(const float* __restrict__, const TecmWin&, int64_t ld, int32_t, int32_t klim,
+                                            const DropCtx&) {
+    if constexpr (IB >= IE) return;
+#pragma unroll
+    for (int j = IB; j < IE; ++j) {
+      const bool ok = inner_ok && (krow0 + j) < klim;
+      L[j] = ok ? *reinterpret_cast<const uint4*>(ptr + (int64_t)j * ld) : make_uint4(0u, 0u, 0u, 0u);
+      okbits = (okbits & ~(1u << j)) | ((ok ? 1u : 0u) << j);
+    }
+    if constexpr (IE == 8) { ptr += (int64_t)BK * ld; krow0 += BK; }
+  }
+  template <int IB, int IE>
+  __device__ __forceinline__ void load_steady(int64_t ld, const DropCtx&) {
+    if constexpr (IB >= IE) return;
+#pragma unroll
+    for (int j = IB; j < IE; ++j) L[j] = inner_ok ? *reinterpret_cast<const uint4*>(ptr + (int64_t)j * ld) : make_uint4(0u, 0u, 0u, 0u);
+    if constexpr (IE == 8) { ptr += (int64_t)BK * ld; krow0 += BK; okbits = inner_ok ? 0xffu : 0u; }
+  }
+  // the transpose needs all eight k rows: the whole item is stored with the FIRST part (the pipeline stores part s of
+  // tile t+1 before it loads part s of tile t+2, so every register still holds tile t+1 then)
+  template <int IB, int IE>
+  __device__ __forceinline__ void store_part(__bf16* lds, const DropCtx&) {
+    if constexpr (IB != 0 || IB >= IE) return;
+    if (!active) return;
+    const int kc = threadIdx.x % KCH, oct = threadIdx.x / KCH;
+    uint32_t w[8][4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { w[j][0] = L[j].x; w[j][1] = L[j].y; w[j][2] = L[j].z; w[j][3] = L[j].w; }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      uint4 o;
+      const uint32_t sel = (r & 1) ? 0x07060302u : 0x05040100u;   // high / low halves of (k+1 word, k word)
+      o.x = __builtin_amdgcn_perm(w[1][r >> 1], w[0][r >> 1], sel);
+      o.y = __builtin_amdgcn_perm(w[3][r >> 1], w[2][r >> 1], sel);
+      o.z = __builtin_amdgcn_perm(w[5][r >> 1], w[4][r >> 1], sel);
+      o.w = __builtin_amdgcn_perm(w[7][r >> 1], w[6][r >> 1], sel);
+      *reinterpret_cast<uint4*>(lds + (oct * 8 + r) * LDH + kc * 8) = o;
+    }
+  }
+  template <int IB, int IE>
+  __device__ __forceinline__ void store_steady(__bf16* lds, const DropCtx& dc) { store_part<IB, IE>(lds, dc); }
+};
+
 template <bool TRANS, int ROWS, bool WIN, bool DROP>
 struct StagerSel {
   using type = DStager<ROWS, WIN, DROP>;
@@ -495,14 +792,15 @@ __device__ __forceinline__ void block_epilogue16(const TecmGemm& g, f32x16 (&acc
 
 template <int ALAY, int BLAY, bool WIN, bool DROP, int ADT = 0, int BDT = 0>      // ADT / BDT: 1 = the operand is bf16 in HBM
 __global__ __launch_bounds__(NTH, 2) void gemm_bf16_kernel(const TecmGemm g, int tiles_m, int tiles_n, int k_chunk) {
-  static_assert((ADT == 0 && BDT == 0) || (!WIN && !DROP && ALAY == TECM_A_MK && BLAY == TECM_B_NK),
-                "bf16 sources: plain MK x NK only");
+  static_assert((ADT == 0 && BDT == 0) || !DROP, "bf16 sources: no prologue dropout");
   constexpr int WN = 2, WM = 4;
   constexpr int WTM = BM / WM, WTN = BN / WN;          // 64 x 64 per wave
   constexpr int MT = WTM / 32, NT = WTN / 32;
   constexpr bool ATR = ALAY == TECM_A_KM, BTR = BLAY == TECM_B_KN;
-  using AStager = std::conditional_t<ADT == 1, HStager<BM>, typename StagerSel<ATR, BM, WIN, DROP>::type>;
-  using BStager = std::conditional_t<BDT == 1, HStager<BN>, typename StagerSel<BTR, BN, WIN, DROP>::type>;
+  using AStager16 = std::conditional_t<ATR, TStager8x8<BM>, std::conditional_t<WIN, HStagerW<BM>, HStager<BM>>>;   // a_win needs MK: [k][m] A is plain
+  using BStager16 = std::conditional_t<BTR, TStager16<BN>, std::conditional_t<WIN, HStagerW<BN>, HStager<BN>>>;
+  using AStager = std::conditional_t<ADT == 1, AStager16, typename StagerSel<ATR, BM, WIN, DROP>::type>;
+  using BStager = std::conditional_t<BDT == 1, BStager16, typename StagerSel<BTR, BN, WIN, DROP>::type>;
   constexpr int A_ELEMS = BM * LDH, B_ELEMS = BN * LDH, TILE_ELEMS = A_ELEMS + B_ELEMS;   // bf16 elements
   constexpr int STG_LD = WTN + 4;
   constexpr int STG_BYTES = 8 * 32 * STG_LD * 4;       // one 32-row slab per wave, fp32

@@ -875,7 +875,18 @@ __global__ __launch_bounds__(threads_for(BN), (AVEC == 4 && BVEC == 4) ? (thread
     cur ^= 1;
   }
 
+#ifdef TECM_ABLATE_NOEPI                                 // diagnostics: K loop without the epilogue (tools/build_variant.py)
+  float keep = 0.f;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) keep += acc[i][j][e];
+  if (keep == 12345.678f) g.C[0] = keep;
+#else
   block_epilogue<MT, NT, WTM, WTN, STG_LD>(g, acc, smem, wave, lane, wm, wn, m0, n0);
+#endif
 }
 
 template <int ALAY, int BLAY, int AVEC, int BVEC, int BN, bool WIN, bool DROP, int BMT = BM>

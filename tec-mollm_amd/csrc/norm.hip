@@ -328,6 +328,24 @@ __global__ __launch_bounds__(256) void gn_gelu_bwd_kernel(const float* __restric
 //   <WPS 8, NPMAX 9>: twice the sequence length (L_in = 96), one 512-thread block per sequence
 //   <WPS 2, NPMAX 18>: forward only, short sequences whose quad count is not a multiple of 256
 
+// A quad of the (B, L, N, 3*Cout) conv tensors: fp32, or -- the kernels' OUTPUTS in bf16 mode (BASELINE configs[2]) --
+// bf16: act and dy only feed bf16 contractions, which would round them in their loaders.  The input y stays fp32: these
+// kernels are bound by requests in flight, not bytes, and 8-byte loads made them 20 % slower (measured).
+// Offsets are in elements.
+template <bool h16>
+__device__ __forceinline__ float4 gn_ld4(const void* p, int64_t off) {
+  if constexpr (h16) {
+    const tecm_bf16x4 v = *reinterpret_cast<const tecm_bf16x4*>(reinterpret_cast<const __bf16*>(p) + off);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+  }
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + off);
+}
+template <bool h16>
+__device__ __forceinline__ void gn_st4(void* p, int64_t off, const float4& v) {
+  if constexpr (h16) tecm_store_bf16x4(reinterpret_cast<__bf16*>(p) + off, v.x, v.y, v.z, v.w);
+  else *reinterpret_cast<float4*>(reinterpret_cast<float*>(p) + off) = v;
+}
+
 template <int CPB, int WPS>
 struct GnGeom {
   static constexpr int CT = 192 * CPB;
@@ -364,9 +382,9 @@ __device__ __forceinline__ void seq_reduce3(float (&v)[3], float (*xch)[3], int 
   }
 }
 
-template <int CPB, int WPS, int GN_NPMAX>
-__global__ __launch_bounds__((GnGeom<CPB, WPS>::NTHR)) void gn_gelu_fwd_reg(const float* __restrict__ y, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, float* __restrict__ act,
+template <int CPB, int WPS, int GN_NPMAX, bool IO16>
+__global__ __launch_bounds__((GnGeom<CPB, WPS>::NTHR)) void gn_gelu_fwd_reg(const void* __restrict__ y, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, void* __restrict__ act,
                                                        float* __restrict__ stats, int B, int L, int N, float eps, int NP) {
   using G = GnGeom<CPB, WPS>;
   __shared__ float xch[G::NTHR / 64][3];
@@ -394,14 +412,12 @@ __global__ __launch_bounds__((GnGeom<CPB, WPS>::NTHR)) void gn_gelu_fwd_reg(cons
   }
   float4 v[GN_NPMAX];
   int32_t off[GN_NPMAX];                                 // relative to the sequence base (host checks L*N*CT < 2^31)
-  const float* yb = y + base;
-  float* ab = act + base;
   {
     int t = l2 / G::QPR, q = l2 % G::QPR;
 #pragma unroll
     for (int i = 0; i < GN_NPMAX; ++i) {
       off[i] = t * (int32_t)tstride + q * 4;
-      if (i < NP) v[i] = *reinterpret_cast<const float4*>(yb + off[i]);
+      if (i < NP) v[i] = gn_ld4<false>(y, base + off[i]);      // y stays fp32: 8-byte loads make the kernel slower, not faster
       t += G::DT;
       q += G::DQ;
       if (q >= G::QPR) { q -= G::QPR; ++t; }
@@ -457,7 +473,7 @@ __global__ __launch_bounds__((GnGeom<CPB, WPS>::NTHR)) void gn_gelu_fwd_reg(cons
         o.y = gelu_erf_fast((v[i].y - ms[s_]) * rs[s_] * gm[s_].y + bt[s_].y);
         o.z = gelu_erf_fast((v[i].z - ms[s_]) * rs[s_] * gm[s_].z + bt[s_].z);
         o.w = gelu_erf_fast((v[i].w - ms[s_]) * rs[s_] * gm[s_].w + bt[s_].w);
-        *reinterpret_cast<float4*>(ab + off[i]) = o;
+        gn_st4<IO16>(act, base + off[i], o);
       }
     if (half == 0 && lane < 3) {
       stats[(sidx * 3 + lane) * 2] = sel3(lane, mean[0], mean[1], mean[2]);
@@ -466,11 +482,11 @@ __global__ __launch_bounds__((GnGeom<CPB, WPS>::NTHR)) void gn_gelu_fwd_reg(cons
   }
 }
 
-template <int CPB, int WPS, int GN_NPMAX>
+template <int CPB, int WPS, int GN_NPMAX, bool IO16>
 __global__ __launch_bounds__((GnGeom<CPB, WPS>::NTHR)) void gn_gelu_bwd_reg(const float* __restrict__ dact, int dstride, int L2,
-                                                       const float* __restrict__ y, const float* __restrict__ gamma,
+                                                       const void* __restrict__ y, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const float* __restrict__ stats,
-                                                       float* __restrict__ dy, float* __restrict__ partials, int B,
+                                                       void* __restrict__ dy, float* __restrict__ partials, int B,
                                                        int L, int N, int NP) {
   using G = GnGeom<CPB, WPS>;
   __shared__ float xch[G::NTHR / 64][3];
@@ -521,16 +537,14 @@ __global__ __launch_bounds__((GnGeom<CPB, WPS>::NTHR)) void gn_gelu_bwd_reg(cons
     }
     float4 yh[GN_NPMAX], gd[GN_NPMAX];                    // y (then y_hat) and dact (then d y_hat)
     int32_t off[GN_NPMAX];
-    const float* yb = y + ybase;
     const float* db = dact + dbase;
-    float* ob = dy + ybase;
     {
       int t = l2 / G::QPR, q = l2 % G::QPR;
 #pragma unroll
       for (int i = 0; i < GN_NPMAX; ++i) {
         off[i] = t * (int32_t)tstride + q * 4;
         if (i < NP) {
-          yh[i] = *reinterpret_cast<const float4*>(yb + off[i]);
+          yh[i] = gn_ld4<false>(y, ybase + off[i]);
           const bool has = (t % dstride) == 0;
           gd[i] = has ? *reinterpret_cast<const float4*>(db + (t / dstride) * (int32_t)tstride + q * 4)
                       : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -583,7 +597,7 @@ __global__ __launch_bounds__((GnGeom<CPB, WPS>::NTHR)) void gn_gelu_bwd_reg(cons
           o.y = rs[s_] * (gd[i].y - m1[s_] - yh[i].y * m2[s_]);
           o.z = rs[s_] * (gd[i].z - m1[s_] - yh[i].z * m2[s_]);
           o.w = rs[s_] * (gd[i].w - m1[s_] - yh[i].w * m2[s_]);
-          *reinterpret_cast<float4*>(ob + off[i]) = o;
+          gn_st4<IO16>(dy, ybase + off[i], o);
           dys[s_].x += o.x; dys[s_].y += o.y; dys[s_].z += o.z; dys[s_].w += o.w;   // conv-bias gradient
         }
     }
@@ -808,9 +822,13 @@ extern "C" int tecm_layernorm_bwd(const float* dy, int64_t lddy, const float* x,
   return TECM_OK;
 }
 
-extern "C" int tecm_groupnorm_gelu_fwd(const float* y, const float* gamma, const float* beta, float* act,
+extern "C" int tecm_groupnorm_gelu_fwd(const void* y_, const float* gamma, const float* beta, void* act_,
                                        float* stats, int32_t B, int32_t L, int32_t N, int32_t Cout, float eps,
-                                       void* stream) {
+                                       int32_t io_bf16, void* stream) {
+  const float* y = reinterpret_cast<const float*>(y_);
+  float* act = reinterpret_cast<float*>(act_);
+  TECM_REQUIRE(io_bf16 == 0 || io_bf16 == TECM_GN_OUT_BF16, TECM_E_ARG, "tecm_groupnorm_gelu_fwd: io_bf16 is 0 or TECM_GN_OUT_BF16");
+  const bool io16 = io_bf16 != 0;
   TECM_REQUIRE(y && gamma && beta && act && stats, TECM_E_ARG, "tecm_groupnorm_gelu_fwd: null pointer");
   TECM_REQUIRE(B > 0 && L > 0 && N > 0, TECM_E_ARG, "tecm_groupnorm_gelu_fwd: bad shape");
   TECM_REQUIRE(Cout == 64 || Cout == 128 || Cout == 256, TECM_E_ARG,
@@ -820,8 +838,14 @@ extern "C" int tecm_groupnorm_gelu_fwd(const float* y, const float* gamma, const
   hipStream_t st = (hipStream_t)stream;
   // register-resident paths: one HBM read of y, float4 accesses
 #define GN_FWD_REG(CPB, WPS, NPM, GRID) \
-  hipLaunchKernelGGL((gn_gelu_fwd_reg<CPB, WPS, NPM>), GRID, dim3(WPS > 4 ? 64 * WPS : 256), 0, st, y, gamma, beta, act, \
-                     stats, B, L, N, eps, np)
+  do {                                                                                                            \
+    if (io16)                                                                                                     \
+      hipLaunchKernelGGL((gn_gelu_fwd_reg<CPB, WPS, NPM, true>), GRID, dim3(WPS > 4 ? 64 * WPS : 256), 0, st, y_, gamma, \
+                         beta, act_, stats, B, L, N, eps, np);                                                    \
+    else                                                                                                          \
+      hipLaunchKernelGGL((gn_gelu_fwd_reg<CPB, WPS, NPM, false>), GRID, dim3(WPS > 4 ? 64 * WPS : 256), 0, st, y_, gamma, \
+                         beta, act_, stats, B, L, N, eps, np);                                                    \
+  } while (0)
   int np = gn_reg_pairs(L, N, Cout, 4, 9, y, act);
   if (np > 0) {
     const dim3 g4((unsigned)S);
@@ -850,6 +874,8 @@ extern "C" int tecm_groupnorm_gelu_fwd(const float* y, const float* gamma, const
     return TECM_OK;
   }
 #undef GN_FWD_REG
+  TECM_REQUIRE(!io16, TECM_E_ARG,
+               "tecm_groupnorm_gelu_fwd: bf16 tensors are served by the register-resident kernels only (L * Cout too large)");
   if (Cout == 64)
     hipLaunchKernelGGL((gn_gelu_fwd_kernel<1>), grid, dim3(256), 0, st, y, gamma, beta, act, stats, B, L, N, eps);
   else if (Cout == 128)
@@ -860,10 +886,14 @@ extern "C" int tecm_groupnorm_gelu_fwd(const float* y, const float* gamma, const
   return TECM_OK;
 }
 
-extern "C" int tecm_groupnorm_gelu_bwd(const float* dact, int32_t dstride, const float* y, const float* gamma,
-                                       const float* beta, const float* stats, float* dy, float* dgb_partials,
+extern "C" int tecm_groupnorm_gelu_bwd(const float* dact, int32_t dstride, const void* y_, const float* gamma,
+                                       const float* beta, const float* stats, void* dy_, float* dgb_partials,
                                        int32_t* num_blocks, int32_t B, int32_t L, int32_t N, int32_t Cout,
-                                       void* stream) {
+                                       int32_t io_bf16, void* stream) {
+  const float* y = reinterpret_cast<const float*>(y_);
+  float* dy = reinterpret_cast<float*>(dy_);
+  TECM_REQUIRE(io_bf16 == 0 || io_bf16 == TECM_GN_OUT_BF16, TECM_E_ARG, "tecm_groupnorm_gelu_bwd: io_bf16 is 0 or TECM_GN_OUT_BF16");
+  const bool io16 = io_bf16 != 0;
   TECM_REQUIRE(B > 0 && L > 0 && N > 0 && dstride > 0, TECM_E_ARG, "tecm_groupnorm_gelu_bwd: bad shape");
   TECM_REQUIRE(Cout == 64 || Cout == 128 || Cout == 256, TECM_E_ARG,
                "tecm_groupnorm_gelu_bwd: Cout must be 64, 128 or 256 (got %d)", Cout);
@@ -873,34 +903,40 @@ extern "C" int tecm_groupnorm_gelu_bwd(const float* dact, int32_t dstride, const
   TECM_REQUIRE(dact && y && gamma && beta && stats && dgb_partials, TECM_E_ARG, "tecm_groupnorm_gelu_bwd: null pointer");
   const int L2 = (L + dstride - 1) / dstride;
   hipStream_t st = (hipStream_t)stream;
+#define GN_BWD_REG(CPB, WPS, NT, NPV)                                                                              \
+  do {                                                                                                            \
+    if (io16)                                                                                                     \
+      hipLaunchKernelGGL((gn_gelu_bwd_reg<CPB, WPS, 9, true>), dim3(nb), dim3(NT), 0, st, dact, dstride, L2, y_, gamma, beta, \
+                         stats, dy_, dgb_partials, B, L, N, NPV);                                                 \
+    else                                                                                                          \
+      hipLaunchKernelGGL((gn_gelu_bwd_reg<CPB, WPS, 9, false>), dim3(nb), dim3(NT), 0, st, dact, dstride, L2, y_, gamma, beta, \
+                         stats, dy_, dgb_partials, B, L, N, NPV);                                                 \
+  } while (0)
   const int np = tecm_aligned(dact, 16) ? gn_reg_pairs(L, N, Cout, 4, 9, y, dy) : 0;
   if (np > 0) {
     if (Cout == 64)
-      hipLaunchKernelGGL((gn_gelu_bwd_reg<1, 4, 9>), dim3(nb), dim3(256), 0, st, dact, dstride, L2, y, gamma, beta, stats,
-                         dy, dgb_partials, B, L, N, np);
+      GN_BWD_REG(1, 4, 256, np);
     else if (Cout == 128)
-      hipLaunchKernelGGL((gn_gelu_bwd_reg<2, 4, 9>), dim3(nb), dim3(256), 0, st, dact, dstride, L2, y, gamma, beta, stats,
-                         dy, dgb_partials, B, L, N, np);
+      GN_BWD_REG(2, 4, 256, np);
     else
-      hipLaunchKernelGGL((gn_gelu_bwd_reg<4, 4, 9>), dim3(nb), dim3(256), 0, st, dact, dstride, L2, y, gamma, beta, stats,
-                         dy, dgb_partials, B, L, N, np);
+      GN_BWD_REG(4, 4, 256, np);
     TECM_CHECK_LAUNCH("tecm_groupnorm_gelu_bwd/reg");
     return TECM_OK;
   }
   const int np8 = tecm_aligned(dact, 16) ? gn_reg_pairs(L, N, Cout, 8, 9, y, dy) : 0;
   if (np8 > 0) {
     if (Cout == 64)
-      hipLaunchKernelGGL((gn_gelu_bwd_reg<1, 8, 9>), dim3(nb), dim3(512), 0, st, dact, dstride, L2, y, gamma, beta, stats,
-                         dy, dgb_partials, B, L, N, np8);
+      GN_BWD_REG(1, 8, 512, np8);
     else if (Cout == 128)
-      hipLaunchKernelGGL((gn_gelu_bwd_reg<2, 8, 9>), dim3(nb), dim3(512), 0, st, dact, dstride, L2, y, gamma, beta, stats,
-                         dy, dgb_partials, B, L, N, np8);
+      GN_BWD_REG(2, 8, 512, np8);
     else
-      hipLaunchKernelGGL((gn_gelu_bwd_reg<4, 8, 9>), dim3(nb), dim3(512), 0, st, dact, dstride, L2, y, gamma, beta, stats,
-                         dy, dgb_partials, B, L, N, np8);
+      GN_BWD_REG(4, 8, 512, np8);
     TECM_CHECK_LAUNCH("tecm_groupnorm_gelu_bwd/reg8");
     return TECM_OK;
   }
+#undef GN_BWD_REG
+  TECM_REQUIRE(!io16, TECM_E_ARG,
+               "tecm_groupnorm_gelu_bwd: bf16 tensors are served by the register-resident kernels only (L * Cout too large)");
   if (Cout == 64)
     hipLaunchKernelGGL((gn_gelu_bwd_kernel<1>), dim3(nb), dim3(256), 0, st, dact, dstride, L2, y, gamma, beta, stats,
                        dy, dgb_partials, B, L, N);

@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TECM_LIB", os.path.join(_HERE, "libtecmollm_hip.so"))   # override for experiments
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 c_f32p = C.c_void_p
 
@@ -122,10 +122,10 @@ EXPORTS = {
     "tecm_spatial_bwd": (C.c_int, [C.POINTER(TecmSpatial), C.POINTER(TecmSpatialGrads), C.c_void_p]),
     "tecm_spatial_bwd_blocks": (C.c_int, [C.POINTER(TecmSpatial)]),
     "tecm_groupnorm_gelu_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32,
-                                          C.c_int32, C.c_float, C.c_void_p]),
+                                          C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
     "tecm_groupnorm_gelu_bwd": (C.c_int, [c_f32p, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                           C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                                          C.c_void_p]),
+                                          C.c_int32, C.c_void_p]),
     "tecm_layernorm_fwd": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_void_p, C.c_int64,
                                      c_f32p, C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
     "tecm_layernorm_bwd": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p,

@@ -283,6 +283,11 @@ class ConvBlockFn(torch.autograd.Function):
         M = B * Lc * N
         ws = (w3, w5, w7)
         bs = (b3, b5, b7)
+        # bf16 mode: the activations behind the norm and (backward) dy live in HBM as bf16 -- they are only ever read by
+        # bf16 contractions, which would round them in their loaders (same bits, half the bytes).  The conv output y
+        # stays fp32 (the norm kernels got slower, not faster, reading 8-byte quads).
+        r16 = int(bf16) == ops.PREC_BF16 and Cout >= 64
+        adt = torch.bfloat16 if r16 else torch.float32
         y = _empty(B, Lc, N, CT, like=inp)
         packs = []
         for j, (w, b) in enumerate(zip(ws, bs)):
@@ -294,7 +299,7 @@ class ConvBlockFn(torch.autograd.Function):
                  a_win=win(N, Lc, Lc, 1, k, ld_in, (k - 1) // 2), bias=b, bf16=bf16)
         gamma = torch.cat([g3, g5, g7])
         beta = torch.cat([be3, be5, be7])
-        act = _empty(B, Lc, N, CT, like=inp)
+        act = torch.empty(B, Lc, N, CT, device=inp.device, dtype=adt)
         stats = _empty(B * N, 3, 2, like=inp)
         ops.groupnorm_gelu_fwd(y, gamma, beta, act, stats, B, Lc, N, Cout)
         Lo = (Lc - 1) // stride + 1
@@ -322,7 +327,7 @@ class ConvBlockFn(torch.autograd.Function):
         dact = _empty(B, Lo, N, CT, like=inp)
         gemm(Mo, CT, Cout, dout, Cout, wf2, CT, dact, CT, b_layout=B_KN, bf16=bf16)
         # GroupNorm + GELU
-        dy = _empty(B, Lc, N, CT, like=inp)
+        dy = torch.empty(B, Lc, N, CT, device=inp.device, dtype=act.dtype)
         dgamma, dbeta, dbconv = ops.groupnorm_gelu_bwd(dact, stride, y, gamma, beta, stats, dy, B, Lc, N, Cout)
         dinp = _empty(B, Lc, N, ld_in, like=inp) if need_dinp else None
         grads = []

@@ -41,7 +41,7 @@ NO_DROP = TecmDrop(0.0, 0, 0, 0)
 
 
 def _off(t: torch.Tensor, col_off: int = 0) -> int:
-    return t.data_ptr() + 4 * col_off
+    return t.data_ptr() + t.element_size() * col_off
 
 
 def gemm(M: int, N: int, K: int, A: torch.Tensor, lda: int, B: torch.Tensor, ldb: int, Cout: torch.Tensor, ldc: int,
@@ -68,8 +68,8 @@ def gemm(M: int, N: int, K: int, A: torch.Tensor, lda: int, B: torch.Tensor, ldb
     io = (IO_A_BF16 if A.dtype == torch.bfloat16 else 0) | (IO_B_BF16 if B.dtype == torch.bfloat16 else 0) | \
          (IO_C_BF16 if Cout.dtype == torch.bfloat16 else 0)
     if io:
-        if int(bf16) != PREC_BF16 or a_off or b_off or c_off:
-            raise _lib.TecmError("bf16 tensors are accepted by the bf16 GEMM only, without element offsets")
+        if int(bf16) != PREC_BF16:
+            raise _lib.TecmError("bf16 tensors are accepted by the bf16 GEMM only")
         g.io_bf16 = io
     g.A, g.lda, g.a_layout = _off(A, a_off), lda, a_layout
     g.B, g.ldb, g.b_layout = _off(B, b_off), ldb, b_layout
@@ -183,6 +183,8 @@ def _kernel_name(g: TecmGemm, use16: bool = False) -> str:
     if use16:
         win16 = "true" if (g.a_win.enabled or g.b_win.enabled) else "false"
         drp16 = "true" if (g.a_drop.p > 0 or g.b_drop.p > 0) else "false"
+        if (g.io_bf16 & (IO_A_BF16 | IO_B_BF16)) and not (g.a_layout == A_MK and g.b_layout == B_NK and win16 == "false"):
+            win16 = "true"                             # the bf16-resident window / transposed instances are built WIN = true
         both16 = (g.io_bf16 & IO_A_BF16) and (g.io_bf16 & IO_B_BF16)
         # mirrors tecm_gemm16_dma_try (csrc/gemm_bf16_dma.hip); the float4-epilogue condition holds for every bf16 call
         if (both16 and g.split_k <= 1 and g.N % 4 == 0 and g.K % 32 == 0 and g.K >= 64 and g.M >= 256 and g.N >= 128
@@ -282,10 +284,20 @@ def layernorm_bwd(dy: torch.Tensor, lddy: int, x: torch.Tensor, ldx: int, gamma:
     return dgb[0, :D], dgb[0, D:]
 
 
+GN_OUT_BF16 = 2
+
+
+def _gn_io(y: torch.Tensor, out: torch.Tensor) -> int:
+    if y.dtype != torch.float32:
+        raise _lib.TecmError("groupnorm_gelu: y is fp32 (only act / dy may be bf16)")
+    return GN_OUT_BF16 if out.dtype == torch.bfloat16 else 0
+
+
 def groupnorm_gelu_fwd(y: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, act: torch.Tensor,
                        stats: torch.Tensor, B: int, L: int, N: int, Cout: int, eps: float = 1e-5) -> None:
+    """act: fp32, or bf16 in bf16 mode (its dtype says which); y is fp32."""
     check(lib().tecm_groupnorm_gelu_fwd(y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), act.data_ptr(),
-                                        stats.data_ptr(), B, L, N, Cout, eps, stream_ptr()),
+                                        stats.data_ptr(), B, L, N, Cout, eps, _gn_io(y, act), stream_ptr()),
           "tecm_groupnorm_gelu_fwd")
 
 
@@ -295,12 +307,12 @@ def groupnorm_gelu_bwd(dact: torch.Tensor, dstride: int, y: torch.Tensor, gamma:
     """Returns (dgamma, dbeta, colsum(dy)), each (3*Cout,); the last is the conv-bias gradient."""
     nb = C.c_int32(0)
     check(lib().tecm_groupnorm_gelu_bwd(None, dstride, None, None, None, None, None, None, C.byref(nb), B, L, N, Cout,
-                                        None), "tecm_groupnorm_gelu_bwd(query)")
+                                        0, None), "tecm_groupnorm_gelu_bwd(query)")
     CT = 3 * Cout
     partials = torch.empty(nb.value, 3 * CT, device=dy.device, dtype=torch.float32)
     check(lib().tecm_groupnorm_gelu_bwd(dact.data_ptr(), dstride, y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                         stats.data_ptr(), dy.data_ptr(), partials.data_ptr(), C.byref(nb), B, L, N,
-                                        Cout, stream_ptr()), "tecm_groupnorm_gelu_bwd")
+                                        Cout, _gn_io(y, dy), stream_ptr()), "tecm_groupnorm_gelu_bwd")
     dgb = colsum(partials, 3 * CT, nb.value, 1, 1, 3 * CT)
     return dgb[0, :CT], dgb[0, CT:2 * CT], dgb[0, 2 * CT:]
 

@@ -172,3 +172,93 @@ def test_bf16_dma_kernel_matches_the_register_staged_kernel_bit_for_bit(dev, M, 
         assert torch.equal(g_, w_)
     ref = A16.double() @ B16.double().t()
     assert _rel(want[1], ref + bias.double()) < TOL
+
+
+@pytest.mark.parametrize("Bn,L,N,Cin,Cout,k", [(2, 48, 5, 24, 64, 3), (2, 24, 7, 64, 128, 7), (1, 48, 300, 24, 64, 5)])
+def test_bf16_resident_conv_block_operands_are_bit_identical(dev, Bn, L, N, Cin, Cout, k):
+    """bf16 mode keeps the conv-block tensors behind the GroupNorm in HBM as bf16 (ConvBlockFn): y written as bf16 by the
+    conv GEMM (column slice of the 3-branch buffer), act / dy read as bf16 through the window (HStagerW) and transposing
+    (TStager16) stagers.  Each form must equal the fp32-tensor form of the same call bit for bit: the loader would have
+    rounded the same values."""
+    from tecmollm import ops
+    CT, M, pad = 3 * Cout, Bn * L * N, (k - 1) // 2
+    x = _rand(Bn, L, N, Cin, dev=dev, seed=1)
+    w = _rand(Cout, Cin, k, dev=dev, seed=2, scale=0.2)
+    bias = _rand(Cout, dev=dev, seed=3)
+    fp, bp = ops.conv_weight_pack(w)
+    # conv forward into column slice 1 of a (.., 3*Cout) buffer: fp32 C vs bf16 C
+    y32 = torch.zeros(Bn, L, N, CT, device=dev)
+    y16 = torch.zeros(Bn, L, N, CT, device=dev, dtype=torch.bfloat16)
+    for y in (y32, y16):
+        ops.gemm(M, Cout, k * Cin, x, Cin, fp, k * Cin, y, CT, c_off=Cout, a_win=ops.win(N, L, L, 1, k, Cin, pad), bias=bias,
+                 bf16=True)
+    assert torch.equal(y16, y32.bfloat16())
+    # dX: A = dy through the window (+ column offset), accumulate into dx
+    dy32 = _rand(Bn, L, N, CT, dev=dev, seed=4).bfloat16().float()       # values that are exactly representable
+    dy16 = dy32.bfloat16()
+    outs = []
+    for dy in (dy32, dy16):
+        dx = torch.full((Bn, L, N, Cin), 0.5, device=dev)
+        ops.gemm(M, Cin, k * Cout, dy, CT, bp, Cin, dx, Cin, b_layout=ops.B_KN, a_off=Cout,
+                 a_win=ops.win(N, L, L, 1, k, Cout, pad), accumulate=True, bf16=True)
+        outs.append(dx)
+    if ops.uses_bf16(Cin, k * Cout, CT, Cin, ops.A_MK, ops.B_KN, Cout, 4):          # else the fp32 call ran the exact kernel
+        assert torch.equal(outs[0], outs[1])
+    gy = dy32[..., Cout:2 * Cout].double().permute(0, 2, 3, 1).reshape(Bn * N, Cout, L)
+    xs = _q(x).permute(0, 2, 3, 1).reshape(Bn * N, Cin, L)
+    gx = torch.nn.grad.conv1d_input(xs.shape, _q(w), gy, padding=pad).view(Bn, N, Cin, L).permute(0, 3, 1, 2)
+    assert _rel(outs[1], gx + 0.5) < TOL
+    # dW: A = dy [k][m] (+ column offset), B = x through the window, split-K
+    outs = []
+    for dy in (dy32, dy16):
+        dpack = torch.empty(Cout, k * Cin, device=dev)
+        ops.gemm(Cout, k * Cin, M, dy, CT, x, Cin, dpack, k * Cin, a_layout=ops.A_KM, b_layout=ops.B_KN, a_off=Cout,
+                 b_win=ops.win(N, L, L, 1, k, Cin, pad), split_k=3, bf16=True)
+        outs.append(dpack)
+    assert torch.equal(outs[0], outs[1])
+    gw = torch.nn.grad.conv1d_weight(xs, w.shape, gy, padding=pad)
+    assert _rel(ops.conv_weight_unpack(outs[1], Cout, Cin, k), gw) < TOL
+    # strided 1x1 conv: A = act through the stride-2 window; its dW: B = act [k][n] through the same window
+    Lo = (L - 1) // 2 + 1
+    a32 = _rand(Bn, L, N, CT, dev=dev, seed=5).bfloat16().float()
+    a16 = a32.bfloat16()
+    wf = _rand(Cout, CT, dev=dev, seed=6, scale=0.1)
+    dout = _rand(Bn, Lo, N, Cout, dev=dev, seed=7)
+    fo, wo = [], []
+    for a in (a32, a16):
+        out = torch.empty(Bn, Lo, N, Cout, device=dev)
+        ops.gemm(Bn * Lo * N, Cout, CT, a, CT, wf, CT, out, Cout, a_win=ops.win(N, L, Lo, 2, 1, CT, 0), bias=bias, bf16=True)
+        fo.append(out)
+        dwf = torch.empty(Cout, CT, device=dev)
+        ops.gemm(Cout, CT, Bn * Lo * N, dout, Cout, a, CT, dwf, CT, a_layout=ops.A_KM, b_layout=ops.B_KN,
+                 b_win=ops.win(N, L, Lo, 2, 1, CT, 0), split_k=2, bf16=True)
+        wo.append(dwf)
+    assert torch.equal(fo[0], fo[1]) and torch.equal(wo[0], wo[1])
+    ref = a32[:, ::2].double() @ _q(wf).t() + bias.double()
+    assert _rel(fo[1], ref) < TOL
+    refw = _q(dout).reshape(-1, Cout).t() @ a32[:, ::2].double().reshape(-1, CT)
+    assert _rel(wo[1], refw) < TOL
+
+
+@pytest.mark.parametrize("Bn,L,N,Cout,stride", [(2, 48, 5, 64, 2), (1, 24, 9, 128, 2), (1, 96, 3, 64, 2)])
+def test_groupnorm_gelu_bf16_outputs(dev, Bn, L, N, Cout, stride):
+    """act / dy written as bf16 == RNE of the fp32 outputs; statistics and parameter gradients unchanged."""
+    from tecmollm import ops
+    CT = 3 * Cout
+    y = _rand(Bn, L, N, CT, dev=dev, seed=1)
+    g, b = 1 + 0.1 * _rand(CT, dev=dev, seed=2), 0.1 * _rand(CT, dev=dev, seed=3)
+    act32, st32 = torch.empty_like(y), torch.empty(Bn * N, 3, 2, device=dev)
+    act16, st16 = torch.empty_like(y, dtype=torch.bfloat16), torch.empty(Bn * N, 3, 2, device=dev)
+    ops.groupnorm_gelu_fwd(y, g, b, act32, st32, Bn, L, N, Cout)
+    ops.groupnorm_gelu_fwd(y, g, b, act16, st16, Bn, L, N, Cout)
+    assert torch.equal(st16, st32) and torch.equal(act16, act32.bfloat16())
+    Lo = (L - 1) // stride + 1
+    dact = _rand(Bn, Lo, N, CT, dev=dev, seed=4)
+    dy32, dy16 = torch.empty_like(y), torch.empty_like(y, dtype=torch.bfloat16)
+    r32 = ops.groupnorm_gelu_bwd(dact, stride, y, g, b, st32, dy32, Bn, L, N, Cout)
+    r16 = ops.groupnorm_gelu_bwd(dact, stride, y, g, b, st16, dy16, Bn, L, N, Cout)
+    assert torch.equal(dy16, dy32.bfloat16())
+    for a_, b_ in zip(r16, r32):                          # block partials are combined with LDS atomics: order varies
+        assert _rel(a_, b_) < 1e-5
+    with pytest.raises(Exception):
+        ops.groupnorm_gelu_fwd(y.bfloat16(), g, b, act16, st16, Bn, L, N, Cout)

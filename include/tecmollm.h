@@ -223,7 +223,8 @@ int tecm_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ld
 /* ctx_bf16 != 0: ctx is a bf16 (B,T,N,D) tensor (its only reader, attn.c_proj, is a bf16 GEMM). */
 int tecm_attention_fwd(const float* qkv, void* ctx, int32_t ctx_bf16, int32_t B, int32_t T, int32_t N, int32_t heads,
                        int32_t D, const TecmDrop* prob_drop, void* stream);
-int tecm_attention_bwd(const float* qkv, const float* dctx, float* dqkv, int32_t B, int32_t T, int32_t N,
+/* dqkv_bf16 != 0: dqkv is a bf16 (B,T,N,3*D) tensor (its readers, the c_attn dX and the LoRA-B dW GEMMs, are bf16 GEMMs). */
+int tecm_attention_bwd(const float* qkv, const float* dctx, void* dqkv, int32_t dqkv_bf16, int32_t B, int32_t T, int32_t N,
                        int32_t heads, int32_t D, const TecmDrop* prob_drop, void* stream);
 
 /* ------------------------------------------------------------------ reductions / small ops

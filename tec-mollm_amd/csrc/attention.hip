@@ -116,8 +116,8 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restr
 //   dS_ij = P_ij (dP_ij - sum_k P_ik dP_ik);  dQ_i += dS_ij K_j / 8;  dK_j += dS_ij Q_i / 8.
 template <int TT>
 __device__ __forceinline__ void attention_bwd_body(const float* __restrict__ qkv, const float* __restrict__ dctx,
-                                                   float* __restrict__ dqkv, int B, int Trt, int N, int H, int D,
-                                                   DropA dr) {
+                                                   float* __restrict__ dqkv, int dqkv_bf16, int B, int Trt, int N, int H,
+                                                   int D, DropA dr) {
   const int T = TT > 0 ? TT : Trt;
   const int sub = threadIdx.x & 15;
   const int64_t item = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
@@ -180,26 +180,26 @@ __device__ __forceinline__ void attention_bwd_body(const float* __restrict__ qkv
   }
 #pragma unroll
   for (int p = 0; p < T; ++p) {
-    float* r = dqkv + (row0 + (int64_t)p * N) * ld + col;
-    *reinterpret_cast<float4*>(r) = dq[p];
-    *reinterpret_cast<float4*>(r + D) = dk[p];
-    *reinterpret_cast<float4*>(r + 2 * D) = dv[p];
+    const int64_t off = (row0 + (int64_t)p * N) * ld + col;       // dqkv: fp32, or bf16 for the two bf16 GEMMs behind it
+    store_ctx(dqkv, dqkv_bf16, off, dq[p]);
+    store_ctx(dqkv, dqkv_bf16, off + D, dk[p]);
+    store_ctx(dqkv, dqkv_bf16, off + 2 * D, dv[p]);
   }
 }
 
 template <int TT>
 __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restrict__ qkv,
                                                             const float* __restrict__ dctx, float* __restrict__ dqkv,
-                                                            int B, int Trt, int N, int H, int D, DropA dr) {
-  attention_bwd_body<TT>(qkv, dctx, dqkv, B, Trt, N, H, D, dr);
+                                                            int dqkv_bf16, int B, int Trt, int N, int H, int D, DropA dr) {
+  attention_bwd_body<TT>(qkv, dctx, dqkv, dqkv_bf16, B, Trt, N, H, D, dr);
 }
 // T = 8, 12: six float4[T] register arrays need more than 256 VGPRs -- one wave per SIMD, the whole 512-entry file
 template <int TT>
 __global__ __launch_bounds__(256, 1) void attention_bwd_kernel_wide(const float* __restrict__ qkv,
                                                                     const float* __restrict__ dctx,
-                                                                    float* __restrict__ dqkv, int B, int Trt, int N,
-                                                                    int H, int D, DropA dr) {
-  attention_bwd_body<TT>(qkv, dctx, dqkv, B, Trt, N, H, D, dr);
+                                                                    float* __restrict__ dqkv, int dqkv_bf16, int B, int Trt,
+                                                                    int N, int H, int D, DropA dr) {
+  attention_bwd_body<TT>(qkv, dctx, dqkv, dqkv_bf16, B, Trt, N, H, D, dr);
 }
 
 int check(const char* who, const void* a, const void* b, const void* c, int B, int T, int N, int heads, int D) {
@@ -247,8 +247,9 @@ extern "C" int tecm_attention_fwd(const float* qkv, void* ctxv, int32_t ctx_bf16
   return TECM_OK;
 }
 
-extern "C" int tecm_attention_bwd(const float* qkv, const float* dctx, float* dqkv, int32_t B, int32_t T, int32_t N,
-                                  int32_t heads, int32_t D, const TecmDrop* prob_drop, void* stream) {
+extern "C" int tecm_attention_bwd(const float* qkv, const float* dctx, void* dqkv_, int32_t dqkv_bf16, int32_t B, int32_t T,
+                                  int32_t N, int32_t heads, int32_t D, const TecmDrop* prob_drop, void* stream) {
+  float* dqkv = reinterpret_cast<float*>(dqkv_);
   const int rc = check("tecm_attention_bwd", qkv, dctx, dqkv, B, T, N, heads, D);
   if (rc) return rc;
   const int64_t items = (int64_t)B * N * heads;
@@ -256,7 +257,7 @@ extern "C" int tecm_attention_bwd(const float* qkv, const float* dctx, float* dq
   const DropA dr = make_dropa(prob_drop);
   hipStream_t st = (hipStream_t)stream;
 #define ATT_BWD(TT) \
-  hipLaunchKernelGGL((attention_bwd_kernel<TT>), grid, dim3(256), 0, st, qkv, dctx, dqkv, B, T, N, heads, D, dr)
+  hipLaunchKernelGGL((attention_bwd_kernel<TT>), grid, dim3(256), 0, st, qkv, dctx, dqkv, dqkv_bf16, B, T, N, heads, D, dr)
   switch (T) {
     case 1: ATT_BWD(1); break;
     case 2: ATT_BWD(2); break;
@@ -264,10 +265,12 @@ extern "C" int tecm_attention_bwd(const float* qkv, const float* dctx, float* dq
     case 4: ATT_BWD(4); break;
     case 6: ATT_BWD(6); break;
     case 8:
-      hipLaunchKernelGGL((attention_bwd_kernel_wide<8>), grid, dim3(256), 0, st, qkv, dctx, dqkv, B, T, N, heads, D, dr);
+      hipLaunchKernelGGL((attention_bwd_kernel_wide<8>), grid, dim3(256), 0, st, qkv, dctx, dqkv, dqkv_bf16, B, T, N, heads, D,
+                         dr);
       break;
     case 12:
-      hipLaunchKernelGGL((attention_bwd_kernel_wide<12>), grid, dim3(256), 0, st, qkv, dctx, dqkv, B, T, N, heads, D, dr);
+      hipLaunchKernelGGL((attention_bwd_kernel_wide<12>), grid, dim3(256), 0, st, qkv, dctx, dqkv, dqkv_bf16, B, T, N, heads, D,
+                         dr);
       break;
     default: ATT_BWD(0); break;
   }

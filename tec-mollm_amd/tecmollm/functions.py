@@ -323,7 +323,7 @@ class ConvBlockFn(torch.autograd.Function):
         dbf = colsum(dout, Cout, Mo, 1, 1, Cout)[0]
         dwf = _empty(Cout, CT, like=inp)
         gemm(Cout, CT, Mo, dout, Cout, act, CT, dwf, CT, a_layout=A_KM, b_layout=B_KN,
-             b_win=win(N, Lc, Lo, stride, 1, CT, 0), split_k=pick_split_k(Cout, CT, Mo), bf16=bf16)
+             b_win=win(N, Lc, Lo, stride, 1, CT, 0), split_k=pick_split_k(Cout, CT, Mo, prec=bf16), bf16=bf16)
         dact = _empty(B, Lo, N, CT, like=inp)
         gemm(Mo, CT, Cout, dout, Cout, wf2, CT, dact, CT, b_layout=B_KN, bf16=bf16)
         # GroupNorm + GELU
@@ -336,7 +336,7 @@ class ConvBlockFn(torch.autograd.Function):
             db = dbconv[j * Cout:(j + 1) * Cout]
             dpack = _empty(Cout, K, like=inp)
             gemm(Cout, K, M, dy, CT, inp, ld_in, dpack, K, a_layout=A_KM, b_layout=B_KN, a_off=j * Cout,
-                 b_win=win(N, Lc, Lc, 1, k, ld_in, (k - 1) // 2), split_k=pick_split_k(Cout, K, M), bf16=bf16)
+                 b_win=win(N, Lc, Lc, 1, k, ld_in, (k - 1) // 2), split_k=pick_split_k(Cout, K, M, prec=bf16), bf16=bf16)
             dw = ops.conv_weight_unpack(dpack, Cout, ld_in, k)
             if ld_in != cin:
                 dw = dw[:, :cin, :].contiguous()
@@ -389,7 +389,7 @@ class PatchEmbedFn(torch.autograd.Function):
             colsum(dh0, d_llm, B, N, P, d_llm, out=dwpe)                     # rows 0..P-1 of wpe
         dWp = _empty(d_llm, K, like=conv)
         gemm(d_llm, K, M, dh0, d_llm, conv, D, dWp, K, a_layout=A_KM, b_layout=B_KN, b_win=w,
-             split_k=pick_split_k(d_llm, K, M), bf16=plan.bf16)
+             split_k=pick_split_k(d_llm, K, M, prec=plan.bf16), bf16=plan.bf16)
         dconv = _empty(B, Lc, N, D, like=conv)
         if P * patch_len != Lc:
             dconv.zero_()
@@ -606,7 +606,10 @@ class GPT2StackFn(torch.autograd.Function):
             # attention: h2 = h + drop(ctx Wo + b)
             dcx = du2                                         # reuse buffer
             gemm(M, D, D, dh2m, D, _bwd_weight(Wo, plan.bf16), D, dcx, D, bf16=plan.bf16)
-            dqkv = _empty(M, F3, like=dh)
+            # dqkv is read by the c_attn dX GEMM ([row][k] A) and the LoRA-B dW GEMM ([k][m] A): bf16 when both run on the
+            # bf16 matrix cores against a bf16 copy of [W ; (alpha/r) B^T]
+            q16 = b16 and wcat.dtype == torch.bfloat16
+            dqkv = torch.empty(M, F3, device=dh.device, dtype=torch.bfloat16 if q16 else torch.float32)
             ops.attention_bwd(qkv, dcx, dqkv, B, T, N, GPT_HEADS, D, plan.spec(site_attn(i), 1))
             du = _empty(M, KE, like=dh)                       # [ d LN1-out (base path) | dz ]
             gemm(M, KE, F3, dqkv, F3, wcat, F3, du, KE, bf16=plan.bf16)
@@ -616,7 +619,7 @@ class GPT2StackFn(torch.autograd.Function):
                  alpha=LORA_SCALE, split_k=pick_split_k(F3, LORA_R, M), bf16=plan.bf16)
             dlA = _empty(LORA_R, D, like=dh)
             gemm(LORA_R, D, M, du, KE, u, KE, dlA, D, a_layout=A_KM, b_layout=B_KN, a_off=D, b_drop=lspec,
-                 split_k=pick_split_k(LORA_R, D, M), bf16=plan.bf16)
+                 split_k=pick_split_k(LORA_R, D, M, prec=plan.bf16), bf16=plan.bf16)
             # LoRA path back to LN1's output: du[:, :D] += mask * (dz A)
             gemm(M, D, LORA_R, du, KE, lA, D, du, KE, b_layout=B_KN, a_off=D, out_drop=lspec, accumulate=True, bf16=plan.bf16)
             dhn = _empty(M, D, like=dh)
@@ -672,14 +675,14 @@ class HeadFn(torch.autograd.Function):
         dpred = dpred.contiguous()
         db2 = colsum(dpred, Lo, S, 1, 1, Lo)[0]
         dW2 = _empty(Lo, Hd, like=hid)
-        gemm(Lo, Hd, S, dpred, Lo, h1, Hd, dW2, Hd, a_layout=A_KM, b_layout=B_KN, split_k=pick_split_k(Lo, Hd, S), bf16=plan.bf16)
+        gemm(Lo, Hd, S, dpred, Lo, h1, Hd, dW2, Hd, a_layout=A_KM, b_layout=B_KN, split_k=pick_split_k(Lo, Hd, S, prec=plan.bf16), bf16=plan.bf16)
         dpre = _empty(S, Hd, like=hid)
         gemm(S, Hd, Lo, dpred, Lo, W2, Hd, dpre, Hd, b_layout=B_KN, act=ACT_GELU_ERF, dact_src=(pre, Hd),
              out_drop=hspec, bf16=plan.bf16)
         db1 = colsum(dpre, Hd, S, 1, 1, Hd)[0]
         dW1 = _empty(Hd, K1, like=hid)
         gemm(Hd, K1, S, dpre, Hd, hid, D, dW1, K1, a_layout=A_KM, b_layout=B_KN, b_win=w,       # hid = dropout(hid) here
-             split_k=pick_split_k(Hd, K1, S), bf16=plan.bf16)
+             split_k=pick_split_k(Hd, K1, S, prec=plan.bf16), bf16=plan.bf16)
         dhid = _empty(B, T, N, D, like=hid)
         gemm(S, K1, Hd, dpre, Hd, W1, K1, dhid, D, b_layout=B_KN, c_win=w, out_drop=pspec, bf16=plan.bf16)
         return dhid, dW1, db1, dW2, db2, None

@@ -236,9 +236,15 @@ def summarize_gemm_timing(records: list) -> dict:
 
 
 def pick_split_k(Mo: int, No: int, K: int, target_blocks: int = 512, min_chunk: int = 512,
-                 max_splits: int = 256) -> int:
+                 max_splits: int = 256, prec: int = 0) -> int:
     """Split the (huge) reduction dim of a weight-gradient GEMM so the grid fills 256 CUs; capped because every
-    split costs one slab of partial sums that the reducer has to read back."""
+    split costs one slab of partial sums that the reducer has to read back.  The fp32 kernel has 128 x 128 tiles and
+    two blocks per CU; the bf16 kernel (prec = PREC_BF16 and at least 64 output columns) 256 x 128 tiles and ONE block
+    per CU, so its grid should be one round of at most 256 blocks, not 270."""
+    if int(prec) == PREC_BF16 and No >= BF16_MIN_N:
+        tiles = ((Mo + 255) // 256) * ((No + 127) // 128)
+        s = max(1, 256 // max(tiles, 1))
+        return int(min(s, max(1, K // min_chunk), max_splits))
     tiles = ((Mo + 127) // 128) * ((No + 127) // 128 if No > 64 else 1)
     s = max(1, target_blocks // max(tiles, 1))
     s = min(s, max(1, K // min_chunk), max_splits)
@@ -327,7 +333,8 @@ def attention_fwd(qkv: torch.Tensor, ctx: torch.Tensor, B: int, T: int, N: int, 
 def attention_bwd(qkv: torch.Tensor, dctx: torch.Tensor, dqkv: torch.Tensor, B: int, T: int, N: int, heads: int,
                   D: int, prob_drop: Optional[TecmDrop] = None) -> None:
     pd = prob_drop if prob_drop is not None else NO_DROP
-    check(lib().tecm_attention_bwd(qkv.data_ptr(), dctx.data_ptr(), dqkv.data_ptr(), B, T, N, heads, D, C.byref(pd),
+    check(lib().tecm_attention_bwd(qkv.data_ptr(), dctx.data_ptr(), dqkv.data_ptr(),
+                                   1 if dqkv.dtype == torch.bfloat16 else 0, B, T, N, heads, D, C.byref(pd),
                                    stream_ptr()), "tecm_attention_bwd")
 
 

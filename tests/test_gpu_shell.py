@@ -407,6 +407,44 @@ def test_bench_py_starts_its_own_ranks(dev):
     assert d["param_checksum_min_eq_max"] is True and line["value"] > 0
 
 
+def test_rccl_process_group_runs_on_this_gpu(dev):
+    """backend "nccl" IS RCCL on ROCm.  A one-GPU box cannot host two RCCL ranks, but it can run the exact calls the
+    N-rank path makes -- init_process_group("nccl", device_id=...), broadcast of the parameters, all-reduce of the
+    flat gradient buffer with its checksum tail -- in a 1-rank communicator, in a fresh process as bench.py's ranks are."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.path.join(ROOT, "tec-mollm_amd")); sys.path.insert(0, ROOT)
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+ones = torch.ones(1, device=dev); dist.all_reduce(ones)
+assert dist.get_backend() == "nccl" and float(ones.item()) == 1.0
+from oracle import ref_cpu as R
+from tests.parity import build_model
+from tecmollm.train import TrainStep, broadcast_parameters
+cfg = R.default_config(L_in=16, L_out=12, num_nodes=12, llm_layers=1)
+model = build_model(cfg, R.init_params(cfg, 0), dev, "per_timestep").train()
+assert broadcast_parameters(model, 0) > 0
+ts = TrainStep(model, lr=1e-3, accumulation_steps=1, world_size=1)
+x, tf, y = R.synthetic_batch(2, 16, 12, 6, 12)
+ei, _ = R.grid_graph(3, 4, threshold_km=170.0)
+ts.step(x.to(dev), tf.to(dev), ei.to(dev), None, y.to(dev))
+g = ts.flat_grad_ext.clone()
+before = g.clone(); dist.all_reduce(g); torch.cuda.synchronize()
+assert torch.equal(g, before)                         # SUM over one rank
+dist.destroy_process_group()
+print("RCCL_OK")
+""".replace("ROOT", repr(root))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
 # ------------------------------------------------------------------------------------ epoch loops
 def test_epoch_loops_train_and_validate_on_a_learnable_series(dev):
     """train_one_epoch / validate (train.py:52-168) over the device dataset: a smooth synthetic series is learnable,

@@ -283,7 +283,7 @@ def _ref_attention(qkv, Bn, T, N, H, D, keep=None):
     return (w @ v).permute(0, 3, 1, 2, 4).reshape(Bn, T, N, D)
 
 
-@pytest.mark.parametrize("T", [1, 3, 6, 5, 21])
+@pytest.mark.parametrize("T", [1, 3, 6, 5, 8, 12, 13, 21, 32])
 def test_attention_fwd_bwd(dev, T):
     from tecmollm import ops
     Bn, N, H, D = 2, 7, 12, 768
@@ -298,6 +298,9 @@ def test_attention_fwd_bwd(dev, T):
     ops.attention_bwd(qkv, dctx, dqkv, Bn, T, N, H, D)
     (g,) = torch.autograd.grad(ref, qd, dctx.double())
     assert _rel(dqkv, g) < TOL
+    dq16 = torch.empty_like(qkv, dtype=torch.bfloat16)                # bf16 mode's output form: RNE of the same values
+    ops.attention_bwd(qkv, dctx, dq16, Bn, T, N, H, D)
+    assert torch.equal(dq16, dqkv.bfloat16())
 
 
 def test_attention_dropout_mask_is_consistent(dev):

@@ -249,7 +249,9 @@ int tecm_conv_weight_pack(const float* w, float* fwd_pack, float* bwd_pack, int3
 int tecm_conv_weight_unpack(const float* dpack, float* dw, int32_t Cout, int32_t Cin, int32_t k,
                             void* stream);
 
-/* dst (bf16) [r][c] = round-to-nearest-even(src [r][c]) for a (rows, cols) block; cols % 4 == 0. */
+/* dst (bf16) [r][c] = round-to-nearest-even(src [r][c]) for a (rows, cols) block; cols % 4 == 0.  The cast torch.autocast
+ * inserts in front of a Linear / Conv1D input (reference train.py:68), done once for a tensor a bf16 GEMM will read (here:
+ * the 32 LoRA columns z = drop(LN1(h)) A^T, reference modules.py:177-186). */
 int tecm_cast_bf16(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int32_t cols, void* stream);
 
 /* dst[r][c] = src[r][c] * keep(seed, r*drop.ld + c) / (1 - p): the counter-based dropout mask every kernel of this

@@ -111,6 +111,63 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restr
   }
 }
 
+// Forward for 12 < T <= TM: k and v register-resident (2 x 24 float4), q_i loaded per query row; loops unrolled to TM
+// behind wave-uniform `i < T` guards (see attention_bwd_kernel_qstream).  The runtime-T path above re-reads k_j / v_j
+// from L1/L2 for every (i, j).
+template <int TM>
+__global__ __launch_bounds__(256) void attention_fwd_kernel_kv(const float* __restrict__ qkv, float* __restrict__ ctx,
+                                                               int ctx_bf16, int B, int T, int N, int H, int D, DropA dr) {
+  const int sub = threadIdx.x & 15;
+  const int64_t item = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int64_t items = (int64_t)B * N * H;
+  if (item >= items) return;
+  const int64_t seq = item / H;
+  const int h = (int)(item - seq * H);
+  const int b = (int)(seq / N), n = (int)(seq - (int64_t)b * N);
+  const int64_t ld = 3 * (int64_t)D;
+  const float scale = 0.125f;
+  const int64_t row0 = ((int64_t)b * T) * N + n;
+  const int col = h * 64 + sub * 4;
+  float4 k[TM], v[TM];
+#pragma unroll
+  for (int p = 0; p < TM; ++p) {
+    k[p] = v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p < T) {
+      const float* r = qkv + (row0 + (int64_t)p * N) * ld + col;
+      k[p] = *reinterpret_cast<const float4*>(r + D);
+      v[p] = *reinterpret_cast<const float4*>(r + 2 * D);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    if (i < T) {
+      const float4 qi = *reinterpret_cast<const float4*>(qkv + (row0 + (int64_t)i * N) * ld + col);
+      float s[TM];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int j = 0; j <= i; ++j) {
+        s[j] = group16_sum(dot4(qi, k[j])) * scale;
+        mx = fmaxf(mx, s[j]);
+      }
+      float den = 0.f;
+#pragma unroll
+      for (int j = 0; j <= i; ++j) {
+        s[j] = expf(s[j] - mx);
+        den += s[j];
+      }
+      const float inv = 1.0f / den;
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int j = 0; j <= i; ++j) {
+        float p = s[j] * inv;
+        if (dr.thresh) p *= tecm_drop_mult(dr.seed, (uint64_t)(((item * T + i) * T) + j), dr.thresh, dr.inv);
+        fma4(o, p, v[j]);
+      }
+      store_ctx(ctx, ctx_bf16, (row0 + (int64_t)i * N) * D + col, o);
+    }
+  }
+}
+
 // Backward: recompute the probabilities, then
 //   dP~_ij = <dctx_i, v_j>;  dV_j += P~_ij dctx_i;  dP_ij = dP~_ij * keep/(1-p);
 //   dS_ij = P_ij (dP_ij - sum_k P_ik dP_ik);  dQ_i += dS_ij K_j / 8;  dK_j += dS_ij Q_i / 8.
@@ -324,7 +381,13 @@ extern "C" int tecm_attention_fwd(const float* qkv, void* ctxv, int32_t ctx_bf16
     case 6: ATT_FWD(6); break;
     case 8: ATT_FWD(8); break;
     case 12: ATT_FWD(12); break;       // L_in = 192 with patch_len 4
-    default: ATT_FWD(0); break;        // runtime T <= 32 (L_in = 336 -> 21 tokens): k / v re-read from L1/L2
+    default:
+      if (T > 12 && T <= 24)             // L_in = 336 -> 21 tokens (the reference's default)
+        hipLaunchKernelGGL((attention_fwd_kernel_kv<24>), grid, dim3(256), 0, st, qkv, ctx, (int)ctx_bf16, B,
+                           T, N, heads, D, dr);
+      else
+        ATT_FWD(0);                      // runtime T <= 32: k / v re-read from L1/L2
+      break;
   }
 #undef ATT_FWD
   TECM_CHECK_LAUNCH("tecm_attention_fwd");

@@ -707,7 +707,7 @@ struct StagerSel<true, ROWS, WIN, DROP> {
 };
 
 // Epilogue shared by the bf16 kernels: identical to the fp32 kernel's, 32-row slabs per wave through LDS.
-template <int MT, int NT, int WTM, int WTN>
+template <int MT, int NT, int WTM, int WTN, bool NTS = false>      // NTS: non-temporal stores in the fast path
 __device__ __forceinline__ void block_epilogue16(const TecmGemm& g, f32x16 (&acc)[MT][NT], unsigned char* smem_raw, int wave,
                                                  int lane, int wm, int wn, int64_t m0, int64_t n0) {
   constexpr int STG_LD = WTN + 4;
@@ -734,7 +734,7 @@ __device__ __forceinline__ void block_epilogue16(const TecmGemm& g, f32x16 (&acc
     const EpiCol ecol = epi_col(g, n0 + wn * WTN + lcol);
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (g.bias && ecol.ok) bias4 = *reinterpret_cast<const float4*>(g.bias + ecol.n);
-    tecm_gemm::epi_fast_dispatch<MT, 32 / RPI, RPI, STG_LD>(fmode, g, odc, stg, lrow, lcol, m0 + wm * WTM, ecol, bias4,
+    tecm_gemm::epi_fast_dispatch<MT, 32 / RPI, RPI, STG_LD, NTS>(fmode, g, odc, stg, lrow, lcol, m0 + wm * WTM, ecol, bias4,
                                                              stage_slab);
     return;
   }
@@ -914,7 +914,8 @@ __global__ __launch_bounds__(NTH, 2) void gemm_bf16_kernel(const TecmGemm g, int
   for (; k0 + 3 * BK <= kend; k0 += BK) tile(k0, std::true_type{});
   for (; k0 < kend; k0 += BK) tile(k0, std::false_type{});
 
-  block_epilogue16<MT, NT, WTM, WTN>(g, acc, smem_raw, wave, lane, wm, wn, m0, n0);
+  // non-temporal stores (see gemm_bf16_dma.hip): +1 % on the whole bf16 step on top of the DMA kernel's own gain
+  block_epilogue16<MT, NT, WTM, WTN, true>(g, acc, smem_raw, wave, lane, wm, wn, m0, n0);
 }
 
 template <int ALAY, int BLAY, bool WIN, bool DROP, int ADT = 0, int BDT = 0>

@@ -39,6 +39,7 @@
 #endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // TecmGemm::io_bf16 as the kernels see it: the caller's bits 0..2 (TECM_IO_*) plus the host-computed epilogue flag
 #define TECM_P0_VEC4 0x100      /* every pointer / leading dimension the epilogue touches is 16-byte friendly */
@@ -515,7 +516,7 @@ __device__ __forceinline__ void epi_fast_load(const TecmGemm& g, int lrow, int64
     }
   }
 }
-template <int NIT, int RPI, int STG_LD, int MODE>
+template <int NIT, int RPI, int STG_LD, int MODE, bool NT>
 __device__ __forceinline__ void epi_fast_rows(const TecmGemm& g, const DropCtx& odc, const float* stg, int lrow, int lcol,
                                               int64_t mrow0, const EpiCol& ecol, const float4& bias4,
                                               const float4 (&in)[NIT]) {
@@ -533,7 +534,14 @@ __device__ __forceinline__ void epi_fast_rows(const TecmGemm& g, const DropCtx& 
       continue;
     }
     float o[4] = {v.x * g.alpha + bias4.x, v.y * g.alpha + bias4.y, v.z * g.alpha + bias4.z, v.w * g.alpha + bias4.w};
-    if (g.preact && row_ok) *reinterpret_cast<float4*>(g.preact + m * g.ldp + n) = make_float4(o[0], o[1], o[2], o[3]);
+    if (g.preact && row_ok) {
+      if constexpr (NT) {                              // streamed past L2: the operand panels stay (bf16 LDS-DMA kernel)
+        f32x4 nv = {o[0], o[1], o[2], o[3]};
+        __builtin_nontemporal_store(nv, reinterpret_cast<f32x4*>(g.preact + m * g.ldp + n));
+      } else {
+        *reinterpret_cast<float4*>(g.preact + m * g.ldp + n) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
     if constexpr (MODE == 2) {
       o[0] *= dgelu_tanh(in[it].x); o[1] *= dgelu_tanh(in[it].y);
       o[2] *= dgelu_tanh(in[it].z); o[3] *= dgelu_tanh(in[it].w);
@@ -553,15 +561,26 @@ __device__ __forceinline__ void epi_fast_rows(const TecmGemm& g, const DropCtx& 
     }
     if (row_ok) {
       const int64_t off = m * g.ldc + n;
-      if (c16) tecm_store_bf16x4(reinterpret_cast<__bf16*>(g.C) + off, o[0], o[1], o[2], o[3]);
-      else *reinterpret_cast<float4*>(g.C + off) = make_float4(o[0], o[1], o[2], o[3]);
+      if constexpr (NT) {
+        if (c16) {
+          tecm_bf16x4 hv;
+          hv[0] = (__bf16)o[0]; hv[1] = (__bf16)o[1]; hv[2] = (__bf16)o[2]; hv[3] = (__bf16)o[3];
+          __builtin_nontemporal_store(hv, reinterpret_cast<tecm_bf16x4*>(reinterpret_cast<__bf16*>(g.C) + off));
+        } else {
+          f32x4 nv = {o[0], o[1], o[2], o[3]};
+          __builtin_nontemporal_store(nv, reinterpret_cast<f32x4*>(g.C + off));
+        }
+      } else {
+        if (c16) tecm_store_bf16x4(reinterpret_cast<__bf16*>(g.C) + off, o[0], o[1], o[2], o[3]);
+        else *reinterpret_cast<float4*>(g.C + off) = make_float4(o[0], o[1], o[2], o[3]);
+      }
     }
   }
 }
 // One wave's staged block of SLABS x (NIT * RPI) rows: the input stream of slab s+1 is requested BEFORE the stores
 // of slab s are issued, so that waiting for it does not mean waiting for those stores (vmcnt retires in order).
 // stage(s) parks slab s of the accumulators in the wave's PRIVATE staging rows (no barrier: nobody else reads them).
-template <int SLABS, int NIT, int RPI, int STG_LD, int MODE, typename StageFn>
+template <int SLABS, int NIT, int RPI, int STG_LD, int MODE, bool NT, typename StageFn>
 __device__ __forceinline__ void epi_fast_block(const TecmGemm& g, const DropCtx& odc, const float* stg, int lrow, int lcol,
                                                int64_t mrow0, const EpiCol& ecol, const float4& bias4, StageFn&& stage) {
   float4 in[2][NIT];
@@ -571,7 +590,7 @@ __device__ __forceinline__ void epi_fast_block(const TecmGemm& g, const DropCtx&
     stage(sc);
     if constexpr (sl + 1 < SLABS)
       epi_fast_load<NIT, RPI, MODE>(g, lrow, mrow0 + (int64_t)(sl + 1) * NIT * RPI, ecol, in[(sl + 1) & 1]);
-    epi_fast_rows<NIT, RPI, STG_LD, MODE>(g, odc, stg, lrow, lcol, mrow0 + (int64_t)sl * NIT * RPI, ecol, bias4, in[sl & 1]);
+    epi_fast_rows<NIT, RPI, STG_LD, MODE, NT>(g, odc, stg, lrow, lcol, mrow0 + (int64_t)sl * NIT * RPI, ecol, bias4, in[sl & 1]);
   });
 }
 // which epilogues the straight-line form serves (everything else: the generic loop)
@@ -585,15 +604,15 @@ __device__ __forceinline__ int epi_fast_mode(const TecmGemm& g) {
   return g.residual ? 1 : (g.dact_src ? 2 : (g.accumulate ? 3 : 0));
 }
 // dispatch on the (wave-uniform) mode
-template <int SLABS, int NIT, int RPI, int STG_LD, typename StageFn>
+template <int SLABS, int NIT, int RPI, int STG_LD, bool NT = false, typename StageFn>
 __device__ __forceinline__ void epi_fast_dispatch(int mode, const TecmGemm& g, const DropCtx& odc, const float* stg, int lrow,
                                                   int lcol, int64_t mrow0, const EpiCol& ecol, const float4& bias4,
                                                   StageFn&& stage) {
-  if (mode == 0) epi_fast_block<SLABS, NIT, RPI, STG_LD, 0>(g, odc, stg, lrow, lcol, mrow0, ecol, bias4, stage);
-  else if (mode == 1) epi_fast_block<SLABS, NIT, RPI, STG_LD, 1>(g, odc, stg, lrow, lcol, mrow0, ecol, bias4, stage);
-  else if (mode == 2) epi_fast_block<SLABS, NIT, RPI, STG_LD, 2>(g, odc, stg, lrow, lcol, mrow0, ecol, bias4, stage);
-  else if (mode == 3) epi_fast_block<SLABS, NIT, RPI, STG_LD, 3>(g, odc, stg, lrow, lcol, mrow0, ecol, bias4, stage);
-  else epi_fast_block<SLABS, NIT, RPI, STG_LD, 4>(g, odc, stg, lrow, lcol, mrow0, ecol, bias4, stage);
+  if (mode == 0) epi_fast_block<SLABS, NIT, RPI, STG_LD, 0, NT>(g, odc, stg, lrow, lcol, mrow0, ecol, bias4, stage);
+  else if (mode == 1) epi_fast_block<SLABS, NIT, RPI, STG_LD, 1, NT>(g, odc, stg, lrow, lcol, mrow0, ecol, bias4, stage);
+  else if (mode == 2) epi_fast_block<SLABS, NIT, RPI, STG_LD, 2, NT>(g, odc, stg, lrow, lcol, mrow0, ecol, bias4, stage);
+  else if (mode == 3) epi_fast_block<SLABS, NIT, RPI, STG_LD, 3, NT>(g, odc, stg, lrow, lcol, mrow0, ecol, bias4, stage);
+  else epi_fast_block<SLABS, NIT, RPI, STG_LD, 4, NT>(g, odc, stg, lrow, lcol, mrow0, ecol, bias4, stage);
 }
 
 // ---------------------------------------------------------------------------------------- block epilogue

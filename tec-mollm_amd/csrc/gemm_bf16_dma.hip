@@ -59,7 +59,7 @@ __global__ __launch_bounds__(DNTH, 1) void gemm_bf16_dma_kernel(const TecmGemm g
   const int xcd = id & 7, local = id >> 3;
   const int q8 = nwg >> 3, r8 = nwg & 7;
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
-  constexpr int GROUP_M = 4;
+  const int GROUP_M = g._p1 > 0 ? g._p1 : 4;              // m-tiles per L2 super-tile (ops.GROUP_M sweeps it)
   const int per_group = GROUP_M * tiles_n;
   const int group = wg / per_group;
   const int first_m = group * GROUP_M;

@@ -69,12 +69,14 @@ class Multi_Scale_Conv_Block(nn.Module):
                           nn.GroupNorm(1, out_channels), nn.GELU()) for k in kernel_sizes])
         self.final_conv = nn.Conv1d(out_channels * len(kernel_sizes), out_channels, kernel_size=1, stride=stride)
 
-    def forward_tm(self, inp: torch.Tensor, cin: int, need_dinp: bool = True, bf16: bool = False) -> torch.Tensor:
-        """inp (B, Lc, N, ld) time-major with `cin` real channels -> (B, Lc/stride, N, Cout)."""
+    def forward_tm(self, inp: torch.Tensor, cin: int, need_dinp: bool = True, bf16: bool = False,
+                   inp16: Optional[torch.Tensor] = None):
+        """inp (B, Lc, N, ld) time-major with `cin` real channels -> (out (B, Lc/stride, N, Cout), out16): out16 is a
+        bf16 copy of out in bf16 mode (None otherwise) for the window GEMMs of the next stage; inp16 likewise."""
         args = []
         for seq in self.convs:
             args += [seq[0].weight, seq[0].bias, seq[1].weight, seq[1].bias]
-        return F_.ConvBlockFn.apply(inp, cin, self.stride, need_dinp, bf16, *args, self.final_conv.weight,
+        return F_.ConvBlockFn.apply(inp, inp16, cin, self.stride, need_dinp, bf16, *args, self.final_conv.weight,
                                     self.final_conv.bias)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -82,7 +84,7 @@ class Multi_Scale_Conv_Block(nn.Module):
         _need_cuda(x, "x")
         S, Cc, L = x.shape
         tm = x.permute(0, 2, 1).contiguous().view(S, L, 1, Cc)
-        out = self.forward_tm(tm, Cc, bf16=autocast_bf16())
+        out, _ = self.forward_tm(tm, Cc, bf16=autocast_bf16())
         return out.view(S, out.shape[1], self.out_channels).permute(0, 2, 1)
 
 
@@ -99,11 +101,12 @@ class MultiScaleConvEmbedder(nn.Module):
             cur = out_channels
         self.embedder = nn.Sequential(*layers)
 
-    def forward_tm(self, inp: torch.Tensor, cin: int, need_dinp: bool = True, bf16: bool = False) -> torch.Tensor:
+    def forward_tm(self, inp: torch.Tensor, cin: int, need_dinp: bool = True, bf16: bool = False):
+        inp16 = None
         for i, blk in enumerate(self.embedder):
-            inp = blk.forward_tm(inp, cin, need_dinp or i > 0, bf16)
+            inp, inp16 = blk.forward_tm(inp, cin, need_dinp or i > 0, bf16, inp16)
             cin = blk.out_channels
-        return inp
+        return inp, inp16
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         for blk in self.embedder:
@@ -119,8 +122,9 @@ class LatentPatchingProjection(nn.Module):
         self.patch_len = patch_len
         self.projection = nn.Linear(patch_len * latent_dim, d_llm)
 
-    def forward_tm(self, conv: torch.Tensor, wpe: Optional[torch.Tensor], plan: F_.DropPlan) -> torch.Tensor:
-        return F_.PatchEmbedFn.apply(conv, self.projection.weight, self.projection.bias, wpe, self.patch_len, plan)
+    def forward_tm(self, conv: torch.Tensor, wpe: Optional[torch.Tensor], plan: F_.DropPlan,
+                   conv16: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return F_.PatchEmbedFn.apply(conv, conv16, self.projection.weight, self.projection.bias, wpe, self.patch_len, plan)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """Reference signature: x (S, L, D_latent) -> (S, num_patches, d_llm)."""
@@ -140,7 +144,8 @@ class TemporalEncoder(nn.Module):
         self.patcher = LatentPatchingProjection(channel_list[-1], patch_len, d_llm)
 
     def forward_tm(self, inp, cin, wpe, plan, need_dinp=True):
-        return self.patcher.forward_tm(self.conv_embedder.forward_tm(inp, cin, need_dinp, plan.bf16), wpe, plan)
+        conv, conv16 = self.conv_embedder.forward_tm(inp, cin, need_dinp, plan.bf16)
+        return self.patcher.forward_tm(conv, wpe, plan, conv16)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """Reference signature: x (S, L_in, C_in) -> (S, num_patches, d_llm).  A sequence-major (S, L, C)

@@ -275,8 +275,10 @@ class ConvBlockFn(torch.autograd.Function):
     (ld_in - cin zero pad channels); returns (B, Lc//stride, N, Cout)."""
 
     @staticmethod
-    def forward(ctx, inp, cin: int, stride: int, need_dinp: bool, bf16: bool,
+    def forward(ctx, inp, inp16, cin: int, stride: int, need_dinp: bool, bf16: bool,
                 w3, b3, g3, be3, w5, b5, g5, be5, w7, b7, g7, be7, wf, bf):
+        """inp16: optional bf16 copy of inp (bf16 mode: written by the producing block's last GEMM next to its fp32 output;
+        only the forward window GEMMs read it).  Returns (out, out16): out16 is that copy of this block's output, or None."""
         B, Lc, N, ld_in = inp.shape
         Cout = w3.shape[0]
         CT = 3 * Cout
@@ -288,6 +290,7 @@ class ConvBlockFn(torch.autograd.Function):
         # stays fp32 (the norm kernels got slower, not faster, reading 8-byte quads).
         r16 = int(bf16) == ops.PREC_BF16 and Cout >= 64
         adt = torch.bfloat16 if r16 else torch.float32
+        side16 = r16
         y = _empty(B, Lc, N, CT, like=inp)
         packs = []
         for j, (w, b) in enumerate(zip(ws, bs)):
@@ -295,7 +298,8 @@ class ConvBlockFn(torch.autograd.Function):
             wp = w if ld_in == cin else torch.nn.functional.pad(w, (0, 0, 0, ld_in - cin))
             fp, bp = ops.conv_weight_pack(wp.contiguous(), want_bwd=True)
             packs.append(bp)
-            gemm(M, Cout, k * ld_in, inp, ld_in, fp, k * ld_in, y, CT, c_off=j * Cout,
+            a_in = inp16 if (inp16 is not None and side16 and ld_in % 8 == 0) else inp
+            gemm(M, Cout, k * ld_in, a_in, ld_in, fp, k * ld_in, y, CT, c_off=j * Cout,
                  a_win=win(N, Lc, Lc, 1, k, ld_in, (k - 1) // 2), bias=b, bf16=bf16)
         gamma = torch.cat([g3, g5, g7])
         beta = torch.cat([be3, be5, be7])
@@ -305,13 +309,22 @@ class ConvBlockFn(torch.autograd.Function):
         Lo = (Lc - 1) // stride + 1
         out = _empty(B, Lo, N, Cout, like=inp)
         wf2 = wf.view(Cout, CT)
-        gemm(B * Lo * N, Cout, CT, act, CT, wf2, CT, out, Cout, a_win=win(N, Lc, Lo, stride, 1, CT, 0), bias=bf, bf16=bf16)
+        out16 = None
+        if side16:
+            # one epilogue, two forms of the same values: the fp32 tensor autograd sees (written through the epilogue's
+            # pre-activation store; there is no activation here) and a bf16 copy for the window GEMMs that read it next
+            out16 = torch.empty(B, Lo, N, Cout, device=inp.device, dtype=torch.bfloat16)
+            gemm(B * Lo * N, Cout, CT, act, CT, wf2, CT, out16, Cout, a_win=win(N, Lc, Lo, stride, 1, CT, 0), bias=bf,
+                 preact=(out, Cout), bf16=bf16)
+            ctx.mark_non_differentiable(out16)
+        else:
+            gemm(B * Lo * N, Cout, CT, act, CT, wf2, CT, out, Cout, a_win=win(N, Lc, Lo, stride, 1, CT, 0), bias=bf, bf16=bf16)
         ctx.save_for_backward(inp, y, act, stats, gamma, beta, wf, *packs)
         ctx.dims = (B, Lc, N, ld_in, cin, Cout, stride, Lo, need_dinp, bf16)
-        return out
+        return out, out16
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, _dout16=None):
         inp, y, act, stats, gamma, beta, wf, bp3, bp5, bp7 = ctx.saved_tensors
         B, Lc, N, ld_in, cin, Cout, stride, Lo, need_dinp, bf16 = ctx.dims
         CT = 3 * Cout
@@ -344,7 +357,7 @@ class ConvBlockFn(torch.autograd.Function):
                 gemm(M, ld_in, k * Cout, dy, CT, bp, ld_in, dinp, ld_in, b_layout=B_KN, a_off=j * Cout,
                      a_win=win(N, Lc, Lc, 1, k, Cout, (k - 1) // 2), accumulate=(j > 0), bf16=bf16)
             grads += [dw, db, dgamma[j * Cout:(j + 1) * Cout], dbeta[j * Cout:(j + 1) * Cout]]
-        return (dinp, None, None, None, None, *grads, dwf.view_as(wf), dbf)
+        return (dinp, None, None, None, None, None, *grads, dwf.view_as(wf), dbf)
 
 
 # ============================================================================ stage a-5 (+ wpe / embd dropout of a-6)
@@ -353,7 +366,8 @@ class PatchEmbedFn(torch.autograd.Function):
     (modeling_gpt2.py:576-604).  conv (B, Lc, N, D) -> tokens (B, P, N, d_llm), P = Lc // patch_len."""
 
     @staticmethod
-    def forward(ctx, conv, Wp, bp, wpe, patch_len: int, plan: DropPlan):
+    def forward(ctx, conv, conv16, Wp, bp, wpe, patch_len: int, plan: DropPlan):
+        """conv16: optional bf16 copy of conv (bf16 mode; the forward GEMM reads it instead)."""
         B, Lc, N, D = conv.shape
         P = Lc // patch_len
         d_llm = Wp.shape[0]
@@ -362,7 +376,8 @@ class PatchEmbedFn(torch.autograd.Function):
         h0 = _empty(B, P, N, d_llm, like=conv)
         w = win(N, Lc, P, patch_len, patch_len, D, 0)
         dspec = plan.spec(SITE_EMBD, d_llm) if wpe is not None else None
-        gemm(M, d_llm, K, conv, D, Wp, K, h0, d_llm, a_win=w, bias=bp,
+        a_in = conv16 if (conv16 is not None and int(plan.bf16) == ops.PREC_BF16 and D % 8 == 0) else conv
+        gemm(M, d_llm, K, a_in, D, Wp, K, h0, d_llm, a_win=w, bias=bp,
              rowbias=(wpe, wpe.shape[1], N, P) if wpe is not None else None, out_drop=dspec, bf16=plan.bf16)
         ctx.save_for_backward(conv, Wp, wpe if wpe is not None else Wp)
         ctx.meta = (B, Lc, N, D, P, d_llm, patch_len, wpe is not None, dspec)
@@ -394,7 +409,7 @@ class PatchEmbedFn(torch.autograd.Function):
         if P * patch_len != Lc:
             dconv.zero_()
         gemm(M, K, d_llm, dh0, d_llm, Wp, K, dconv, D, b_layout=B_KN, c_win=w, bf16=plan.bf16)
-        return dconv, dWp, dbp, dwpe, None, None
+        return dconv, None, dWp, dbp, dwpe, None, None
 
 
 # ============================================================================ stage a-6

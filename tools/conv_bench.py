@@ -22,7 +22,7 @@ for ld_in, cin, Cout, L in blocks:
     for it in range(3):
         if it == 2:
             rec = ops.enable_gemm_timing(detail=True)
-        out = blk.forward_tm(inp, cin, True, prec)
+        out, _ = blk.forward_tm(inp, cin, True, prec)
         out.backward(torch.randn_like(out))
     torch.cuda.synchronize()
     agg = collections.OrderedDict()

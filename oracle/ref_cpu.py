@@ -136,7 +136,7 @@ def spatial(h: torch.Tensor, edge_index: torch.Tensor, p: Params, heads: int,
     return xg + gat
 
 
-# ------------------------------------------------------------------- stage a-4/a-5
+# ------------------------------------------------------------------- precision emulation (BASELINE configs[2])
 def bf16_round(t: torch.Tensor) -> torch.Tensor:
     """Round to bf16 (RNE) and back: what the bf16 MFMA path does to GEMM operands (autocast semantics)."""
     return t.bfloat16().float()
@@ -146,21 +146,107 @@ def _ident(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
-def conv_block(x: torch.Tensor, p: Params, idx: int, stride: int, q=_ident) -> torch.Tensor:
+class Rounding:
+    """Operand rounding of the dense contractions as a PAIR: `fwd` is applied to both operands of a forward
+    contraction, `bwd` to both operands of the two contractions its backward consists of (dX = dY.W^T and
+    dW = X^T.dY).  Accumulation, bias, activation, dropout, norms, softmax and the GATv2 stage are fp32 in every mode.
+    FP32 = the reference's CPU arithmetic.  BF16 = what `torch.autocast('cuda', bfloat16)` (train.py:68) does to the
+    operands of Linear / Conv1d / matmul, forward AND backward, as the MI355X bf16 mode implements it: fp32 outputs,
+    bf16 operands.  A tensor the HIP path stores in HBM as bf16 (LN outputs, attention context, gelu(c_fc), conv
+    activations; in the backward dqkv, d gelu-input, the dropout-masked LayerNorm-backward outputs, the conv dy) is a
+    tensor whose readers are bf16 contractions only, so rounding at the store and rounding in the reader are the same
+    arithmetic -- with the exceptions written next to the call sites below (`dx=` / `dw=` flags)."""
+
+    def __init__(self, fwd=None, bwd=None, name="fp32"):
+        self.fwd, self.bwd, self.name = fwd, bwd, name
+
+    def __repr__(self):
+        return f"Rounding({self.name})"
+
+
+FP32 = Rounding(None, None, "fp32")
+BF16 = Rounding(bf16_round, bf16_round, "bf16")
+BF16_FORWARD_ONLY = Rounding(bf16_round, None, "bf16-forward-only")   # forward emulation with an exact backward
+
+
+def _r(fn, t):
+    return t if fn is None else fn(t)
+
+
+class _MatMul(torch.autograd.Function):
+    """y = a @ b with a (..., K), b (K, N): the three contractions of a Linear, each with its own operand rounding."""
+
+    @staticmethod
+    def forward(ctx, a, b, rf, rdx, rdw):
+        ctx.save_for_backward(a, b)
+        ctx.r = (rdx, rdw)
+        return _r(rf, a) @ _r(rf, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        rdx, rdw = ctx.r
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            da = _r(rdx, g) @ _r(rdx, b).t()
+        if ctx.needs_input_grad[1]:
+            a2 = _r(rdw, a).reshape(-1, a.shape[-1])
+            db = a2.t() @ _r(rdw, g).reshape(-1, g.shape[-1])
+        return da, db, None, None, None
+
+
+class _Conv1d(torch.autograd.Function):
+    """F.conv1d without bias, the same three-way operand rounding (the HIP path runs it as a window-view GEMM)."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, padding, rf, rdx, rdw):
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, padding, rdx, rdw)
+        return F.conv1d(_r(rf, x), _r(rf, w), None, stride=stride, padding=padding)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        stride, padding, rdx, rdw = ctx.cfg
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.nn.grad.conv1d_input(x.shape, _r(rdx, w), _r(rdx, g), stride=stride, padding=padding)
+        if ctx.needs_input_grad[1]:
+            dw = torch.nn.grad.conv1d_weight(_r(rdw, x), w.shape, _r(rdw, g), stride=stride, padding=padding)
+        return dx, dw, None, None, None, None, None
+
+
+def mm(a: torch.Tensor, b: torch.Tensor, q: Rounding = FP32, f: bool = True, dx: bool = True, dw: bool = True):
+    """a @ b under rounding policy q.  f / dx / dw = False: THAT contraction runs on the exact fp32 kernel in the HIP
+    path even in bf16 mode (fewer than 64 output columns and no bf16-resident operand: tecmollm/ops.py:uses_bf16)."""
+    if q.fwd is None and q.bwd is None:
+        return a @ b
+    return _MatMul.apply(a, b, q.fwd if f else None, q.bwd if dx else None, q.bwd if dw else None)
+
+
+def conv1d(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, q: Rounding = FP32, stride: int = 1, padding: int = 0):
+    if q.fwd is None and q.bwd is None:
+        return F.conv1d(x, w, bias, stride=stride, padding=padding)
+    return _Conv1d.apply(x, w, stride, padding, q.fwd, q.bwd, q.bwd) + bias.view(1, -1, 1)
+
+
+# ------------------------------------------------------------------- stage a-4/a-5
+def conv_block(x: torch.Tensor, p: Params, idx: int, stride: int, q: Rounding = FP32) -> torch.Tensor:
     """Multi_Scale_Conv_Block.forward, modules.py:43-60: x (S, C_in, L).
-    q: operand rounding of the dense contractions (identity = fp32; bf16_round emulates the bf16 MFMA mode)."""
+    bf16 mode: all four convolutions and their dX / dW contractions have >= 64 output columns or read the bf16-resident
+    dy (block 0's dX has 24 columns but its A operand is the bf16 dy), so every one is a bf16 contraction."""
     outs = []
     for j, k in enumerate((3, 5, 7)):
         pre = f"{P_CONV}{idx}.convs.{j}."
-        y = F.conv1d(q(x), q(p[pre + "0.weight"]), p[pre + "0.bias"], padding=(k - 1) // 2)
+        y = conv1d(x, p[pre + "0.weight"], p[pre + "0.bias"], q, padding=(k - 1) // 2)
         y = F.group_norm(y, 1, p[pre + "1.weight"], p[pre + "1.bias"], eps=1e-5)
         outs.append(F.gelu(y))
     cat = torch.cat(outs, dim=1)
     pre = f"{P_CONV}{idx}.final_conv."
-    return F.conv1d(q(cat), q(p[pre + "weight"]), p[pre + "bias"], stride=stride)
+    return conv1d(cat, p[pre + "weight"], p[pre + "bias"], q, stride=stride)
 
 
-def temporal_encoder(x: torch.Tensor, p: Params, strides, patch_len: int, q=_ident) -> torch.Tensor:
+def temporal_encoder(x: torch.Tensor, p: Params, strides, patch_len: int, q: Rounding = FP32) -> torch.Tensor:
     """TemporalEncoder.forward modules.py:134-154 + LatentPatchingProjection :100-119.
     x (S, L, C) -> (S, P, d_llm).  Patch vector index = l*D + d (einops 'b (p l) d -> b p (l d)')."""
     y = x.permute(0, 2, 1)
@@ -169,7 +255,7 @@ def temporal_encoder(x: torch.Tensor, p: Params, strides, patch_len: int, q=_ide
     y = y.permute(0, 2, 1)                                   # (S, L', D)
     S, Lc, D = y.shape
     y = y.reshape(S, Lc // patch_len, patch_len * D)
-    return q(y) @ q(p[P_PATCH + "weight"]).t() + p[P_PATCH + "bias"]
+    return mm(y, p[P_PATCH + "weight"].t(), q) + p[P_PATCH + "bias"]
 
 
 # ------------------------------------------------------------------- stage a-6
@@ -189,13 +275,16 @@ def _mul(t: torch.Tensor, masks, key: str) -> torch.Tensor:
     return t * m
 
 
-def gpt2_lora(h: torch.Tensor, p: Params, n_layers: int, q=_ident, masks=None) -> torch.Tensor:
+def gpt2_lora(h: torch.Tensor, p: Params, n_layers: int, q: Rounding = FP32, masks=None) -> torch.Tensor:
     """LLMBackbone.forward modules.py:205-209 -> peft(GPT2Model)(inputs_embeds=h, all-ones mask).
     h (S, T, 768).  c_attn' = base Conv1D + 2.0 * B(A(lora_dropout(u))).
     Dropout sites (all p = 0.1 in the reference; masks=None is eval mode): GPT2Model `drop` on
     inputs_embeds + wpe ("embd", modeling_gpt2.py embd_pdrop), peft's lora_dropout on the LoRA branch input
     ("lora{i}", modules.py:181), attention-probability dropout ("attn{i}", (S, heads, T, T), attn_pdrop),
-    residual dropouts after attn.c_proj and mlp.c_proj ("res1_{i}", "res2_{i}", resid_pdrop)."""
+    residual dropouts after attn.c_proj and mlp.c_proj ("res1_{i}", "res2_{i}", resid_pdrop).
+    bf16 mode (q = BF16), as the HIP path runs it: c_attn + LoRA-B is ONE contraction with K = 768 + 32 over
+    [LN1(h) | z] and [W ; 2 B^T]; the LoRA-A product z (32 output columns) runs on the exact kernel in the forward,
+    while its two backward contractions (768 output columns each) are bf16."""
     S, T, D = h.shape
     hd = D // GPT2_HEADS
     h = _mul(h + p[P_GPT + "wpe.weight"][:T], masks, "embd")
@@ -205,9 +294,9 @@ def gpt2_lora(h: torch.Tensor, p: Params, n_layers: int, q=_ident, masks=None) -
         u = F.layer_norm(h, (D,), p[pre + "ln_1.weight"], p[pre + "ln_1.bias"], LN_EPS)
         A = p[pre + "attn.c_attn.lora_A.default.weight"]     # (r, 768)
         Bm = p[pre + "attn.c_attn.lora_B.default.weight"]    # (2304, r)
-        z = _mul(u, masks, f"lora{i}") @ A.t()               # 32 output columns: stays on the exact fp32 kernel
-        qkv = q(u) @ q(p[pre + "attn.c_attn.base_layer.weight"]) + p[pre + "attn.c_attn.base_layer.bias"]
-        qkv = qkv + q(z) @ q(LORA_SCALE * Bm.t())            # one K-extended GEMM in the HIP path
+        z = mm(_mul(u, masks, f"lora{i}"), A.t(), q, f=False)
+        wcat = torch.cat([p[pre + "attn.c_attn.base_layer.weight"], LORA_SCALE * Bm.t()], 0)     # (768 + r, 2304)
+        qkv = mm(torch.cat([u, z], -1), wcat, q) + p[pre + "attn.c_attn.base_layer.bias"]
         qq, k, v = qkv.split(D, dim=-1)
         qq = qq.view(S, T, GPT2_HEADS, hd).transpose(1, 2)
         k = k.view(S, T, GPT2_HEADS, hd).transpose(1, 2)
@@ -215,28 +304,31 @@ def gpt2_lora(h: torch.Tensor, p: Params, n_layers: int, q=_ident, masks=None) -
         w = (qq @ k.transpose(-1, -2)) / math.sqrt(hd)
         w = _mul(w.masked_fill(~causal, float("-inf")).softmax(-1), masks, f"attn{i}")
         ctx = (w @ v).transpose(1, 2).reshape(S, T, D)
-        h = h + _mul(q(ctx) @ q(p[pre + "attn.c_proj.weight"]) + p[pre + "attn.c_proj.bias"], masks, f"res1_{i}")
+        h = h + _mul(mm(ctx, p[pre + "attn.c_proj.weight"], q) + p[pre + "attn.c_proj.bias"], masks, f"res1_{i}")
         u = F.layer_norm(h, (D,), p[pre + "ln_2.weight"], p[pre + "ln_2.bias"], LN_EPS)
-        f = gelu_new(q(u) @ q(p[pre + "mlp.c_fc.weight"]) + p[pre + "mlp.c_fc.bias"])
-        h = h + _mul(q(f) @ q(p[pre + "mlp.c_proj.weight"]) + p[pre + "mlp.c_proj.bias"], masks, f"res2_{i}")
+        f = gelu_new(mm(u, p[pre + "mlp.c_fc.weight"], q) + p[pre + "mlp.c_fc.bias"])
+        h = h + _mul(mm(f, p[pre + "mlp.c_proj.weight"], q) + p[pre + "mlp.c_proj.bias"], masks, f"res2_{i}")
     return F.layer_norm(h, (D,), p[P_GPT + "ln_f.weight"], p[P_GPT + "ln_f.bias"], LN_EPS)
 
 
 # ------------------------------------------------------------------- stage a-8
-def head(x: torch.Tensor, p: Params, q=_ident, masks=None) -> torch.Tensor:
+def head(x: torch.Tensor, p: Params, q: Rounding = FP32, masks=None) -> torch.Tensor:
     """PredictionHead.forward modules.py:295-313: (S,T,768) -> (S, L_out); nn.Dropout after the GELU
     (modules.py:289, mask "head" (S, hidden)).
-    The 12-column output layer stays fp32 in the bf16 mode (fewer than 64 output columns)."""
+    bf16 mode: the L_out-column output layer runs on the exact kernel in the forward (fewer than 64 output columns);
+    its dX and dW contractions have `hidden` (>= 64) output columns and are bf16."""
     z = x.reshape(x.shape[0], -1)
-    z = _mul(F.gelu(q(z) @ q(p[P_HEAD + "0.weight"]).t() + p[P_HEAD + "0.bias"]), masks, "head")
-    return z @ p[P_HEAD + "3.weight"].t() + p[P_HEAD + "3.bias"]
+    z = _mul(F.gelu(mm(z, p[P_HEAD + "0.weight"].t(), q) + p[P_HEAD + "0.bias"]), masks, "head")
+    hidden = p[P_HEAD + "0.weight"].shape[0]
+    small = p[P_HEAD + "3.weight"].shape[0] < 64
+    return mm(z, p[P_HEAD + "3.weight"].t(), q, f=not small, dx=hidden >= 64, dw=hidden >= 64) + p[P_HEAD + "3.bias"]
 
 
 # ------------------------------------------------------------------- full path
 def forward(x: torch.Tensor, tf: torch.Tensor, edge_index: torch.Tensor, p: Params, cfg: dict,
-            graphs_with_edges: Optional[int] = 1, q=_ident, masks=None) -> torch.Tensor:
+            graphs_with_edges: Optional[int] = 1, q: Rounding = FP32, masks=None) -> torch.Tensor:
     """TEC_MoLLM.forward tec_mollm.py:59-125.  Returns (B, L_out, N, 1).
-    q=bf16_round emulates the bf16 MFMA mode (GATv2's 22x22 transforms stay fp32 there).
+    q=BF16 emulates the bf16 MFMA mode, forward and backward (GATv2's 22x22 transforms stay fp32 there).
     masks=None: eval mode.  masks = {site: multiplier tensor}: training mode with the given dropout masks at
     every site of the reference -- "gat" (modules.py:333), "embd"/"lora{i}"/"attn{i}"/"res1_{i}"/"res2_{i}"
     (GPT-2 + peft, see gpt2_lora), "post" (F.dropout tec_mollm.py:115, (S,T,768)), "head" (modules.py:289)."""

@@ -602,17 +602,28 @@ __global__ __launch_bounds__((GnGeom<CPB, WPS>::NTHR)) void gn_gelu_bwd_reg(cons
         }
     }
   }
-  // block reduction of the per-lane parameter gradients (each channel is held by many lanes) -> one partial row
-  __syncthreads();
+  // block reduction of the per-lane parameter gradients (each channel quad is held by NTHR*3/QPR (lane, slot) pairs)
+  // -> one partial row.  In a FIXED order, so that the gradients repeat bit for bit: for a given slot the holders of
+  // one quad are the lanes with the same l2 % QPR, ranked by (sequence of the block, l2 / QPR); in round (slot, rank)
+  // every quad has at most one writer, which adds with a plain read-modify-write.  (LDS float atomics here made
+  // d gamma / d beta / d conv-bias order-dependent in the last bits.)
+  {
+    constexpr int RMAX = (G::LPS + G::QPR - 1) / G::QPR;
+    const int rank = sp * RMAX + l2 / G::QPR;
 #pragma unroll
-  for (int s_ = 0; s_ < 3; ++s_) {
-    const int c = qs[s_] * 4;
-    atomicAdd(&red[c + 0], dgm[s_].x); atomicAdd(&red[c + 1], dgm[s_].y);
-    atomicAdd(&red[c + 2], dgm[s_].z); atomicAdd(&red[c + 3], dgm[s_].w);
-    atomicAdd(&red[G::CT + c + 0], dbt[s_].x); atomicAdd(&red[G::CT + c + 1], dbt[s_].y);
-    atomicAdd(&red[G::CT + c + 2], dbt[s_].z); atomicAdd(&red[G::CT + c + 3], dbt[s_].w);
-    atomicAdd(&red[2 * G::CT + c + 0], dys[s_].x); atomicAdd(&red[2 * G::CT + c + 1], dys[s_].y);
-    atomicAdd(&red[2 * G::CT + c + 2], dys[s_].z); atomicAdd(&red[2 * G::CT + c + 3], dys[s_].w);
+    for (int s_ = 0; s_ < 3; ++s_) {
+      const int c = qs[s_] * 4;
+      for (int r = 0; r < G::SPB * RMAX; ++r) {
+        __syncthreads();
+        if (r == rank) {
+          red[c + 0] += dgm[s_].x; red[c + 1] += dgm[s_].y; red[c + 2] += dgm[s_].z; red[c + 3] += dgm[s_].w;
+          red[G::CT + c + 0] += dbt[s_].x; red[G::CT + c + 1] += dbt[s_].y;
+          red[G::CT + c + 2] += dbt[s_].z; red[G::CT + c + 3] += dbt[s_].w;
+          red[2 * G::CT + c + 0] += dys[s_].x; red[2 * G::CT + c + 1] += dys[s_].y;
+          red[2 * G::CT + c + 2] += dys[s_].z; red[2 * G::CT + c + 3] += dys[s_].w;
+        }
+      }
+    }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < 3 * G::CT; c += G::NTHR) partials[(int64_t)blockIdx.x * 3 * G::CT + c] = red[c];

@@ -17,11 +17,38 @@ for _p in (ROOT, os.path.join(ROOT, "tec-mollm_amd")):
 from oracle import ref_cpu as R  # noqa: E402
 
 RTOL = 1e-3          # north star: "within 1e-3 rel fp32"
-# Absolute slack of the element-wise bar, as a fraction of the oracle tensor's RMS.  Not tighter than 5e-3: GATv2's
+# Absolute slack of the element-wise bar, as a fraction of the oracle tensor's RMS: |a-b| <= RTOL*|b| + ATOL_RMS*rms(b).
+ATOL_RMS = 5e-4
+# The ONE documented exception, applied only where a test passes `kink=True` (the full 2911-node graph): GATv2's
 # LeakyReLU has a kink -- when a sum x_l[j,c] + x_r[i,c] lands within rounding distance of 0 the two sides can see
 # opposite signs, lrelu' jumps between 0.2 and 1, and ONE term of a gradient sum changes (observed at N = 2911, 48
-# graphs: two neighbouring rows of the node-table gradient off by 1.8e-3 of its RMS, every other row below 2e-5).
-ATOL_RMS = 5e-3
+# graphs: two neighbouring rows of the node-table gradient off by 1.8e-3 of its RMS, every other row below 2e-5;
+# tools/diag_parity.py; train mode, same size: one element of d lin_r.weight at 5.4e-4 of its RMS).  Only the tensors
+# whose gradient passes through lrelu'(x_l[j] + x_r[i]) -- the embedding tables and the two GATv2 input transforms -- get
+# the wider absolute term; `att`, the output bias and everything downstream of the spatial stage do not.
+ATOL_RMS_KINK = 5e-3
+KINK_TENSORS = tuple(f"spatio_temporal_embedding.{n}_embedding.weight" for n in ("node", "tod", "doy", "year", "season")) + \
+    tuple(f"spatial_encoder.gat_conv.lin_{s}.{w}" for s in ("l", "r") for w in ("weight", "bias"))
+
+# bf16 mode (BASELINE configs[2]) against the bf16-EMULATING oracle (ref_cpu.BF16: the same operand roundings in the
+# forward and in the backward contractions).  What is left between the two sides is fp32 summation order PLUS
+# rounding flips: a value that differs by one fp32 ulp between the sides can round to a different bf16 neighbour, a
+# 2^-9 = 2e-3 relative jump of ONE operand element of the next contraction.  Sums over thousands of such elements
+# average the flips out (parameter gradients), single activations do not, hence a bar of 1e-2 relative +
+# 1e-2 * rms(b) absolute -- ten times the fp32 bar, ten times tighter than bf16 against the fp32 oracle (8e-2).
+RTOL_BF16 = 1e-2
+ATOL_RMS_BF16 = 1e-2
+# The bar above holds for ONE stage fed identical inputs on both sides (tests/test_gpu_bf16_model.py, stage tests).  It
+# cannot hold through the whole model, and no implementation could make it: a relative deviation eps in front of a bf16
+# rounding comes out as sqrt(ulp_bf16 * eps) behind it (a flip of probability eps/ulp and size ulp; ulp = 2^-8), so
+# 1e-6 (fp32 summation order) -> 6e-5 -> 5e-4 -> 1.4e-3 -> ... converges to the bf16 quantisation noise itself after a
+# handful of chained contractions, whatever the starting point (measured stage by stage: tools/diag_bf16.py,
+# profiles/r03_bf16_stage_deviation.md).  The model-level statement is therefore (i) fixed bars at the scale of that
+# noise floor -- max-norm 2e-2, element-wise 2e-2*|b| + 6e-2*rms(b) (measured worst case over all tests: 1.3e-2 and
+# 5.0e-2, on gradients that are sums over only B*T*N = 120 rows), against 8e-2 for bf16 vs the fp32 oracle -- and (ii) the self-calibrated test: the device is as close to the oracle as the oracle is to ITSELF when its
+# inputs are perturbed by the fp32-mode deviation between the two implementations (1e-6).
+RTOL_BF16_MODEL = 2e-2
+ATOL_RMS_BF16_MODEL = 6e-2
 
 
 def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
@@ -31,22 +58,39 @@ def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
 
 
 def elem_err(a: torch.Tensor, b: torch.Tensor, rtol: float = RTOL, atol_rms: float = ATOL_RMS) -> float:
-    """Element-wise bar: max over elements of |a-b| / (rtol*|b| + atol), atol = atol_rms * rms(b).
+    """Element-wise bar: max over elements of |a-b| / (rtol*|b| + atol), atol = atol_rms * rms(non-zero entries of b).
     A value < 1 means EVERY element satisfies |a-b| <= rtol*|b| + atol (the torch.allclose form with the absolute
     term tied to the tensor's own scale), so a small entry that is wrong by 100 % fails even when the tensor's
     largest entry hides it from `rel_err`.  b = oracle."""
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
-    rms = float(b.pow(2).mean().sqrt())
-    if rms == 0.0:
+    nz = int((b != 0).sum())
+    if nz == 0:
         return 0.0 if float((a - b).abs().max()) == 0.0 else float("inf")
+    rms = float((b.pow(2).sum() / nz).sqrt())          # RMS of the entries that are used: rows of an embedding / position
+    #                                                     table no sample touches have an exactly-zero gradient on both sides
     return float(((a - b).abs() / (rtol * b.abs() + atol_rms * rms)).max())
 
 
-def build_model(cfg: dict, params: Dict[str, torch.Tensor], device, gat_graphs: str = "reference"):
+def l2_rel(a: torch.Tensor, b: torch.Tensor) -> float:
+    """||a-b||_2 / ||b||_2  (b = oracle)."""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-300))
+
+
+def assert_close(a: torch.Tensor, b: torch.Tensor, what: str = "", rtol: float = RTOL, atol_rms: float = ATOL_RMS) -> None:
+    """Stage-level bar: max-norm relative error AND the element-wise bar (b = oracle / golden)."""
+    r, e = rel_err(a, b), elem_err(a, b, rtol, atol_rms)
+    assert r < rtol and e < 1.0, f"{what}: max-norm rel {r:.3e} (bar {rtol}), element-wise {e:.3f} of the bar"
+
+
+def build_model(cfg: dict, params: Dict[str, torch.Tensor], device, gat_graphs: str = "reference",
+                precision: Optional[str] = None):
     """TEC_MoLLM (HIP path) carrying exactly the oracle's parameters (strict state-dict load)."""
     from src.model.tec_mollm import TEC_MoLLM
     mc = dict(cfg)
     mc.update(gat_graphs=gat_graphs, include_wte=False, load_pretrained_gpt2=False)
+    if precision is not None:
+        mc["precision"] = precision
     model = TEC_MoLLM(mc)
     missing, unexpected = model.load_state_dict(params, strict=True), None
     del missing, unexpected
@@ -54,10 +98,11 @@ def build_model(cfg: dict, params: Dict[str, torch.Tensor], device, gat_graphs: 
 
 
 def oracle_step(cfg, params, x, tf, ei, y, graphs_with_edges,
-                masks=None) -> Tuple[torch.Tensor, torch.Tensor, Dict[str, torch.Tensor]]:
-    """CPU oracle forward + Huber loss + autograd backward.  Returns (out, loss, grads of trainable params)."""
+                masks=None, q: "R.Rounding" = R.FP32) -> Tuple[torch.Tensor, torch.Tensor, Dict[str, torch.Tensor]]:
+    """CPU oracle forward + Huber loss + autograd backward.  Returns (out, loss, grads of trainable params).
+    q = R.BF16: the bf16-emulating oracle (operand roundings of the forward and backward contractions)."""
     p = {k: v.clone().requires_grad_(R.is_trainable(k)) for k, v in params.items()}
-    out = R.forward(x, tf, ei, p, cfg, graphs_with_edges, masks=masks)
+    out = R.forward(x, tf, ei, p, cfg, graphs_with_edges, q=q, masks=masks)
     loss = R.huber(out, y)
     names = [k for k, v in p.items() if v.requires_grad]
     grads = torch.autograd.grad(loss, [p[k] for k in names], allow_unused=True)
@@ -145,12 +190,14 @@ def device_masks(cfg: dict, B: int, ei: torch.Tensor, base_seed: int, gat_graphs
 
 def compare_forward_backward(cfg: dict, B: int, grid: Tuple[int, int], threshold_km: float = 150.0,
                              gat_graphs: str = "reference", seed: int = 0, use_fused_huber: bool = True,
-                             device: Optional[str] = None, train: bool = False) -> dict:
+                             device: Optional[str] = None, train: bool = False, precision: str = "fp32") -> dict:
     """Run the same seeded step through the CPU oracle and the HIP model and report the errors of the forward output,
     the loss and every trainable gradient: `*_rel` = max-norm relative error, `*_elem` = the element-wise bar
     (`elem_err`, < 1 passes).  train=False: eval mode (dropout off).  train=True: training mode, every dropout site of
     the reference active (p = 0.1); the oracle receives the NumPy mirror of the device's counter-based masks
-    (`device_masks`), so both sides drop exactly the same elements."""
+    (`device_masks`), so both sides drop exactly the same elements.
+    precision="bf16": the model runs its bf16 mode (BASELINE configs[2]) and the oracle its bf16 emulation (R.BF16);
+    the element-wise numbers are then relative to (RTOL_BF16_MODEL, ATOL_RMS_BF16_MODEL)."""
     from src.model import modules as M_
     from tecmollm import functions as F_
     device = device or "cuda"
@@ -167,9 +214,12 @@ def compare_forward_backward(cfg: dict, B: int, grid: Tuple[int, int], threshold
         M_._seed_counter[0] = 17                                  # make_plan: base = initial_seed + 7919 * (count + 1)
         base_seed = torch.initial_seed() + 7919 * 18
         masks = device_masks(cfg, B, ei, base_seed, gat_graphs)
-    out_ref, loss_ref, grads_ref = oracle_step(cfg, params, x, tf, ei, y, gwe, masks)
+    assert precision in ("fp32", "bf16")
+    b16 = precision == "bf16"
+    rtol, atol = (RTOL_BF16_MODEL, ATOL_RMS_BF16_MODEL) if b16 else (RTOL, ATOL_RMS)
+    out_ref, loss_ref, grads_ref = oracle_step(cfg, params, x, tf, ei, y, gwe, masks, q=R.BF16 if b16 else R.FP32)
 
-    model = build_model(cfg, params, device, gat_graphs)
+    model = build_model(cfg, params, device, gat_graphs, precision=precision)
     model.train(train)
     xd, yd = x.to(device), y.to(device)
     tfd = tf[:, :, 0, :].contiguous().to(device).unsqueeze(-2).expand(B, cfg["temporal_seq_len"], N, 4)
@@ -178,10 +228,11 @@ def compare_forward_backward(cfg: dict, B: int, grid: Tuple[int, int], threshold
     loss = F_.HuberFn.apply(out, yd, 1.0) if use_fused_huber else torch.nn.functional.huber_loss(out, yd, delta=1.0)
     loss.backward()
     torch.cuda.synchronize()
-    res = {"fwd_rel": rel_err(out, out_ref), "fwd_elem": elem_err(out, out_ref),
-           "loss_rel": abs(loss.item() - loss_ref.item()) / abs(loss_ref.item())}
+    res = {"fwd_rel": rel_err(out, out_ref), "fwd_elem": elem_err(out, out_ref, rtol, atol), "fwd_l2": l2_rel(out, out_ref),
+           "loss_rel": abs(loss.item() - loss_ref.item()) / abs(loss_ref.item()), "precision": precision}
     worst, worst_name = 0.0, ""
     worst_e, worst_e_name = 0.0, ""
+    worst_k, worst_k_name = 0.0, ""
     per = {}
     named = dict(model.named_parameters())
     for k, gref in grads_ref.items():
@@ -189,24 +240,41 @@ def compare_forward_backward(cfg: dict, B: int, grid: Tuple[int, int], threshold
         assert g is not None, f"no gradient for trainable parameter {k}"
         nz = gref.abs().max() > 0
         e = rel_err(g, gref) if nz else float(g.abs().max())
-        ee = elem_err(g, gref) if nz else float(g.abs().max())
-        per[k] = (e, ee)
+        ee = elem_err(g, gref, rtol, atol) if nz else float(g.abs().max())
+        per[k] = (e, ee, l2_rel(g, gref) if nz else 0.0)
         if e > worst:
             worst, worst_name = e, k
+        if k in KINK_TENSORS and not b16:            # judged separately: `assert_parity(kink=True)` widens only these
+            ek = elem_err(g, gref, rtol, ATOL_RMS_KINK) if nz else float(g.abs().max())
+            if ek > worst_k:
+                worst_k, worst_k_name = ek, k
+            res.setdefault("kink_elem_tight", {})[k] = ee
+            continue
         if ee > worst_e:
             worst_e, worst_e_name = ee, k
     frozen_with_grad = [k for k, p in named.items() if not R.is_trainable(k) and p.grad is not None]
     res.update(grad_rel_max=worst, grad_worst=worst_name, grad_elem_max=worst_e, grad_elem_worst=worst_e_name,
+               kink_elem_max=worst_k, kink_elem_worst=worst_k_name,
                n_grads=len(per), frozen_with_grad=frozen_with_grad)
     res["per_param"] = per
     return res
 
 
-def assert_parity(res: dict, tol: float = RTOL) -> None:
-    """The bar of every full-step test: forward, loss and all gradients within 1e-3 in the max norm AND element-wise."""
+def assert_parity(res: dict, tol: Optional[float] = None, kink: bool = False) -> None:
+    """The bar of every full-step test.  fp32: forward, loss and all gradients within 1e-3 in the max norm AND
+    element-wise |a-b| <= 1e-3*|b| + 5e-4*rms(b).  kink=True (full-size graph only): the tensors of KINK_TENSORS get
+    the absolute term ATOL_RMS_KINK; without it they meet the same bar as everything else.
+    bf16 (res["precision"]): the same two bars at RTOL_BF16_MODEL / ATOL_RMS_BF16_MODEL against the bf16-emulating
+    oracle (why not tighter: see the constants)."""
+    b16 = res.get("precision") == "bf16"
+    tol = tol if tol is not None else (RTOL_BF16_MODEL if b16 else RTOL)
     brief = {k: v for k, v in res.items() if k != "per_param"}
     assert res["fwd_rel"] < tol and res["loss_rel"] < tol, brief
     assert res["grad_rel_max"] < tol, brief
     assert res["fwd_elem"] < 1.0, brief
     assert res["grad_elem_max"] < 1.0, brief
+    if kink:
+        assert res["kink_elem_max"] < 1.0, brief
+    else:
+        assert all(v < 1.0 for v in res.get("kink_elem_tight", {}).values()), brief
     assert res["frozen_with_grad"] == [], brief

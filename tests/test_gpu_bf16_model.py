@@ -1,0 +1,239 @@
+"""bf16 mode (BASELINE configs[2] = the reference's own training arithmetic, train.py:68), model level, forward AND
+backward, against the bf16-EMULATING oracle: oracle/ref_cpu.py `Rounding` / `_MatMul` / `_Conv1d` apply the same bf16
+operand roundings to the forward and to both backward contractions of every Linear / Conv1d the HIP path runs on the
+bf16 matrix cores (and leave exact the ones it runs on the fp32 kernel).
+
+Three layers of evidence, tightest first (bars and their justification: tests/parity.py):
+  1. every STAGE (conv block, patch projection, one GPT-2 block, head) with identical inputs and identical upstream
+     gradients on both sides: 1e-2 element-wise for the output, the input gradient and every parameter gradient;
+  2. the whole step (eval and train mode with mirrored masks, N = 20 / 135 / 2911, 3 and 6 tokens), all 66 gradients, at
+     the model-level bars -- bf16 roundings amplify ANY deviation to the bf16 noise floor within a few chained stages;
+  3. the self-calibrated form of 2: the device is as close to the oracle as the oracle is to itself under a 1e-6
+     perturbation of its inputs (the size of the fp32-mode deviation between the two implementations)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+from tests.parity import (ATOL_RMS_BF16, RTOL_BF16, assert_close, assert_parity, build_model, compare_forward_backward,
+                          l2_rel, oracle_step)
+
+pytestmark = pytest.mark.gpu
+BF16 = 1                      # tecmollm.ops.PREC_BF16
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda")
+
+
+def _close16(a, b, what, atol_rms=ATOL_RMS_BF16):
+    assert_close(a, b, what, RTOL_BF16, atol_rms)
+
+
+def _tm(t, B, N):
+    """oracle (S = B*N, T, D) -> device time-major (B, T, N, D)."""
+    S, T, D = t.shape
+    return t.reshape(B, N, T, D).permute(0, 2, 1, 3).contiguous()
+
+
+def _seq(t):
+    """device (B, T, N, D) -> oracle (S, T, D)."""
+    B, T, N, D = t.shape
+    return t.permute(0, 2, 1, 3).reshape(B * N, T, D)
+
+
+def _leaf(p, prefix):
+    return {k: v.clone().requires_grad_(True) for k, v in p.items() if k.startswith(prefix)}
+
+
+# ----------------------------------------------------------------------------------- 1. stages, identical inputs
+@pytest.mark.parametrize("idx,L,cin,ld", [(0, 48, 22, 24), (1, 24, 64, 64)], ids=["block0", "block1"])
+def test_bf16_conv_block_stage_fwd_bwd(dev, idx, L, cin, ld):
+    """Multi_Scale_Conv_Block (modules.py:43-60) in bf16 mode: output, d input and the 14 parameter gradients."""
+    from src.model.modules import Multi_Scale_Conv_Block
+    B, N = 2, 37
+    cfg = R.default_config(L_in=48, num_nodes=N)
+    p = R.init_params(cfg, seed=41)
+    pre = f"{R.P_CONV}{idx}."
+    g = torch.Generator().manual_seed(42 + idx)
+    x = torch.randn(B * N, L, cin, generator=g)                           # oracle layout (S, L, C)
+    pr = _leaf(p, pre)
+    xr = x.clone().requires_grad_(True)
+    ref = R.conv_block(xr.permute(0, 2, 1), pr, idx, 2, R.BF16).permute(0, 2, 1)       # (S, L/2, Cout)
+    gout = torch.randn(ref.shape, generator=g)
+    gref = torch.autograd.grad(ref, [xr] + list(pr.values()), gout)
+
+    cout = ref.shape[-1]
+    blk = Multi_Scale_Conv_Block(cin, cout, 2)
+    blk.load_state_dict({k[len(pre):]: v for k, v in p.items() if k.startswith(pre)})
+    blk = blk.to(dev)
+    xd = torch.zeros(B, L, N, ld)
+    xd[..., :cin] = _tm(x, B, N)
+    xd = xd.to(dev).requires_grad_(True)
+    out, out16 = blk.forward_tm(xd, cin, True, BF16, None)
+    assert out16 is not None and out16.dtype == torch.bfloat16 and torch.equal(out16.float(), out.bfloat16().float())
+    _close16(_seq(out), ref, f"conv block {idx} forward")
+    named = dict(blk.named_parameters())
+    ghip = torch.autograd.grad(out, [xd] + [named[k[len(pre):]] for k in pr], _tm(gout, B, N).to(dev))
+    _close16(_seq(ghip[0][..., :cin]), gref[0], f"conv block {idx} d input")
+    for k, a, b in zip(pr, ghip[1:], gref[1:]):
+        _close16(a, b, k)
+
+
+def test_bf16_patch_projection_stage_fwd_bwd(dev):
+    """LatentPatchingProjection (modules.py:100-119) + wpe in bf16 mode."""
+    from src.model.modules import LatentPatchingProjection
+    B, N, Lc, D = 2, 33, 12, 128
+    cfg = R.default_config(L_in=48, num_nodes=N)
+    p = R.init_params(cfg, seed=43)
+    g = torch.Generator().manual_seed(44)
+    conv = torch.randn(B * N, Lc, D, generator=g)
+    W = p[R.P_PATCH + "weight"].clone().requires_grad_(True)
+    b = p[R.P_PATCH + "bias"].clone().requires_grad_(True)
+    wpe = p[R.P_GPT + "wpe.weight"].clone().requires_grad_(True)
+    cr = conv.clone().requires_grad_(True)
+    ref = R.mm(cr.reshape(B * N, Lc // 4, 4 * D), W.t(), R.BF16) + b + wpe[:Lc // 4]
+    gout = torch.randn(ref.shape, generator=g)
+    gref = torch.autograd.grad(ref, [cr, W, b, wpe], gout)
+    pj = LatentPatchingProjection(D, 4, 768)
+    pj.projection.load_state_dict({"weight": W.detach(), "bias": b.detach()})
+    pj = pj.to(dev)
+    from tecmollm import functions as F_
+    cd = _tm(conv, B, N).to(dev).requires_grad_(True)
+    wd = wpe.detach().to(dev).requires_grad_(True)
+    out = pj.forward_tm(cd, wd, F_.DropPlan(False, 0.0, 0, BF16), None)
+    _close16(_seq(out), ref, "tokens")
+    ghip = torch.autograd.grad(out, [cd, pj.projection.weight, pj.projection.bias, wd], _tm(gout, B, N).to(dev))
+    _close16(_seq(ghip[0]), gref[0], "d conv")
+    for name, a, r in zip(("W", "b", "wpe"), ghip[1:], gref[1:]):
+        _close16(a, r, name)
+
+
+@pytest.mark.parametrize("T", [3, 6])
+def test_bf16_gpt2_block_stage_fwd_bwd(dev, T):
+    """ONE GPT-2 block with LoRA + ln_f (modeling_gpt2.py:262-310, modules.py:177-186) in bf16 mode: the K-extended
+    c_attn contraction, the exact-kernel LoRA-A product with bf16 backward contractions, the bf16 dqkv / d gelu-input /
+    masked LayerNorm-backward operands.  Output, d input and the 8 trainable parameter gradients.  A block is itself a
+    chain of 4 forward + 4 backward bf16 contractions in front of the LoRA gradients, so the absolute term is 2e-2*rms
+    here (measured 1.02e-2 on lora_B at T = 6) against 1e-2 for the single-contraction stages."""
+    from src.model.modules import LLMBackbone
+    from tecmollm import functions as F_
+    B, N = 2, 41
+    cfg = R.default_config(L_in=16 * T, num_nodes=N, llm_layers=1)
+    p = R.init_params(cfg, seed=45)
+    g = torch.Generator().manual_seed(46)
+    tok = torch.randn(B * N, T, 768, generator=g) * 0.5
+    pr = {k: v.clone().requires_grad_(R.is_trainable(k)) for k, v in p.items() if k.startswith(R.P_GPT)}
+    tr = tok.clone().requires_grad_(True)
+    # gpt2_lora adds wpe itself; the device stage receives tokens + wpe
+    ref = R.gpt2_lora(tr, pr, 1, R.BF16)
+    gout = torch.randn(ref.shape, generator=g)
+    names = [k for k, v in pr.items() if v.requires_grad and "wpe" not in k]
+    gref = torch.autograd.grad(ref, [tr] + [pr[k] for k in names], gout)
+    bb = LLMBackbone(1, include_wte=False, load_pretrained=False)
+    bb.load_state_dict({k[len("llm_backbone."):]: v for k, v in p.items() if k.startswith("llm_backbone.")})
+    bb = bb.to(dev).eval()
+    h0 = _tm(tok + p[R.P_GPT + "wpe.weight"][:T], B, N).to(dev).requires_grad_(True)
+    out = bb.forward_tm(h0, F_.DropPlan(False, 0.0, 0, BF16))
+    _close16(_seq(out), ref, "block output")
+    named = {"llm_backbone." + k: v for k, v in bb.named_parameters()}
+    ghip = torch.autograd.grad(out, [h0] + [named[k] for k in names], _tm(gout, B, N).to(dev))
+    _close16(_seq(ghip[0]), gref[0], "d tokens", 2e-2)
+    for k, a, r in zip(names, ghip[1:], gref[1:]):
+        _close16(a, r, k, 2e-2)
+
+
+def test_bf16_head_stage_fwd_bwd(dev):
+    """PredictionHead (modules.py:295-313) in bf16 mode: the 12-column output layer is exact in the forward and bf16 in
+    both backward contractions."""
+    from src.model.modules import PredictionHead
+    from tecmollm import functions as F_
+    B, N, T = 2, 45, 3
+    cfg = R.default_config(L_in=48, num_nodes=N)
+    p = R.init_params(cfg, seed=47)
+    g = torch.Generator().manual_seed(48)
+    hid = torch.randn(B * N, T, 768, generator=g)
+    pr = _leaf(p, R.P_HEAD)
+    hr = hid.clone().requires_grad_(True)
+    ref = R.head(hr, pr, R.BF16)
+    gout = torch.randn(ref.shape, generator=g)
+    gref = torch.autograd.grad(ref, [hr] + list(pr.values()), gout)
+    ph = PredictionHead(T * 768, 12)
+    ph.load_state_dict({k[len("prediction_head."):]: v for k, v in p.items() if k.startswith(R.P_HEAD)})
+    ph = ph.to(dev).eval()
+    hd = _tm(hid, B, N).to(dev).requires_grad_(True)
+    out = ph.forward_tm(hd, F_.DropPlan(False, 0.0, 0, BF16))             # (B, N, L_out)
+    _close16(out.reshape(B * N, -1), ref, "prediction")
+    named = {"prediction_head." + k: v for k, v in ph.named_parameters()}
+    ghip = torch.autograd.grad(out, [hd] + [named[k] for k in pr], gout.view(B, N, -1).to(dev))
+    _close16(_seq(ghip[0]), gref[0], "d hidden")
+    for k, a, r in zip(pr, ghip[1:], gref[1:]):
+        _close16(a, r, k)
+
+
+# ----------------------------------------------------------------------------------- 2. the whole step
+@pytest.mark.parametrize("train", [False, True], ids=["eval", "train"])
+@pytest.mark.parametrize("grid,thr,B", [((4, 5), 170.0, 2), ((9, 15), 150.0, 2)], ids=["N20", "N135"])
+def test_bf16_full_step_against_bf16_emulating_oracle(dev, grid, thr, B, train):
+    cfg = R.default_config(L_in=48, L_out=12, num_nodes=grid[0] * grid[1])
+    res = compare_forward_backward(cfg, B=B, grid=grid, threshold_km=thr, gat_graphs="per_timestep", seed=31,
+                                   train=train, precision="bf16")
+    assert_parity(res)
+    assert res["n_grads"] == sum(R.is_trainable(k) for k in R.init_params(cfg, 0))
+
+
+def test_bf16_train_mode_L96_six_tokens(dev):
+    """BASELINE configs[4] shape in the bf16 mode (6 tokens, head 4608 -> 1152 -> 24), training mode."""
+    cfg = R.default_config(L_in=96, L_out=24, num_nodes=20)
+    assert_parity(compare_forward_backward(cfg, B=2, grid=(4, 5), threshold_km=170.0, gat_graphs="per_timestep", seed=34,
+                                           train=True, precision="bf16"))
+
+
+def test_bf16_train_mode_full_size_graph_F10(dev):
+    """The bf16 configuration as `bench.py --precision bf16` times it, at B = 1: training mode, dropout at every site,
+    F = 10 / d_emb = 12, N = 2911, per-timestep graphs -- forward, loss and all 66 gradients against the emulating oracle."""
+    cfg = R.default_config(L_in=48, L_out=12, num_nodes=2911, c_in=10, d_emb=12)
+    assert_parity(compare_forward_backward(cfg, B=1, grid=(41, 71), gat_graphs="per_timestep", seed=35, train=True,
+                                           precision="bf16"))
+
+
+# ----------------------------------------------------------------------------------- 3. self-calibrated
+def test_bf16_device_is_as_close_to_the_oracle_as_the_oracle_is_to_itself(dev):
+    """The distance device <-> emulating oracle, per gradient tensor, against the oracle's own sensitivity: the same
+    oracle with x and every parameter perturbed by a relative 1e-6 (what separates the two implementations in fp32 mode:
+    summation order).  Both distances sit at the bf16 noise floor; the device must not be farther than 2x the oracle's own
+    wobble (+ a 2e-3 floor for tensors whose self-distance happens to be small), and on average not farther than 1.3x.
+    The FP32 oracle and the forward-only emulation are measurably farther away than the full emulation."""
+    grid, B = (9, 15), 2
+    N = grid[0] * grid[1]
+    cfg = R.default_config(L_in=48, L_out=12, num_nodes=N)
+    p = R.init_params(cfg, seed=51)
+    x, tf, y = R.synthetic_batch(B, 48, N, 6, 12, seed=151)
+    ei, _ = R.grid_graph(grid[0], grid[1])
+    model = build_model(cfg, p, dev, "per_timestep", precision="bf16").eval()
+    tfd = tf[:, :, 0, :].contiguous().to(dev).unsqueeze(-2).expand(B, 48, N, 4)
+    out = model(x.to(dev), tfd, ei.to(dev))
+    torch.nn.functional.huber_loss(out, y.to(dev)).backward()
+    named = dict(model.named_parameters())
+    out_o, _, g_o = oracle_step(cfg, p, x, tf, ei, y, None, q=R.BF16)
+    gen = torch.Generator().manual_seed(52)
+
+    def wobble(t):
+        return t * (1.0 + 1e-6 * torch.randn(t.shape, generator=gen)) if t.is_floating_point() else t
+    p2 = {k: wobble(v) for k, v in p.items()}
+    out_s, _, g_s = oracle_step(cfg, p2, wobble(x), tf, ei, y, None, q=R.BF16)
+    _, _, g_32 = oracle_step(cfg, p, x, tf, ei, y, None, q=R.FP32)
+    _, _, g_fo = oracle_step(cfg, p, x, tf, ei, y, None, q=R.BF16_FORWARD_ONLY)
+    keys = [k for k, g in g_o.items() if g.abs().max() > 0]
+    d_dev = np.array([l2_rel(named[k].grad, g_o[k]) for k in keys])
+    d_self = np.array([l2_rel(g_s[k], g_o[k]) for k in keys])
+    d_32 = np.array([l2_rel(named[k].grad, g_32[k]) for k in keys])
+    d_fo = np.array([l2_rel(named[k].grad, g_fo[k]) for k in keys])
+    worst = int(np.argmax(d_dev / (d_self + 1e-3)))
+    assert (d_dev <= 2.0 * d_self + 2e-3).all(), (keys[worst], d_dev[worst], d_self[worst])
+    assert d_dev.mean() <= 1.3 * d_self.mean(), (d_dev.mean(), d_self.mean())
+    assert l2_rel(out, out_o) <= 2.0 * l2_rel(out_s, out_o) + 2e-3
+    # ... and the emulation is the better model of what the device computes
+    assert d_dev.mean() < d_fo.mean() < d_32.mean(), (d_dev.mean(), d_fo.mean(), d_32.mean())

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import ref_cpu as R
-from tests.parity import assert_parity, build_model, compare_forward_backward, elem_err, oracle_step, rel_err
+from tests.parity import assert_close, assert_parity, build_model, compare_forward_backward, elem_err, oracle_step, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
@@ -55,7 +55,7 @@ def test_spatial_fwd_bwd_matches_oracle(dev, mode, grid, thr):
     ref_tm = ref.view(L, B, N, 22).permute(1, 0, 2, 3)
     out, ps, names = _run_spatial(p, x, tf, ei, dev, 1 if mode == "reference" else B * L)
     assert out.shape == (B, L, N, 24)
-    assert rel_err(out[..., :22], ref_tm) < TOL
+    assert_close(out[..., :22], ref_tm)
     assert float(out[..., 22:].abs().max()) == 0.0
     gout = torch.randn(B, L, N, 22, generator=torch.Generator().manual_seed(9))
     gref = torch.autograd.grad(ref_tm, [pr[n] for n in names], gout)
@@ -63,7 +63,7 @@ def test_spatial_fwd_bwd_matches_oracle(dev, mode, grid, thr):
     gpad[..., :22] = gout
     ghip = torch.autograd.grad(out, ps, gpad.to(dev))
     for n, a, b in zip(names, ghip, gref):
-        assert rel_err(a, b) < TOL, n
+        assert_close(a, b, n)
 
 
 def test_spatial_general_time_features_per_node(dev):
@@ -76,14 +76,14 @@ def test_spatial_general_time_features_per_node(dev):
     pr = {k: v.clone().requires_grad_(True) for k, v in p.items() if k.startswith((R.P_EMB, R.P_GAT))}
     ref = R.spatial(R.embed(x, tf, pr), ei, pr, 2, None).view(3, 2, 20, 22).permute(1, 0, 2, 3)
     out, ps, names = _run_spatial(p, x, tf, ei, dev, 6, tf_dev=tf.to(dev))
-    assert rel_err(out[..., :22], ref) < TOL
+    assert_close(out[..., :22], ref)
     gout = torch.randn(2, 3, 20, 22, generator=g)
     gref = torch.autograd.grad(ref, [pr[n] for n in names], gout)
     gpad = torch.zeros(2, 3, 20, 24)
     gpad[..., :22] = gout
     ghip = torch.autograd.grad(out, ps, gpad.to(dev))
     for n, a, b in zip(names, ghip, gref):
-        assert rel_err(a, b) < TOL, n
+        assert_close(a, b, n)
 
 
 def test_embedding_gather_bit_exact_against_reference_golden(dev, golden_dir):
@@ -114,9 +114,9 @@ def test_temporal_encoder_matches_reference_golden(dev, golden_dir, tag):
     te = te.to(dev)
     x = torch.from_numpy(g["x"]).to(dev)
     out = te(x)
-    assert rel_err(out, torch.from_numpy(g["out"])) < TOL
+    assert_close(out, torch.from_numpy(g["out"]))
     blk0 = te.conv_embedder.embedder[0](x.permute(0, 2, 1).contiguous())
-    assert rel_err(blk0, torch.from_numpy(g["block0"])) < TOL
+    assert_close(blk0, torch.from_numpy(g["block0"]))
 
 
 def test_prediction_head_matches_reference_golden(dev, golden_dir):
@@ -127,7 +127,7 @@ def test_prediction_head_matches_reference_golden(dev, golden_dir):
     ph = PredictionHead(2304, 12).eval()
     ph.load_state_dict({k[len("prediction_head."):]: v for k, v in p.items() if k.startswith("prediction_head.")})
     out = ph.to(dev)(torch.from_numpy(g["x"]).to(dev))
-    assert rel_err(out, torch.from_numpy(g["out"])) < TOL
+    assert_close(out, torch.from_numpy(g["out"]))
 
 
 @pytest.mark.parametrize("tag", ["T3", "T6"])
@@ -143,7 +143,7 @@ def test_gpt2_trunk_matches_transformers_golden(dev, golden_dir, tag):
         sd[f"model.base_model.model.h.{i}.attn.c_attn.lora_B.default.weight"] = torch.zeros(2304, 32)
     bb.load_state_dict(sd)
     out = bb.to(dev)(torch.from_numpy(g["x"]).to(dev), None)
-    assert rel_err(out, torch.from_numpy(g["out"])) < TOL
+    assert_close(out, torch.from_numpy(g["out"]))
 
 
 @pytest.mark.parametrize("mode", ["reference", "per_timestep"])
@@ -181,21 +181,21 @@ def test_full_step_L192_T12(dev):
 def test_full_size_graph_B1_against_oracle(dev):
     """BASELINE config shape (L_in=48, N=2911, E=20924) at B=1: forward + every trainable gradient."""
     cfg = R.default_config(L_in=48, L_out=12, num_nodes=2911)
-    assert_parity(compare_forward_backward(cfg, B=1, grid=(41, 71), gat_graphs="per_timestep", seed=7))
+    assert_parity(compare_forward_backward(cfg, B=1, grid=(41, 71), gat_graphs="per_timestep", seed=7), kink=True)
 
 
 def test_full_size_graph_F10_demb12_the_timed_workload(dev):
     """The workload bench.py times: raw feature width F = 10 with d_emb = 12 (still C = 22), N = 2911,
     per-timestep graphs -- forward, loss and every trainable gradient against the oracle, eval mode."""
     cfg = R.default_config(L_in=48, L_out=12, num_nodes=2911, c_in=10, d_emb=12)
-    assert_parity(compare_forward_backward(cfg, B=1, grid=(41, 71), gat_graphs="per_timestep", seed=13))
+    assert_parity(compare_forward_backward(cfg, B=1, grid=(41, 71), gat_graphs="per_timestep", seed=13), kink=True)
 
 
 def test_full_size_graph_L96_L24_stress_config(dev):
     """BASELINE configs[4] per-GPU shape at full graph size: L_in=96 / L_out=24 (6 tokens, head 4608 -> 1152 -> 24),
     N = 2911, F = 10."""
     cfg = R.default_config(L_in=96, L_out=24, num_nodes=2911, c_in=10, d_emb=12)
-    assert_parity(compare_forward_backward(cfg, B=1, grid=(41, 71), gat_graphs="per_timestep", seed=14))
+    assert_parity(compare_forward_backward(cfg, B=1, grid=(41, 71), gat_graphs="per_timestep", seed=14), kink=True)
 
 
 # ----------------------------------------------------------------------------- training mode (every dropout site on)
@@ -227,7 +227,7 @@ def test_train_mode_full_size_graph_F10_the_timed_configuration(dev):
     """Exactly what BENCH times, at B = 1: training mode, dropout p = 0.1 at every site, F = 10 / d_emb = 12,
     N = 2911, per-timestep graphs; forward, loss and all 66 trainable gradients within 1e-3 of the oracle."""
     cfg = R.default_config(L_in=48, L_out=12, num_nodes=2911, c_in=10, d_emb=12)
-    assert_parity(compare_forward_backward(cfg, B=1, grid=(41, 71), gat_graphs="per_timestep", seed=24, train=True))
+    assert_parity(compare_forward_backward(cfg, B=1, grid=(41, 71), gat_graphs="per_timestep", seed=24, train=True), kink=True)
 
 
 def test_gat_alpha_dropout_matches_oracle_alpha_mult(dev):
@@ -264,7 +264,7 @@ def test_gat_alpha_dropout_matches_oracle_alpha_mult(dev):
     gpad[..., :22] = gout
     ghip = torch.autograd.grad(out, ps, gpad.to(dev))
     for n, a, b in zip(names, ghip, gref):
-        assert rel_err(a, b) < TOL, n
+        assert_close(a, b, n)
 
 
 def test_three_arg_call_and_output_contract(dev):
@@ -337,26 +337,27 @@ def _bf16_inputs(cfg, B, grid, seed, thr=170.0):
 
 
 def test_bf16_forward_matches_bf16_emulating_oracle(dev):
-    """Operands of every GEMM the bf16 kernel serves are rounded to bf16 in the oracle too (ref_cpu.forward(q=...)).
-    What is left is summation order PLUS rounding flips: an activation that differs by 1 ulp(fp32) between the two
-    sides can round to a different bf16 value (a 2^-9 relative jump) before the next GEMM, so the bar is 1e-2 here
-    (observed 4e-3) -- an order of magnitude tighter than against the fp32 oracle.  The GEMM itself is checked
-    at 2e-4 against rounded operands in tests/test_gpu_bf16.py."""
+    """Operands of every GEMM the bf16 kernel serves are rounded to bf16 in the oracle too (ref_cpu.forward(q=R.BF16)).
+    What is left is summation order PLUS rounding flips amplified along the chain (tests/parity.py: RTOL_BF16_MODEL):
+    max-norm observed 4.7e-3.  Backward and the per-stage bars: tests/test_gpu_bf16_model.py.  The GEMM itself is checked at 2e-4 against rounded
+    operands in tests/test_gpu_bf16.py."""
+    from tests.parity import ATOL_RMS_BF16_MODEL, RTOL_BF16_MODEL
     cfg = R.default_config(L_in=48, L_out=12, num_nodes=20)
     p, x, tf, y, ei = _bf16_inputs(cfg, 2, (4, 5), seed=11)
-    ref = R.forward(x, tf, ei, p, cfg, None, q=R.bf16_round)
+    ref = R.forward(x, tf, ei, p, cfg, None, q=R.BF16)
     model = build_model(dict(cfg, precision="bf16"), p, dev, "per_timestep").eval()
     with torch.no_grad():
         out = model(x.to(dev), tf.to(dev), ei.to(dev))
         model.precision = "fp32"
         out32 = model(x.to(dev), tf.to(dev), ei.to(dev))
-    assert rel_err(out, ref) < 1e-2
+    assert_close(out, ref, "bf16 forward", RTOL_BF16_MODEL, ATOL_RMS_BF16_MODEL)
     assert rel_err(out32, ref) > rel_err(out, ref)     # fp32 mode is farther from the bf16 emulation than bf16 mode
 
 
 def test_bf16_autocast_selects_bf16_and_full_step_tracks_fp32_oracle(dev):
     """Under torch.autocast(bf16) (how train.py:68 calls the model) precision 'auto' picks the bf16 kernels.
-    Forward/backward vs the fp32 oracle within bf16 noise (operands carry 8 significant bits)."""
+    Forward/backward vs the FP32 oracle within bf16 noise (operands carry 8 significant bits): a sanity bound only --
+    the parity statement of the bf16 mode is the emulating-oracle tests below."""
     cfg = R.default_config(L_in=16, L_out=12, num_nodes=12)
     p, x, tf, y, ei = _bf16_inputs(cfg, 2, (3, 4), seed=12)
     out_ref, loss_ref, grads_ref = oracle_step(cfg, p, x, tf, ei, y, None)
@@ -373,6 +374,10 @@ def test_bf16_autocast_selects_bf16_and_full_step_tracks_fp32_oracle(dev):
     named = dict(model.named_parameters())
     worst = max(rel_err(named[k].grad, g) for k, g in grads_ref.items() if g.abs().max() > 0)
     assert worst < 8e-2, worst
+    # the same gradients against the oracle that rounds what the device rounds: an order of magnitude closer
+    _, _, grads_16 = oracle_step(cfg, p, x, tf, ei, y, None, q=R.BF16)
+    worst16 = max(rel_err(named[k].grad, g) for k, g in grads_16.items() if g.abs().max() > 0)
+    assert worst16 < 1e-2 and worst16 < worst, (worst16, worst)
 
 
 def test_frozen_weight_transposes_follow_the_parameter(dev):
@@ -403,15 +408,17 @@ def test_frozen_weight_transposes_follow_the_parameter(dev):
     assert rel_err(b, R.forward(x, tf, ei, p2, cfg, None)) < 1e-3
 
 
-def test_full_size_batch_of_8_properties(dev):
-    """BASELINE configs[1] size (B=8, L_in=48, N=2911, F=10) through properties that need no oracle run:
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_full_size_batch_of_8_properties(dev, precision):
+    """BASELINE configs[1] / configs[2] size (B=8, L_in=48, N=2911, F=10; fp32 and bf16 mode) through properties that need
+    no oracle run:
     samples are independent (row b of the batch == the same sample run alone, bit for bit: no kernel mixes rows of
     different samples and none of the forward kernels uses atomics), the batch order is irrelevant, eval forward
     is deterministic, and the train-mode dropout masks are a pure function of (torch seed, forward-call count, position)."""
     cfg = R.default_config(L_in=48, L_out=12, num_nodes=2911, c_in=10, d_emb=12)
     p = R.init_params(cfg, seed=4)
-    model = build_model(cfg, p, dev, "per_timestep").eval()
-    x, tf, _ = R.synthetic_batch(8, 48, 2911, 10, 12, seed=77)
+    model = build_model(cfg, p, dev, "per_timestep", precision=precision).eval()
+    x, tf, y = R.synthetic_batch(8, 48, 2911, 10, 12, seed=77)
     ei = R.grid_graph()[0].to(dev)
     xd = x.to(dev)
     tfd = tf[:, :, 0, :].contiguous().to(dev).unsqueeze(-2).expand(8, 48, 2911, 4)
@@ -430,7 +437,9 @@ def test_full_size_batch_of_8_properties(dev):
         # the same time features materialised per node take the general path (embedding rows rebuilt per graph instead
         # of the temporal embedding folded into the bias): another fp32 association of the same sum
         general = model(xd[perm], tfd[perm], ei)
-        assert tfd[perm].stride(2) != 0 and rel_err(general, full[perm]) < 1e-5
+        # (bf16 mode: a 1e-7 difference in the spatial stage's output is amplified to the bf16 noise floor by the chain
+        # of roundings behind it -- tests/parity.py, RTOL_BF16_MODEL)
+        assert tfd[perm].stride(2) != 0 and rel_err(general, full[perm]) < (1e-5 if precision == "fp32" else 2e-2)
     from src.model import modules as M_
     model.train()
 
@@ -438,8 +447,24 @@ def test_full_size_batch_of_8_properties(dev):
         torch.manual_seed(seed)
         M_._seed_counter[0] = call                                        # mask seed = f(torch seed, forward-call count)
         return model(xd[:2], tfd[:2], ei)
-    a, b_, c, d_ = run(11, 0), run(11, 0), run(12, 0), run(11, 1)
+    with torch.no_grad():
+        a, b_, c, d_ = run(11, 0), run(11, 0), run(12, 0), run(11, 1)
     assert torch.equal(a, b_) and not torch.equal(a, c) and not torch.equal(a, d_)
+
+    # the full training-mode backward at B = 8: everything behind the spatial stage (55 tensors: split-K slabs and
+    # per-block partial rows reduced in a fixed order) is bit-deterministic; the 11 tensors of the spatial stage
+    # (embedding tables, GATv2) are accumulated with float atomics (csrc/spatial_bwd.hip) and repeat to 1e-5
+    def grads():
+        model.zero_grad(set_to_none=True)
+        torch.nn.functional.huber_loss(run(11, 0), y[:2].to(dev)).backward()
+        return {k: v.grad.clone() for k, v in model.named_parameters() if v.grad is not None}
+    g1, g2 = grads(), grads()
+    assert len(g1) == 66 and all(torch.isfinite(v).all() for v in g1.values())
+    spatial = [k for k in g1 if k.startswith(("spatio_temporal_embedding.", "spatial_encoder."))]
+    assert len(spatial) == 11
+    assert all(torch.equal(g1[k], g2[k]) for k in g1 if k not in spatial), \
+        [k for k in g1 if k not in spatial and not torch.equal(g1[k], g2[k])]
+    assert all(rel_err(g1[k], g2[k]) < 1e-5 for k in spatial), [(k, rel_err(g1[k], g2[k])) for k in spatial]
 
 
 @pytest.mark.parametrize("kind", ["no_edges", "irregular"])
@@ -467,14 +492,14 @@ def test_spatial_irregular_graphs(dev, kind):
     ref = R.spatial(R.embed(x, tf, pr), ei, pr, 2, None)
     ref_tm = ref.view(L, B, N, 22).permute(1, 0, 2, 3)
     out, ps, names = _run_spatial(p, x, tf, ei, dev, B * L)
-    assert rel_err(out[..., :22], ref_tm) < TOL
+    assert_close(out[..., :22], ref_tm)
     gout = torch.randn(B, L, N, 22, generator=torch.Generator().manual_seed(11))
     gref = torch.autograd.grad(ref_tm, [pr[n] for n in names], gout)
     gpad = torch.zeros(B, L, N, 24)
     gpad[..., :22] = gout
     ghip = torch.autograd.grad(out, ps, gpad.to(dev))
     for n, a, b in zip(names, ghip, gref):
-        assert rel_err(a, b) < TOL, n
+        assert_close(a, b, n)
 
 
 def test_out_of_range_time_index_is_rejected_not_clamped(dev):
@@ -588,6 +613,6 @@ def test_standalone_spatial_encoder_forward_backward(dev, mode):
     gref = torch.autograd.grad(ref, [pr[n] for n in names], gout)
     ghip = torch.autograd.grad(out, list(enc.params()), gout.to(dev))
     for n, a, b in zip(names, ghip, gref):
-        assert rel_err(a, b) < TOL, n
+        assert_close(a, b, n)
     with pytest.raises(Exception):
         enc(x.to(dev).requires_grad_(True), ei.to(dev)).sum().backward()   # d x is not part of the MI355X path

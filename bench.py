@@ -11,7 +11,9 @@ checksums riding in its tail) + clip(1.0) + AdamW + cosine-warm-restart schedule
 site active), inputs resident in HBM.  Weak scaling: every rank processes `--batch` (default 8) samples;
 value = all samples / max-over-ranks time.  Rank 0 prints ONE JSON line carrying `roofline` (dominant kernel,
 measured with events on the launch stream inside the timed region) and, at N=1, `cpu_baseline` (the CPU oracle's
-train step timed on the host cores of this box) and `configs_extra.bf16` (BASELINE configs[2] with its own roofline).
+train step timed on the host cores of this box) and `configs_extra` (BASELINE configs[2] = bf16 and the configs[4]
+per-GPU shape L_in=96 / L_out=24, each with its own roofline).  N > 1: `config.dist` carries the event-timed all-reduce
+(`allreduce_ms`) and the per-rank step times.
 """
 from __future__ import annotations
 
@@ -54,11 +56,43 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU train steps after one warm-up step")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-other-precisions", action="store_true",
-                    help="skip the short runs of the other precision modes (N=1, default flags only)")
+                    help="skip configs_extra (the bf16 and L_in=96 legs that follow the main run at N=1 with default flags)")
+    ap.add_argument("--emulation-modes", action="store_true",
+                    help="also time the opt-in bf16x6 / bf16x3 modes (context only; not part of the default run)")
+    ap.add_argument("--data", choices=["fixed", "window"], default="fixed",
+                    help="fixed: one resident batch (default).  window: every step's batch is drawn by the device "
+                         "window sampler (tecm_window_batch) from a resident synthetic series, as train.py:57-65 "
+                         "draws it from the DataLoader")
     return ap.parse_args()
 
 
 # ------------------------------------------------------------------------------------------ N-rank launcher
+def visible_gpus():
+    """Number of GPUs this process tree may use, WITHOUT touching the HIP runtime (the launcher parent must stay a
+    process that never initialised the GPU): GPU nodes of the KFD topology in sysfs (CPU nodes have simd_count 0),
+    narrowed by ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when set.  None when the topology
+    is not readable (then nothing is checked here and a rank that finds no device fails on its own)."""
+    root = os.environ.get("TECM_KFD_TOPOLOGY", "/sys/class/kfd/kfd/topology/nodes")
+    try:
+        nodes = sorted(os.listdir(root))
+    except OSError:
+        return None
+    n = 0
+    for node in nodes:
+        try:
+            with open(os.path.join(root, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([t for t in v.split(",") if t.strip() != ""]))
+    return n
+
+
 def launch_ranks(args) -> int:
     """`python bench.py --gpus N` without torchrun: start N fresh rank processes (one per GPU) of this same script and
     relay rank 0's JSON line.  Runs BEFORE anything in this process touches the GPU -- a process that has initialised
@@ -66,8 +100,8 @@ def launch_ranks(args) -> int:
     process waits for them and exits with the first non-zero code (killing the exact PIDs it started)."""
     n = args.gpus
     backend = os.environ.get("TECM_DIST_BACKEND", "nccl")
-    visible = torch.cuda.device_count()            # counting devices does not initialise HIP on this image
-    if backend == "nccl" and visible < n:
+    visible = visible_gpus()                       # sysfs only: this process never loads the HIP runtime
+    if backend == "nccl" and visible is not None and visible < n:
         print(f"bench.py: --gpus {n} needs {n} visible GPUs for RCCL (one rank per device), found {visible}",
               file=sys.stderr)
         return 2
@@ -136,7 +170,7 @@ def pmc_traffic(kernel: str, args, precision: str):
     committed passes do not cover this configuration."""
     if args.batch != 8 or args.L_in != 48 or args.gat != "per_timestep" or precision not in ("fp32", "bf16"):
         return None
-    for tag in ("r02", "r01"):
+    for tag in ("r03", "r02", "r01"):
         rel = os.path.join("profiles", f"{tag}_pmc_traffic_{precision}_B8.json")
         try:
             with open(os.path.join(ROOT, rel)) as f:
@@ -237,14 +271,18 @@ def roofline_of(agg: dict, dt_s: float, args, precision: str):
             "all_gemm_share_of_step": round(sum(v["ms"] for v in agg.values()) / (dt_s * 1e3), 4)}
 
 
-def other_precision(cfg, args, dev, mode, x, tf, ei, ew, y, with_roofline=False):
-    """samples/s of the same step in another precision mode of the library:
-    "bf16" = autocast semantics (BASELINE configs[2]; reported with its own roofline), "bf16x6" / "bf16x3" = fp32
-    emulated by six / three bf16 MFMAs per product (opt-in modes, reported for context only)."""
+def extra_config(cfg, args, dev, mode, ei, ew, workload, L_in=None, L_out=None, with_roofline=True, steps=10):
+    """samples/s of one more BASELINE configuration, measured after the main run with its own roofline:
+    mode "bf16" = autocast semantics (BASELINE configs[2]); L_in / L_out = the stress shape of configs[4] on one GPU;
+    "bf16x6" / "bf16x3" (only with --emulation-modes) = fp32 emulated by six / three bf16 MFMAs per product."""
     from src.model.tec_mollm import TEC_MoLLM
     from tecmollm import ops
+    from tecmollm.synthetic import synthetic_batch
     from tecmollm.train import TrainStep
-    mc = dict(cfg, gat_graphs=args.gat, include_wte=False, load_pretrained_gpt2=False, precision=mode)
+    a2 = argparse.Namespace(**vars(args))
+    a2.L_in, a2.L_out = L_in or args.L_in, L_out or args.L_out
+    cfg2 = make_config(a2)
+    mc = dict(cfg2, gat_graphs=args.gat, include_wte=False, load_pretrained_gpt2=False, precision=mode)
     torch.manual_seed(0)
     model = TEC_MoLLM(mc)
     with torch.no_grad():
@@ -252,25 +290,68 @@ def other_precision(cfg, args, dev, mode, x, tf, ei, ew, y, with_roofline=False)
             blk.attn.c_attn.lora_B.default.weight.normal_(std=0.02)
     model = model.to(dev)
     model.train(not args.eval_mode)
+    B = args.batch
+    x, tf, y = synthetic_batch(B, a2.L_in, 2911, args.c_in, a2.L_out, seed=1234)
+    x, y = x.to(dev), y.to(dev)
+    tf = tf[:, :, 0, :].contiguous().to(dev).unsqueeze(-2).expand(B, a2.L_in, 2911, 4)
     ts = TrainStep(model, world_size=1)
-    n = 10 if with_roofline else 5
     for _ in range(3):
         ts.step(x, tf, ei, ew, y)
     torch.cuda.synchronize()
     prof = ops.enable_gemm_timing() if with_roofline else None
     t0 = time.perf_counter()
-    for _ in range(n):
+    for _ in range(steps):
         ts.step(x, tf, ei, ew, y)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ops.disable_gemm_timing()
-    res = {"samples_per_s": round(n * x.shape[0] / dt, 2), "ms_per_step": round(dt / n * 1e3, 2), "steps": n}
+    res = {"samples_per_s": round(steps * B / dt, 2), "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps,
+           "dtype": {"fp32": "f32"}.get(mode, mode), "workload": workload}
     if with_roofline:
-        res["dtype"] = "bf16"
-        res["workload"] = "BASELINE configs[2]: the same step with every dense contraction the bf16 kernel serves on the " \
-                          "bf16 matrix cores (operands rounded to bf16, fp32 accumulate; norms / softmax / GATv2 fp32)"
-        res["roofline"] = roofline_of(ops.summarize_gemm_timing(prof), dt, args, "bf16")
+        a2.precision = mode
+        res["roofline"] = roofline_of(ops.summarize_gemm_timing(prof), dt, a2, mode)
+    del ts, model
+    torch.cuda.empty_cache()
     return res
+
+
+class WindowFeed:
+    """--data window: a synthetic series resident in HBM (T time steps of the 41 x 71 grid) behind the device mirror of
+    the reference's SlidingWindowSamplerDataset (src/data/dataset.py:65-99); every step draws its batch of B windows
+    with ONE launch of tecm_window_batch, as the DataLoader + collate + H2D + reshapes of train.py:57-65 would."""
+
+    def __init__(self, args, dev, rank, steps_total):
+        from src.data.dataset import SlidingWindowSamplerDataset
+        T = args.L_in + args.L_out + 256
+        g = torch.Generator().manual_seed(4321 + rank)
+        X = torch.randn(T, 41, 71, args.c_in, generator=g)
+        Y = torch.randn(T, 41, 71, args.L_out, generator=g)
+        hours = torch.arange(T)
+        tfeat = torch.stack([(hours % 24) // 2, (hours // 24) % 366, (hours // (24 * 366)) % 13,
+                             ((hours // 24) % 366) // 92], -1).float()
+        self.ds = SlidingWindowSamplerDataset.from_tensors(X, Y, tfeat, args.L_in, args.L_out, stride=1, device=dev)
+        self.B = args.batch
+        perm = torch.randperm(len(self.ds), generator=g)
+        need = steps_total * self.B
+        self.order = perm.repeat((need + len(perm) - 1) // len(perm))[:need].tolist()
+        self.i = 0
+        self.events = []
+
+    def next(self, timed: bool):
+        idx = self.order[self.i * self.B:(self.i + 1) * self.B]
+        self.i += 1
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        x, tf, y = self.ds.batch(idx)
+        if timed:
+            e1.record()
+            self.events.append((e0, e1))
+        return x, tf, y
+
+    def ms_per_step(self):
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self.events) / max(len(self.events), 1)
 
 
 def main():
@@ -328,7 +409,15 @@ def main():
     tf = tf[:, :, 0, :].contiguous().to(dev).unsqueeze(-2).expand(B, args.L_in, 2911, 4)   # train.py:65
     ei, ew = grid_graph()
     ei, ew = ei.to(dev), ew.to(dev)
-    ts = TrainStep(model, world_size=world)            # ... and rank 0's parameters broadcast anyway (train.py:354)
+    t_setup = time.perf_counter()
+    from tecmollm import graph as graph_
+    graph_.get(ei, 2911, dev, 22 - args.c_in)          # host-side CSR / tile windows of the graph (cached per process)
+    host_graph_s = time.perf_counter() - t_setup
+    ts = TrainStep(model, world_size=world, time_collective=True)   # rank 0's parameters broadcast (train.py:354)
+    feed = WindowFeed(args, dev, rank, args.warmup + args.steps) if args.data == "window" else None
+
+    def batch(timed):
+        return feed.next(timed) if feed is not None else (x, tf, y)
 
     def barrier():
         if world > 1:
@@ -339,18 +428,42 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        ts.step(x, tf, ei, ew, y)
+        xb, tfb, yb = batch(False)
+        ts.step(xb, tfb, ei, ew, yb)
     barrier()
+    ts.reset_collective_timing()
     prof = None if args.no_kernel_timing else ops.enable_gemm_timing()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = ts.step(x, tf, ei, ew, y)
+    marks[0].record()
+    for i in range(args.steps):
+        xb, tfb, yb = batch(True)
+        loss = ts.step(xb, tfb, ei, ew, yb)
+        marks[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
     ops.disable_gemm_timing()
     check_device_errors(dev, sync=True)                # bad time indices / diverged ranks reported by any step
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]      # this rank's device time per step
     if world > 1:
+        coll = ts.collective_ms()
+        mine = torch.tensor([sum(step_ms) / len(step_ms), min(step_ms), max(step_ms),
+                             sum(coll) / max(len(coll), 1), max(coll) if coll else 0.0], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        allr = torch.stack(allr).cpu()
+        dist_info["allreduce_ms"] = {"mean_over_ranks": round(float(allr[:, 3].mean()), 4),
+                                     "max_over_ranks": round(float(allr[:, 4].max()), 4),
+                                     "per_rank_mean": [round(float(v), 4) for v in allr[:, 3]],
+                                     "bytes": int(ts.flat_grad_ext.numel() * 4), "launches": len(coll),
+                                     "note": "events on the launch stream around the ONE all-reduce of the step (flat "
+                                             "fp32 gradient + per-rank parameter checksums); includes waiting for the "
+                                             "slowest rank to arrive"}
+        dist_info["step_ms_per_rank"] = {"mean": [round(float(v), 3) for v in allr[:, 0]],
+                                         "min_over_ranks": round(float(allr[:, 0].min()), 3),
+                                         "max_over_ranks": round(float(allr[:, 0].max()), 3),
+                                         "slowest_single_step": round(float(allr[:, 2].max()), 3)}
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         csum = ts._param_checksum().reshape(1)
         lo, hi = csum.clone(), csum.clone()
@@ -375,20 +488,40 @@ def main():
                                    f"{PRECISION_TEXT[args.precision]}, "
                                    f"GATv2 {args.gat}, dropout {'off' if args.eval_mode else 'on (p=0.1)'}",
                        "global_batch": B * world, "parallelism": f"dp{world}", "final_loss": round(float(loss), 5),
-                       "peak_hbm_gb_per_gpu": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)},
+                       "peak_hbm_gb_per_gpu": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
+                       "data_feed": args.data, "host_graph_build_s": round(host_graph_s, 3),
+                       "step_ms_min_max": [round(min(step_ms), 3), round(max(step_ms), 3)]},
             "roofline": roof,
         }
+        if feed is not None:
+            d_ms = feed.ms_per_step()
+            line["config"]["data_feed_ms_per_step"] = round(d_ms, 4)
+            line["config"]["data_feed_share_of_step"] = round(d_ms / (dt / args.steps * 1e3), 5)
         if dist_info is not None:
             line["config"]["dist"] = dist_info
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"], ref = cpu_baseline(cfg, args)
             line["parity"] = rmse_vs_ref(cfg, args, dev, ref)
-        if world == 1 and args.precision == "fp32" and not args.no_other_precisions:
-            # `value` above is the exact-fp32 number (BASELINE configs[1]).  configs[2] (bf16 autocast semantics) is
-            # measured here on the same workload with its own roofline; the emulation modes are context only.
-            line["configs_extra"] = {"bf16": other_precision(cfg, args, dev, "bf16", x, tf, ei, ew, y, True)}
-            line["other_precisions"] = {m: other_precision(cfg, args, dev, m, x, tf, ei, ew, y)
-                                        for m in ("bf16x6", "bf16x3")}
+        default_shape = args.L_in == 48 and args.L_out == 12 and args.data == "fixed"
+        if world == 1 and args.precision == "fp32" and default_shape and not args.no_other_precisions:
+            # `value` above is the exact-fp32 number (BASELINE configs[1]).  Two more BASELINE configurations are
+            # measured here, each with its own roofline: configs[2] (bf16 autocast semantics, same workload) and the
+            # per-GPU shape of configs[4] (L_in = 96 / L_out = 24: twice the rows and tokens per sample), fp32.
+            del ts, model
+            torch.cuda.empty_cache()
+            line["configs_extra"] = {
+                "bf16": extra_config(cfg, args, dev, "bf16", ei, ew,
+                                     "BASELINE configs[2]: the same step with every dense contraction the bf16 kernel "
+                                     "serves on the bf16 matrix cores (operands rounded to bf16, fp32 accumulate; "
+                                     "norms / softmax / GATv2 fp32)"),
+                "L96": extra_config(cfg, args, dev, "fp32", ei, ew,
+                                    f"BASELINE configs[4] per-GPU shape: B={B}, L_in=96, L_out=24 (6 tokens per "
+                                    f"sequence, head 4608 -> 1152 -> 24), N=2911, F={args.c_in}, fp32, full "
+                                    f"fwd+bwd+AdamW, GATv2 {args.gat}, dropout on", L_in=96, L_out=24)}
+            if args.emulation_modes:
+                line["other_precisions"] = {m: extra_config(cfg, args, dev, m, ei, ew, PRECISION_TEXT[m],
+                                                            with_roofline=False, steps=5)
+                                            for m in ("bf16x6", "bf16x3")}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

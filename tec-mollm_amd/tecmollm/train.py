@@ -67,7 +67,8 @@ class TrainStep:
 
     def __init__(self, model: torch.nn.Module, lr: float = 1e-4, weight_decay: float = 1e-2, max_norm: float = 1.0,
                  accumulation_steps: int = 1, world_size: int = 1, group=None, fused_huber: bool = True,
-                 optimizer: str = "native", broadcast_init: bool = True, check_divergence: bool = True):
+                 optimizer: str = "native", broadcast_init: bool = True, check_divergence: bool = True,
+                 time_collective: bool = False):
         if optimizer not in ("native", "torch"):
             raise ValueError("optimizer must be 'native' or 'torch'")
         self.model = model
@@ -102,6 +103,23 @@ class TrainStep:
             self.scheduler = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(self.optimizer, T_0=10, T_mult=2,
                                                                                  eta_min=1e-7)
         self._micro = 0
+        # time_collective: bracket the one collective of the step with events on the stream it is enqueued behind
+        # (RCCL runs it on its own stream; the current stream waits for it, so the bracket covers it) -- bench.py
+        # reports it as dist.allreduce_ms so that a scaling curve can separate communication from compute
+        self.time_collective = bool(time_collective) and world_size > 1
+        self._coll_events: list = []
+        self._coll_host_s: list = []
+
+    def collective_ms(self) -> List[float]:
+        """Duration of every timed all-reduce so far (ms): device events for GPU tensors, host clock for CPU ones."""
+        if self._coll_events:
+            torch.cuda.synchronize()
+            return [a.elapsed_time(b) for a, b in self._coll_events]
+        return [1e3 * t for t in self._coll_host_s]
+
+    def reset_collective_timing(self) -> None:
+        self._coll_events.clear()
+        self._coll_host_s.clear()
 
     def _loss(self, out: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
         if self.fused_huber:
@@ -137,6 +155,22 @@ class TrainStep:
         per-rank parameter checksums in its tail."""
         if self.world_size == 1:
             return
+        if self.time_collective:
+            import time
+            if self.flat_grad.is_cuda:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self._allreduce_grads_untimed()
+                e1.record()
+                self._coll_events.append((e0, e1))
+            else:
+                t0 = time.perf_counter()
+                self._allreduce_grads_untimed()
+                self._coll_host_s.append(time.perf_counter() - t0)
+            return
+        self._allreduce_grads_untimed()
+
+    def _allreduce_grads_untimed(self) -> None:
         if not self.check_divergence:
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
             return

@@ -405,6 +405,51 @@ def test_bench_py_starts_its_own_ranks(dev):
     d = line["config"]["dist"]
     assert d["world_size"] == 2 and d["allreduce_of_ones"] == 2.0 and d["launcher"] == "bench.py"
     assert d["param_checksum_min_eq_max"] is True and line["value"] > 0
+    # the collective is event-timed on every rank and the per-rank step times ride in the same line, so that a scaling
+    # record can separate communication from compute
+    ar = d["allreduce_ms"]
+    assert ar["launches"] == 2 and len(ar["per_rank_mean"]) == 2 and 0 < ar["mean_over_ranks"] <= ar["max_over_ranks"]
+    assert ar["bytes"] >= 4 * 3_000_000                 # 3.07 M trainable values at F = 10 / d_emb = 12
+    sm = d["step_ms_per_rank"]
+    assert len(sm["mean"]) == 2 and 0 < sm["min_over_ranks"] <= sm["max_over_ranks"] <= sm["slowest_single_step"] * 1.0001
+
+
+def _bench_line(extra, env_extra=None, launcher=None):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    cmd = (launcher or [sys.executable]) + [os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-other-precisions",
+                                            *extra]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_n1_through_the_launcher_environment_reproduces_the_plain_run(dev):
+    """The driver starts N = 1 as plain `python bench.py` and N > 1 through torch.distributed.run; the one-rank case of the
+    launcher path (RANK=0, WORLD_SIZE=1 in the environment) must be the same measurement: within 2 %, best of two runs
+    each (box noise on this pool is about 1 %)."""
+    flags = ["--steps", "10", "--warmup", "3"]
+    tr = {"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29517"}
+    plain = max(_bench_line(flags)["value"] for _ in range(2))
+    under = max(_bench_line(flags, tr)["value"] for _ in range(2))
+    assert abs(under - plain) / plain < 0.02, (plain, under)
+
+
+def test_bench_window_feed_costs_less_than_one_percent(dev):
+    """--data window: every step's batch drawn by tecm_window_batch from a resident series (train.py:57-65): the sampler
+    is event-timed inside the timed region and must cost < 1 % of the step; throughput within 2 % of the fixed batch."""
+    flags = ["--steps", "10", "--warmup", "3"]
+    win = _bench_line(flags + ["--data", "window"])
+    assert win["config"]["data_feed"] == "window"
+    assert 0 < win["config"]["data_feed_share_of_step"] < 0.01, win["config"]
+    fixed = _bench_line(flags)
+    assert win["value"] > 0.98 * fixed["value"], (win["value"], fixed["value"])
 
 
 def test_rccl_process_group_runs_on_this_gpu(dev):

@@ -456,3 +456,29 @@ def test_synthetic_inputs_do_not_come_from_the_oracle():
             if f.endswith(".py"):
                 txt = open(os.path.join(root, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, os.path.join(root, f)
+
+
+def test_bench_counts_gpus_from_sysfs_without_the_hip_runtime(tmp_path, monkeypatch):
+    """bench.py's launcher parent must never touch the HIP runtime: it counts GPU nodes of the KFD topology in sysfs
+    (CPU nodes have simd_count 0) and honours the *_VISIBLE_DEVICES variables."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for i, simd in enumerate((0, 0, 1024, 1024, 1024)):              # two CPU sockets, three GPUs
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text(f"cpu_cores_count {64 if simd == 0 else 0}\nsimd_count {simd}\nmem_banks_count 1\n")
+    monkeypatch.setenv("TECM_KFD_TOPOLOGY", str(tmp_path))
+    for v in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(v, raising=False)
+    assert bench.visible_gpus() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert bench.visible_gpus() == 2
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "")
+    assert bench.visible_gpus() == 0
+    monkeypatch.setenv("TECM_KFD_TOPOLOGY", str(tmp_path / "missing"))
+    assert bench.visible_gpus() is None
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    launcher = src[src.index("def launch_ranks"):src.index("def make_config")]
+    assert "torch.cuda" not in launcher                               # the parent never asks the runtime

@@ -191,6 +191,144 @@ __global__ __launch_bounds__(DNTH, 1) void gemm_bf16_dma_kernel(const TecmGemm g
 #endif
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Second geometry, for matrices whose width the 256-column tile quantises badly (N = 800, the dX of c_attn: four
+// n-tiles of which the last is 32 / 256 wide): 256 x 128 x 32 tiles, 8 waves as 4(m) x 2(n) of 64 x 64 (2 x 2 MFMA tiles,
+// 64 accumulators), a THREE-slot LDS ring of 24 KiB K-tiles (72 KiB) and at most 128 registers per lane, so that TWO
+// blocks = 16 waves share a CU.  Measured against the 256 x 256 kernel (M = 69 864, us per launch, round 3,
+// tools/dma_ab.sh): N=800 K=2304 375 vs 402 (-7 %), N=2304 K=800 374 vs 381, N=768 K=768 136 vs 138, fc1 form 680 vs
+// 683, GELU' form 797 vs 729, N=768 K=3072 491 vs 437, 8192^3 1196 vs 1006 -- it only pays where it removes column
+// waste, so the dispatcher uses it for N % 256 in [1, 128] and nothing else.  What it does NOT do is hide one block's
+// epilogue under the other block's K loop (the reason it was built): two co-resident blocks started together run in
+// lockstep, and neither a start-up stagger of the odd block of a CU (per-CU arrival tickets), nor persistent blocks,
+// nor pacing the epilogue's stores with s_sleep changed a launch by more than noise (tools/experiments/README.md).
+//   * K-tile = 256 + 128 rows of 64 B: 24 DMA pieces of 16 rows x 64 B, three per wave; lane -> (row 16p + lane/4,
+//     position lane%4), the chunk fetched into a position is position ^ ((row >> 2) & 3) -- with 64-byte rows the four
+//     16-lane groups of a ds_read_b128 then cover all 64 banks once;
+//   * ring: tiles t+1 and t+2 are in flight while tile t is multiplied; `s_waitcnt vmcnt(3)` (the three youngest DMAs
+//     = tile t+1) + one barrier per K-tile; the slot refilled at step t was last read at step t-1, which every wave has
+//     left when it passes the barrier of step t.
+constexpr int D2M = 256, D2N = 128, D2K = 32, D2TH = 512, D2ST = 3;
+
+__global__ __launch_bounds__(D2TH, 4) void gemm_bf16_dma2_kernel(const TecmGemm g, int tiles_m, int tiles_n) {
+  constexpr int WM = 4, WN = 2;
+  constexpr int WTM = D2M / WM, WTN = D2N / WN;        // 64 x 64 per wave
+  constexpr int MT = WTM / 32, NT = WTN / 32;          // 2 x 2
+  constexpr int A_ELEMS = D2M * D2K, B_ELEMS = D2N * D2K, TILE_ELEMS = A_ELEMS + B_ELEMS;   // 24 KiB
+  constexpr int PIECE = 16 * D2K;                      // 16 rows of 64 B = 1 KiB
+  __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[D2ST * TILE_ELEMS * 2];
+  __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);
+  static_assert(D2ST * TILE_ELEMS * 2 >= 8 * 32 * (WTN + 4) * 4, "epilogue slabs fit in the operand ring");
+
+  const int nwg = tiles_m * tiles_n;
+  const int id = blockIdx.x;
+  const int xcd = id & 7, local = id >> 3;
+  const int q8 = nwg >> 3, r8 = nwg & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
+  const int GROUP_M = g._p1 > 0 ? g._p1 : 4;
+  const int per_group = GROUP_M * tiles_n;
+  const int group = wg / per_group;
+  const int first_m = group * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int in_group = wg - group * per_group;
+  const int tm = first_m + in_group % gsz, tn = in_group / gsz;
+  const int64_t m0 = (int64_t)tm * D2M;
+  const int64_t n0 = (int64_t)tn * D2N;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 31, h = lane >> 5;
+  const int ntiles = (int)g.K / D2K;                   // K % 32 == 0 (host)
+
+  // pieces 0..15 = A rows 16p.., pieces 16..23 = B rows; wave w moves pieces w, w + 8, w + 16
+  const __bf16* Ah = reinterpret_cast<const __bf16*>(g.A);
+  const __bf16* Bh = reinterpret_cast<const __bf16*>(g.B);
+  const __bf16* src[3];
+  int dst[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int p = wave + 8 * i;
+    const bool isb = p >= 16;
+    const int row = (isb ? p - 16 : p) * 16 + (lane >> 2);
+    const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+    if (!isb) {
+      int64_t gm = m0 + row;
+      gm = gm < g.M ? gm : g.M - 1;                    // clamped rows feed accumulator rows that are never stored
+      src[i] = Ah + gm * g.lda + chunk * 8;
+      dst[i] = p * PIECE;
+    } else {
+      int64_t gn = n0 + row;
+      gn = gn < g.N ? gn : g.N - 1;
+      src[i] = Bh + gn * g.ldb + chunk * 8;
+      dst[i] = A_ELEMS + (p - 16) * PIECE;
+    }
+  }
+  auto issue_tile = [&](int slot) {
+    __bf16* buf = smem + slot * TILE_ELEMS;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      dma16(src[i], buf + dst[i]);
+      src[i] += D2K;
+    }
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  int a_off[MT], b_off[NT], a_sw[MT], b_sw[NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int row = wm * WTM + i * 32 + r;
+    a_off[i] = row * D2K;
+    a_sw[i] = (row >> 2) & 3;
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int row = wn * WTN + j * 32 + r;
+    b_off[j] = A_ELEMS + row * D2K;
+    b_sw[j] = (row >> 2) & 3;
+  }
+  auto read_frags = [&](const __bf16* T, int s_, bf16x8 (&af)[MT], bf16x8 (&bf)[NT]) {
+    const int c = 2 * s_ + h;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(T + a_off[i] + ((c ^ a_sw[i]) << 3));
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(T + b_off[j] + ((c ^ b_sw[j]) << 3));
+  };
+  auto do_mfma = [&](const bf16x8 (&af)[MT], const bf16x8 (&bf)[NT]) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+  };
+
+  issue_tile(0);
+  if (ntiles > 1) issue_tile(1);
+  int slot = 0;
+  bf16x8 fa[2][MT], fb[2][NT];
+  for (int t = 0; t < ntiles; ++t) {
+    // tile t has landed once at most the DMAs of tile t+1 (the three youngest) are outstanding
+    if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 < ntiles) issue_tile(slot == 0 ? 2 : slot - 1);      // slot (t + 2) % 3
+    const __bf16* Tc = smem + slot * TILE_ELEMS;
+    read_frags(Tc, 0, fa[0], fb[0]);
+    read_frags(Tc, 1, fa[1], fb[1]);
+    do_mfma(fa[0], fb[0]);
+    do_mfma(fa[1], fb[1]);
+    slot = slot == 2 ? 0 : slot + 1;
+  }
+  __syncthreads();                                      // every wave has left the last K-tile: the ring becomes staging
+  block_epilogue16<MT, NT, WTM, WTN, true, true>(g, acc, smem_raw, wave, lane, wm, wn, m0, n0);
+}
+
 }  // namespace tecm_gemm16
 
 // Returns the number of K splits (1) when the DMA kernel served the call, 0 when the call is not eligible.
@@ -201,6 +339,16 @@ int tecm_gemm16_dma_try(const TecmGemm& g, hipStream_t st) {
   const bool both = (g.io_bf16 & TECM_IO_A_BF16) && (g.io_bf16 & TECM_IO_B_BF16);
   if (!both || !(g.io_bf16 & TECM_P0_VEC4) || g.split_k > 1 || g.K % 32 != 0 || g.K < DBK || g.M < DBM || g.N < DBN / 2)
     return 0;
+  // the 128-column geometry where the 256-column tile would waste more than half of its last n-tile (N = 800);
+  // TECM_BF16_DMA = 1 / 2 forces one of the two (A/B diagnostics, tools/dma_ab.sh)
+  const int nrem = (int)(g.N % DBN);
+  const bool narrow = sel ? sel[0] == '2' : (nrem >= 1 && nrem <= D2N);
+  if (narrow) {
+    const int t2m = (int)((g.M + D2M - 1) / D2M), t2n = (int)((g.N + D2N - 1) / D2N);
+    hipLaunchKernelGGL(gemm_bf16_dma2_kernel, dim3((unsigned)(t2m * t2n)), dim3(D2TH), 0, st, g, t2m, t2n);
+    TECM_CHECK_LAUNCH("tecm_gemm_bf16/dma2");
+    return 1;
+  }
   const int tiles_m = (int)((g.M + DBM - 1) / DBM);
   const int tiles_n = (int)((g.N + DBN - 1) / DBN);
   hipLaunchKernelGGL(gemm_bf16_dma_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(DNTH), 0, st, g, tiles_m, tiles_n);

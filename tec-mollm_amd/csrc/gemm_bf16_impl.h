@@ -707,7 +707,9 @@ struct StagerSel<true, ROWS, WIN, DROP> {
 };
 
 // Epilogue shared by the bf16 kernels: identical to the fp32 kernel's, 32-row slabs per wave through LDS.
-template <int MT, int NT, int WTM, int WTN, bool NTS = false>      // NTS: non-temporal stores in the fast path
+// HALF: the fast path walks 16-row half slabs (half the registers of the prefetched input stream: the 128-register
+// two-blocks-per-CU kernel); same element arithmetic, same bits.
+template <int MT, int NT, int WTM, int WTN, bool NTS = false, bool HALF = false>      // NTS: non-temporal stores in the fast path
 __device__ __forceinline__ void block_epilogue16(const TecmGemm& g, f32x16 (&acc)[MT][NT], unsigned char* smem_raw, int wave,
                                                  int lane, int wm, int wn, int64_t m0, int64_t n0) {
   constexpr int STG_LD = WTN + 4;
@@ -734,8 +736,23 @@ __device__ __forceinline__ void block_epilogue16(const TecmGemm& g, f32x16 (&acc
     const EpiCol ecol = epi_col(g, n0 + wn * WTN + lcol);
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (g.bias && ecol.ok) bias4 = *reinterpret_cast<const float4*>(g.bias + ecol.n);
-    tecm_gemm::epi_fast_dispatch<MT, 32 / RPI, RPI, STG_LD, NTS>(fmode, g, odc, stg, lrow, lcol, m0 + wm * WTM, ecol, bias4,
-                                                             stage_slab);
+    if constexpr (HALF) {
+      auto stage_half = [&](auto sc) {                   // half slab hs of 32-row slab i: accumulator registers 8hs .. 8hs+7
+        constexpr int i = decltype(sc)::value / 2, hs = decltype(sc)::value % 2;
+        static_for<8>([&](auto ec) {
+          constexpr int e = 8 * hs + decltype(ec)::value;
+          static_for<NT>([&](auto jc) {
+            constexpr int jn = decltype(jc)::value;
+            stg[((e & 3) + 8 * ((e >> 2) & 1) + 4 * h) * STG_LD + jn * 32 + r] = acc[i][jn][e];
+          });
+        });
+      };
+      tecm_gemm::epi_fast_dispatch<2 * MT, 16 / RPI, RPI, STG_LD, NTS>(fmode, g, odc, stg, lrow, lcol, m0 + wm * WTM, ecol,
+                                                                   bias4, stage_half);
+    } else {
+      tecm_gemm::epi_fast_dispatch<MT, 32 / RPI, RPI, STG_LD, NTS>(fmode, g, odc, stg, lrow, lcol, m0 + wm * WTM, ecol, bias4,
+                                                               stage_slab);
+    }
     return;
   }
   static_for<MT>([&](auto ic) {

@@ -575,6 +575,9 @@ __device__ __forceinline__ void epi_fast_rows(const TecmGemm& g, const DropCtx& 
         else *reinterpret_cast<float4*>(g.C + off) = make_float4(o[0], o[1], o[2], o[3]);
       }
     }
+#ifdef TECM_EPI_SLEEP                                    // diagnostics: pace the epilogue's stores (tools/build_variant.py)
+    __builtin_amdgcn_s_sleep(TECM_EPI_SLEEP);
+#endif
   }
 }
 // One wave's staged block of SLABS x (NIT * RPI) rows: the input stream of slab s+1 is requested BEFORE the stores

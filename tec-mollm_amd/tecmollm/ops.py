@@ -187,9 +187,11 @@ def _kernel_name(g: TecmGemm, use16: bool = False) -> str:
             win16 = "true"                             # the bf16-resident window / transposed instances are built WIN = true
         both16 = (g.io_bf16 & IO_A_BF16) and (g.io_bf16 & IO_B_BF16)
         # mirrors tecm_gemm16_dma_try (csrc/gemm_bf16_dma.hip); the float4-epilogue condition holds for every bf16 call
+        sel = os.environ.get("TECM_BF16_DMA", "")[:1]
         if (both16 and g.split_k <= 1 and g.N % 4 == 0 and g.K % 32 == 0 and g.K >= 64 and g.M >= 256 and g.N >= 128
-                and os.environ.get("TECM_BF16_DMA", "1")[:1] != "0"):
-            return "gemm_bf16_dma_kernel"
+                and sel != "0"):
+            narrow = sel == "2" if sel else 1 <= g.N % 256 <= 128      # the 256 x 128 geometry (N = 800)
+            return "gemm_bf16_dma2_kernel" if narrow else "gemm_bf16_dma_kernel"
         return f"gemm_bf16_kernel<{g.a_layout},{g.b_layout},{win16},{drp16}>"
     av = _vec(g.A, g.lda, g.a_win, g.a_layout == A_MK, g.K)
     bv = _vec(g.B, g.ldb, g.b_win, g.b_layout == B_NK, g.K)

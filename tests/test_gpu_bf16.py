@@ -142,7 +142,8 @@ def test_bf16_resident_operands_and_output_are_bit_identical(dev, M, N, K):
 
 @pytest.mark.parametrize("M,N,K", [(256, 128, 64), (257, 800, 2304), (700, 132, 96), (1031, 2304, 800), (4099, 768, 3072),
                                    (513, 3072, 768), (300, 256, 32 * 7)])
-def test_bf16_dma_kernel_matches_the_register_staged_kernel_bit_for_bit(dev, M, N, K, monkeypatch):
+@pytest.mark.parametrize("geometry", ["1", "2"], ids=["256x256", "256x128x2blocks"])
+def test_bf16_dma_kernel_matches_the_register_staged_kernel_bit_for_bit(dev, M, N, K, geometry, monkeypatch):
     """The 256x256 LDS-DMA kernel (gemm_bf16_dma.hip: both operands bf16 in HBM) against the 256x128 register-staged
     kernel on the same tensors: ragged M and N tiles, K tails of 32, single K-tile, every epilogue the GPT-2 stack
     uses (bias + GELU + pre-activation store + bf16 C; bias + dropout + residual; GELU' from a saved pre-activation)."""
@@ -166,7 +167,7 @@ def test_bf16_dma_kernel_matches_the_register_staged_kernel_bit_for_bit(dev, M, 
 
     monkeypatch.setenv("TECM_BF16_DMA", "0")
     want = run()
-    monkeypatch.setenv("TECM_BF16_DMA", "1")
+    monkeypatch.setenv("TECM_BF16_DMA", geometry)
     got = run()
     for g_, w_ in zip(got, want):
         assert torch.equal(g_, w_)

@@ -33,7 +33,7 @@ extern "C" {
 #define TECM_E_LAUNCH (-3)     /* hipGetLastError() != hipSuccess after the launch       */
 #define TECM_E_LDS (-4)        /* problem does not fit the 160 KiB LDS budget            */
 
-#define TECM_ABI_VERSION 6
+#define TECM_ABI_VERSION 7
 int tecm_abi_version(void);
 /* Human-readable text for the last error on this thread (host pointer, never NULL). */
 const char* tecm_last_error(void);
@@ -248,6 +248,23 @@ int tecm_conv_weight_pack(const float* w, float* fwd_pack, float* bwd_pack, int3
 /* inverse of fwd_pack for the weight gradient: dW[co][ci][tap] = dpack[co][tap*Cin+ci]. */
 int tecm_conv_weight_unpack(const float* dpack, float* dw, int32_t Cout, int32_t Cin, int32_t k,
                             void* stream);
+
+/* Multi_Scale_Conv_Block (reference src/model/modules.py:43-60), bf16 mode (train.py:68): the input gradient of the three
+ * parallel Conv1d(k = 3, 5, 7, padding (k-1)/2) in ONE launch that reads dy once (csrc/conv_seq.hip):
+ *   dinp[b,t,n,ci] = sum_j sum_tau sum_co dy[b, t - tau + (k_j-1)/2, n, j*Cout + co] * w_j[co, ci, tau]
+ * dy: bf16 (B, Lc, N, 3*Cout) time-major -- the GroupNorm+GELU backward's output; dinp: fp32 (B, Lc, N, ld_in), columns
+ * >= Cin are written as zeros; wpack: the three weights (Cout, Cin, k_j) fp32 rounded to bf16 in MFMA fragment order by
+ * tecm_conv_dx_pack, 15*Cout * 32*ceil(ld_in/32) bf16 values.  Cout % 64 == 0, ld_in % 4 == 0, ld_in <= 64,
+ * Lc % 8 == 0; 16-byte aligned pointers. */
+typedef struct TecmConvDx {
+  const void* dy;
+  const void* wpack;
+  float* dinp;
+  int32_t B, Lc, N, Cout, ld_in, _pad;
+} TecmConvDx;
+int tecm_conv_dx_pack(const float* w3, const float* w5, const float* w7, void* wpack, int32_t Cout, int32_t Cin,
+                      int32_t ld_in, void* stream);
+int tecm_conv_dx_bf16(const TecmConvDx* p, void* stream);
 
 /* dst (bf16) [r][c] = round-to-nearest-even(src [r][c]) for a (rows, cols) block; cols % 4 == 0.  The cast torch.autocast
  * inserts in front of a Linear / Conv1D input (reference train.py:68), done once for a tensor a bf16 GEMM will read (here:

@@ -1,0 +1,315 @@
+// Multi_Scale_Conv_Block (reference modules.py:43-60), bf16 mode: the input gradient of the three parallel Conv1d
+// (k = 3, 5, 7) as ONE kernel that reads dy once.
+//
+//     dinp[b, t, n, ci] = sum_j sum_tau sum_co  dy[b, t - tau + p_j, n, j*Cout + co] * w_j[co, ci, tau],   p_j = (k_j - 1) / 2
+//
+// Before: three window-view GEMMs (K = 3/5/7 x Cout, N = 24 or 64 output columns, the second and third accumulating into
+// dinp), each re-reading its taps of dy through a 256 x 128 tile at one block per CU: 0.82 + 0.72 ms per step in bf16 mode
+// at 50-200 TFLOP/s -- bound by data movement, not by the matrix cores.  Here: a SEQUENCE tile.  A block owns 4 nodes x
+// (up to 48) time steps of one sample and stages exactly those rows of dy (all 3*Cout channels, bf16) in LDS once; every
+// tap of every kernel size is then a row offset inside the tile (rows outside [0, Lc) read a shared zero row), so dy
+// leaves HBM once (429 MB at B = 8) and the weights (61 / 246 KB, fragment-ordered by tecm_conv_dx_pack) stream from L2.
+//   * matrix cores: v_mfma_f32_32x32x16_bf16 with the WEIGHTS as the A operand (32 input channels x 16 k) and 32 data
+//     rows (8 time steps x 4 nodes) as the B operand, so an accumulator lane holds runs of 4 consecutive input channels of
+//     ONE row: the result leaves in float4 stores straight from registers, 32 rows x 96 (256) B contiguous per tile;
+//   * K = 15 tap-blocks x Cout is split over the block's 4 waves (every wave multiplies its k range against ALL rows of
+//     the tile); the four partial sums meet in LDS (the dy image is dead by then) and each accumulator tile is finished
+//     and stored by one owner wave -- a fixed order, bit-reproducible;
+//   * k order = (time offset delta = -3..3, kernel size j active at delta, co): for a fixed delta the active channels of a
+//     dy row are contiguous (all 3*Cout for |delta| <= 1, the upper 2*Cout for 2, the upper Cout for 3), so every
+//     16-wide k step is one aligned 32-byte run of one LDS row;
+//   * 77 KiB of LDS (pitch 3*Cout*2 + 16 B: conflict-free ds_read_b128) and ~150 registers: two blocks per CU, one
+//     loading while the other multiplies.
+// Measured (B = 8, N = 2911, round 3): block 1 (Lc 48, Cout 64, 24 columns) 823 -> 220-290 us, block 2 (Lc 24, Cout 128,
+// 64 columns) 718 -> 290-350 us; whole bf16 step 23.19 -> 22.26 ms on one box.  Phase ablations (-DCDX_ABLATE): staging +
+// stores alone 182 us, the K loop alone 135 us, neither 24 us.  A persistent form that requests the NEXT tile's rows into
+// registers before multiplying the current one (72 registers of prefetch) measured the same (217 / 322 us): not kept.
+// Arithmetic = the bf16 mode's: operands rounded to bf16 (dy by its producer, the weights by the pack kernel, RNE), fp32
+// accumulation; the summation order differs from the GEMM path's (four k ranges), the rounding points do not.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // a native vector: arrays of it stay in registers
+
+namespace tecm_convseq {
+
+#ifndef CDX_ABLATE
+#define CDX_ABLATE 0      // diagnostics (tools/build_variant.py): bit0 no staging loads, bit1 no K loop, bit2 no exchange
+#endif
+
+constexpr int NB = 4;        // nodes per tile (one MFMA column block = 8 time steps x 4 nodes)
+constexpr int NTH = 256;     // 4 waves = 4 k ranges
+constexpr int MAXT = 6;      // accumulator tiles per wave: (time steps / 8) x (input-channel blocks of 32)
+
+// k segment d = delta + 3: how many kernel sizes are active, first active channel
+__host__ __device__ __forceinline__ int seg_nact(int d) {
+  const int a = d < 3 ? 3 - d : d - 3;
+  return a <= 1 ? 3 : (a == 2 ? 2 : 1);
+}
+
+struct Args {
+  const __bf16* dy;
+  const __bf16* wpack;
+  float* dinp;
+  int B, Lc, N, Cout, ld_in, NCI, TC, nchunk, nblk, pitch, zero_off;   // pitch, zero_off in bytes
+};
+
+struct Tile {
+  int b, n0, t0, tc, ts_lo, rows;
+};
+__device__ __forceinline__ Tile decode_tile(const Args& a, int tile) {
+  Tile t;
+  const int nbk = tile % a.nblk;
+  tile /= a.nblk;
+  const int chunk = tile % a.nchunk;
+  t.b = tile / a.nchunk;
+  t.n0 = nbk * NB;
+  t.t0 = chunk * a.TC;
+  t.tc = min(a.TC, a.Lc - t.t0);                           // multiple of 8
+  t.ts_lo = max(0, t.t0 - 3);
+  t.rows = (min(a.Lc, t.t0 + t.tc + 3) - t.ts_lo) * NB;
+  return t;
+}
+
+// dy rows of a tile: (ts, n) -> LDS row (ts - ts_lo) * 4 + n, in 16-byte chunks; chunk q of this lane is chunk
+// tid + q * NTH of the image.  Loads are clamped (never out of bounds) and only real chunks are stored.
+template <int SB>
+__device__ __forceinline__ void stage_load(const Args& a, const Tile& t, int q0, u32x4 (&v)[SB]) {
+  const int CT = 3 * a.Cout, cpr = CT / 8, total = t.rows * cpr;
+#pragma unroll
+  for (int q = 0; q < SB; ++q) {
+    const int idx = min((int)threadIdx.x + (q0 + q) * NTH, total - 1);
+    const int row = idx / cpr, ch = idx - row * cpr;
+    const int ts = t.ts_lo + (row >> 2);
+    const int ng = min(t.n0 + (row & 3), a.N - 1);         // the ragged last node block re-reads node N-1; never stored
+    v[q] = *reinterpret_cast<const u32x4*>(a.dy + (((int64_t)t.b * a.Lc + ts) * a.N + ng) * CT + ch * 8);
+  }
+}
+template <int SB>
+__device__ __forceinline__ void stage_store(const Args& a, const Tile& t, int q0, const u32x4 (&v)[SB], unsigned char* lds) {
+  const int cpr = 3 * a.Cout / 8, total = t.rows * cpr;
+#pragma unroll
+  for (int q = 0; q < SB; ++q) {
+    const int idx = (int)threadIdx.x + (q0 + q) * NTH;
+    const int row = idx / cpr, ch = idx - row * cpr;
+    if (idx < total) *reinterpret_cast<u32x4*>(lds + row * a.pitch + ch * 16) = v[q];
+  }
+}
+
+// The tile's product: this wave's k range against all rows (accumulators), then the exchange and the stores.
+template <int NCI>
+__device__ __forceinline__ void tile_compute(const Args& a, const Tile& t, unsigned char* lds, int wave, int lane,
+                                             bool) {
+  const int r = lane & 31, h = lane >> 5;
+  const int zero_off = a.zero_off;
+  // ---- this wave's k range, in 16-wide steps; (d, sd) = (segment, step inside the segment)
+  const int spc = a.Cout / 16;                             // k steps per kernel size and time offset
+  const int KS = 15 * spc;
+  const int s_beg = wave * (KS / 4), s_end = s_beg + KS / 4;
+  int d = 0, sd = s_beg;
+  while (sd >= seg_nact(d) * spc) {
+    sd -= seg_nact(d) * spc;
+    ++d;
+  }
+  const int ntt = t.tc >> 3;                               // row tiles (8 time steps x 4 nodes) of this chunk
+  f32x16 acc[MAXT];
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  // lane r of row tile i is data row (tl = 8 i + r / 4, n = r % 4); its source row at offset delta is LDS row
+  // (t0 + tl + delta - ts_lo) * 4 + n = r + 4 * (t0 - ts_lo + 8 i + delta)
+  const int tl0 = r >> 2;
+  // weight fragments come straight from L2 (fragment-ordered, 1 KiB per wave-instruction): a ring of WD steps in
+  // registers, refilled WD steps ahead -- one step (6 MFMAs) is far shorter than an L2 round trip
+  constexpr int WD = 3;                                    // KS / 4 = 15 * Cout / 64 is a multiple of 15
+  const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.wpack) + (int64_t)s_beg * NCI * 64 + lane;
+  bf16x8 wf[WD][NCI];
+#pragma unroll
+  for (int u = 0; u < WD; ++u)
+#pragma unroll
+    for (int c = 0; c < NCI; ++c) wf[u][c] = wp[(u * NCI + c) * 64];
+  for (int s0 = s_beg; s0 < ((CDX_ABLATE & 2) ? s_beg : s_end); s0 += WD) {
+#pragma unroll
+    for (int u = 0; u < WD; ++u) {
+      const int delta = d - 3;
+      const int colb = ((3 - seg_nact(d)) * a.Cout + sd * 16 + 8 * h) * 2;    // byte offset inside the dy row
+      const int rbase = (t.t0 - t.ts_lo + delta) * 4 + r;
+#pragma unroll
+      for (int i = 0; i < MAXT / NCI; ++i) {
+        if (i < ntt) {
+          const int ts = t.t0 + 8 * i + tl0 + delta;
+          const bool ok = ts >= 0 && ts < a.Lc;
+          const int off = ok ? (rbase + 32 * i) * a.pitch + colb : zero_off + 16 * h;
+          const bf16x8 df = *reinterpret_cast<const bf16x8*>(lds + off);
+#pragma unroll
+          for (int c = 0; c < NCI; ++c)
+            acc[i * NCI + c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u][c], df, acc[i * NCI + c], 0, 0, 0);
+        }
+      }
+      if (s0 + u + WD < s_end) {
+#pragma unroll
+        for (int c = 0; c < NCI; ++c) wf[u][c] = wp[((u + WD) * NCI + c) * 64];
+      }
+      if (++sd == seg_nact(d) * spc) {
+        sd = 0;
+        ++d;
+      }
+    }
+    wp += WD * NCI * 64;
+  }
+  __syncthreads();                                         // the dy image is dead: it becomes the exchange buffer
+
+  // ---- the four k ranges meet: tile T is finished by wave T % 4; the other three park their partial sums in
+  //      part[T][slot][e][lane] (slot = (wave - owner - 1) & 3 in 0..2), conflict-free both ways
+  float* part = reinterpret_cast<float*>(lds);
+  const int NT = ntt * NCI;
+#pragma unroll
+  for (int T = 0; T < MAXT; ++T) {
+    if (T < NT && (T & 3) != wave && !(CDX_ABLATE & 4)) {
+      const int slot = (wave - (T & 3) - 1) & 3;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) part[((T * 3 + slot) * 16 + e) * 64 + lane] = acc[T][e];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int T = 0; T < MAXT; ++T) {
+    if (T < NT && (T & 3) == wave) {
+      f32x16 v = acc[T];
+#pragma unroll
+      for (int slot = 0; slot < ((CDX_ABLATE & 4) ? 0 : 3); ++slot)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] += part[((T * 3 + slot) * 16 + e) * 64 + lane];
+      // accumulator register e of lane (r, h): input channel 32 c + (e & 3) + 8 (e >> 2) + 4 h of data row r
+      const int i = T / NCI, c = T % NCI;
+      const int tt = t.t0 + 8 * i + tl0, n = t.n0 + (r & 3);
+      if (n < a.N) {
+        float* orow = a.dinp + (((int64_t)t.b * a.Lc + tt) * a.N + n) * a.ld_in;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int ci = 32 * c + 8 * gq + 4 * h;
+          if (ci < a.ld_in)
+            *reinterpret_cast<float4*>(orow + ci) = make_float4(v[4 * gq], v[4 * gq + 1], v[4 * gq + 2], v[4 * gq + 3]);
+        }
+      }
+    }
+  }
+}
+
+// One tile per block (any shape the LDS admits).
+template <int NCI>
+__global__ __launch_bounds__(NTH, 2) void conv_dx_seq_kernel(const Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const Tile t = decode_tile(a, blockIdx.x);
+  {
+    constexpr int SB = 12;                                 // loads in flight per lane (the accumulators are not live yet)
+    const int total = t.rows * (3 * a.Cout / 8);
+    for (int q0 = 0; q0 * NTH < ((CDX_ABLATE & 1) ? 0 : total); q0 += SB) {
+      u32x4 v[SB];
+      stage_load<SB>(a, t, q0, v);
+      stage_store<SB>(a, t, q0, v, lds);
+    }
+    if (tid < a.pitch / 16) *reinterpret_cast<uint4*>(lds + a.zero_off + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
+  }
+  __syncthreads();
+  tile_compute<NCI>(a, t, lds, wave, lane, false);
+}
+
+// wpack[s][c][lane][e] = w_j[co][ci][tau]  for k = 16 s + 8 (lane >> 5) + e  -> (delta, j, co), tau = p_j - delta,
+// ci = 32 c + (lane & 31); zero for ci >= Cin (the 22 -> 24 channel padding and the tail of the last channel block)
+__global__ __launch_bounds__(256) void conv_dx_pack_kernel(const float* __restrict__ w3, const float* __restrict__ w5,
+                                                           const float* __restrict__ w7, __bf16* __restrict__ wpack,
+                                                           int Cout, int Cin, int NCI) {
+  const int KTOT = 15 * Cout;
+  const int total = KTOT * NCI * 32;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int e = i & 7, lane = (i >> 3) & 63;
+    const int sc = i >> 9, c = sc % NCI, s = sc / NCI;
+    int k = 16 * s + 8 * (lane >> 5) + e;
+    const int ci = 32 * c + (lane & 31);
+    int d = 0;
+    while (k >= seg_nact(d) * Cout) {
+      k -= seg_nact(d) * Cout;
+      ++d;
+    }
+    const int col = (3 - seg_nact(d)) * Cout + k;          // channel of the dy row: kernel size j = col / Cout
+    const int j = col / Cout, co = col - j * Cout;
+    const int kj = 3 + 2 * j, tau = (kj - 1) / 2 - (d - 3);
+    const float* w = j == 0 ? w3 : (j == 1 ? w5 : w7);
+    float v = 0.f;
+    if (ci < Cin && tau >= 0 && tau < kj) v = w[((int64_t)co * Cin + ci) * kj + tau];
+    wpack[i] = (__bf16)v;
+  }
+}
+
+}  // namespace tecm_convseq
+
+extern "C" int tecm_conv_dx_pack(const float* w3, const float* w5, const float* w7, void* wpack, int32_t Cout, int32_t Cin,
+                                 int32_t ld_in, void* stream) {
+  using namespace tecm_convseq;
+  TECM_REQUIRE(w3 && w5 && w7 && wpack, TECM_E_ARG, "tecm_conv_dx_pack: null pointer");
+  TECM_REQUIRE(Cout > 0 && Cout % 64 == 0 && Cin > 0 && Cin <= ld_in && ld_in % 4 == 0, TECM_E_ARG,
+               "tecm_conv_dx_pack: Cout must be a multiple of 64, Cin <= ld_in, ld_in a multiple of 4");
+  const int NCI = (ld_in + 31) / 32;
+  const int total = 15 * Cout * NCI * 32;
+  hipLaunchKernelGGL(conv_dx_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w3, w5, w7,
+                     static_cast<__bf16*>(wpack), Cout, Cin, NCI);
+  TECM_CHECK_LAUNCH("tecm_conv_dx_pack");
+  return TECM_OK;
+}
+
+extern "C" int tecm_conv_dx_bf16(const TecmConvDx* p, void* stream) {
+  using namespace tecm_convseq;
+  TECM_REQUIRE(p && p->dy && p->wpack && p->dinp, TECM_E_ARG, "tecm_conv_dx_bf16: null pointer");
+  TECM_REQUIRE(p->B > 0 && p->Lc > 0 && p->N > 0, TECM_E_ARG, "tecm_conv_dx_bf16: bad shape");
+  TECM_REQUIRE(p->Cout % 64 == 0 && p->Cout > 0 && p->ld_in % 4 == 0 && p->ld_in > 0 && p->ld_in <= 64, TECM_E_ARG,
+               "tecm_conv_dx_bf16: Cout must be a multiple of 64 and ld_in a multiple of 4 up to 64");
+  TECM_REQUIRE(p->Lc % 8 == 0, TECM_E_ARG, "tecm_conv_dx_bf16: the sequence length must be a multiple of 8");
+  TECM_REQUIRE(tecm_aligned(p->dy, 16) && tecm_aligned(p->wpack, 16) && tecm_aligned(p->dinp, 16), TECM_E_ALIGN,
+               "tecm_conv_dx_bf16: 16-byte aligned pointers");
+  Args a;
+  a.dy = static_cast<const __bf16*>(p->dy);
+  a.wpack = static_cast<const __bf16*>(p->wpack);
+  a.dinp = p->dinp;
+  a.B = p->B; a.Lc = p->Lc; a.N = p->N; a.Cout = p->Cout; a.ld_in = p->ld_in;
+  a.NCI = (p->ld_in + 31) / 32;
+  a.pitch = 3 * p->Cout * 2 + 16;
+  // time steps per tile: at most MAXT accumulator tiles per wave, and the staged rows (+ 3 halo steps each side) must
+  // fit: two blocks per CU when that costs nothing (Lc <= 48 at Cout = 64, Lc <= 24 at Cout = 128), else one
+  int TC = 8 * (MAXT / a.NCI);
+  if (TC > p->Lc) TC = p->Lc;
+  auto img_steps = [&](int tc) { return tc + 6 < p->Lc ? tc + 6 : p->Lc; };
+  auto zero_of = [&](int tc) {                             // the shared zero row sits behind the image AND the exchange buffer
+    const size_t img = (size_t)img_steps(tc) * NB * a.pitch;
+    const size_t xch = (size_t)(tc / 8) * a.NCI * 3 * 16 * 64 * 4;
+    return img > xch ? img : xch;
+  };
+  while (TC > 8 && zero_of(TC) + a.pitch > 160 * 1024) TC -= 8;
+  const size_t lds = zero_of(TC) + a.pitch;
+  TECM_REQUIRE(lds <= 160 * 1024, TECM_E_LDS, "tecm_conv_dx_bf16: %d channels need %zu B of LDS per tile", 3 * p->Cout, lds);
+  a.TC = TC;
+  a.zero_off = (int)zero_of(TC);
+  a.nchunk = (p->Lc + TC - 1) / TC;
+  a.nblk = (p->N + NB - 1) / NB;
+  const int64_t tiles = (int64_t)p->B * a.nchunk * a.nblk;
+  TECM_REQUIRE(tiles < ((int64_t)1 << 31), TECM_E_ARG, "tecm_conv_dx_bf16: too many tiles");
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dx_seq_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dx_seq_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        160 * 1024);
+    attr_set = true;
+  }
+  if (a.NCI == 1)
+    hipLaunchKernelGGL(conv_dx_seq_kernel<1>, dim3((unsigned)tiles), dim3(NTH), lds, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(conv_dx_seq_kernel<2>, dim3((unsigned)tiles), dim3(NTH), lds, (hipStream_t)stream, a);
+  TECM_CHECK_LAUNCH("tecm_conv_dx_bf16");
+  return TECM_OK;
+}

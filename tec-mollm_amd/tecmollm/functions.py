@@ -320,6 +320,7 @@ class ConvBlockFn(torch.autograd.Function):
         else:
             gemm(B * Lo * N, Cout, CT, act, CT, wf2, CT, out, Cout, a_win=win(N, Lc, Lo, stride, 1, CT, 0), bias=bf, bf16=bf16)
         ctx.save_for_backward(inp, y, act, stats, gamma, beta, wf, *packs)
+        ctx.w357 = (w3.detach(), w5.detach(), w7.detach())       # raw (Cout, cin, k) weights: the fused d-inp kernel packs them
         ctx.dims = (B, Lc, N, ld_in, cin, Cout, stride, Lo, need_dinp, bf16)
         return out, out16
 
@@ -343,6 +344,11 @@ class ConvBlockFn(torch.autograd.Function):
         dy = torch.empty(B, Lc, N, CT, device=inp.device, dtype=act.dtype)
         dgamma, dbeta, dbconv = ops.groupnorm_gelu_bwd(dact, stride, y, gamma, beta, stats, dy, B, Lc, N, Cout)
         dinp = _empty(B, Lc, N, ld_in, like=inp) if need_dinp else None
+        # bf16 mode: d inp of the three kernel sizes in ONE launch that reads dy once (csrc/conv_seq.hip) instead of
+        # three accumulating window GEMMs; same operand roundings (dy bf16, weights rounded to bf16), fp32 accumulation
+        dx_seq = need_dinp and dy.dtype == torch.bfloat16 and ops.conv_dx_seq_ok(Lc, Cout, ld_in)
+        if dx_seq:
+            ops.conv_dx_bf16(dy, ctx.w357[0], ctx.w357[1], ctx.w357[2], dinp, B, Lc, N, Cout, cin, ld_in)
         grads = []
         for j, (k, bp) in enumerate(((3, bp3), (5, bp5), (7, bp7))):
             K = k * ld_in
@@ -353,7 +359,7 @@ class ConvBlockFn(torch.autograd.Function):
             dw = ops.conv_weight_unpack(dpack, Cout, ld_in, k)
             if ld_in != cin:
                 dw = dw[:, :cin, :].contiguous()
-            if need_dinp:
+            if need_dinp and not dx_seq:
                 gemm(M, ld_in, k * Cout, dy, CT, bp, ld_in, dinp, ld_in, b_layout=B_KN, a_off=j * Cout,
                      a_win=win(N, Lc, Lc, 1, k, Cout, (k - 1) // 2), accumulate=(j > 0), bf16=bf16)
             grads += [dw, db, dgamma[j * Cout:(j + 1) * Cout], dbeta[j * Cout:(j + 1) * Cout]]

@@ -30,7 +30,8 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // a native vector: arrays of it stay in registers
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // a native vector: arrays of it stay in registers
 
 namespace tecm_convseq {
 
@@ -49,10 +50,11 @@ __host__ __device__ __forceinline__ int seg_nact(int d) {
 }
 
 struct Args {
-  const __bf16* dy;
-  const __bf16* wpack;
+  const void* dy;            // bf16 or fp32 (B, Lc, N, 3 * Cout)
+  const void* wpack;         // fragment-ordered weights, the element type of dy
   float* dinp;
   int B, Lc, N, Cout, ld_in, NCI, TC, nchunk, nblk, pitch, zero_off;   // pitch, zero_off in bytes
+  int row_bytes, cpr;        // one dy row: bytes, 16-byte chunks
 };
 
 struct Tile {
@@ -76,22 +78,23 @@ __device__ __forceinline__ Tile decode_tile(const Args& a, int tile) {
 // tid + q * NTH of the image.  Loads are clamped (never out of bounds) and only real chunks are stored.
 template <int SB>
 __device__ __forceinline__ void stage_load(const Args& a, const Tile& t, int q0, u32x4 (&v)[SB]) {
-  const int CT = 3 * a.Cout, cpr = CT / 8, total = t.rows * cpr;
+  const int cpr = a.cpr, total = t.rows * cpr, nth = (int)blockDim.x;
+  const char* src = static_cast<const char*>(a.dy);
 #pragma unroll
   for (int q = 0; q < SB; ++q) {
-    const int idx = min((int)threadIdx.x + (q0 + q) * NTH, total - 1);
+    const int idx = min((int)threadIdx.x + (q0 + q) * nth, total - 1);
     const int row = idx / cpr, ch = idx - row * cpr;
     const int ts = t.ts_lo + (row >> 2);
     const int ng = min(t.n0 + (row & 3), a.N - 1);         // the ragged last node block re-reads node N-1; never stored
-    v[q] = *reinterpret_cast<const u32x4*>(a.dy + (((int64_t)t.b * a.Lc + ts) * a.N + ng) * CT + ch * 8);
+    v[q] = *reinterpret_cast<const u32x4*>(src + (((int64_t)t.b * a.Lc + ts) * a.N + ng) * a.row_bytes + ch * 16);
   }
 }
 template <int SB>
 __device__ __forceinline__ void stage_store(const Args& a, const Tile& t, int q0, const u32x4 (&v)[SB], unsigned char* lds) {
-  const int cpr = 3 * a.Cout / 8, total = t.rows * cpr;
+  const int cpr = a.cpr, total = t.rows * cpr, nth = (int)blockDim.x;
 #pragma unroll
   for (int q = 0; q < SB; ++q) {
-    const int idx = (int)threadIdx.x + (q0 + q) * NTH;
+    const int idx = (int)threadIdx.x + (q0 + q) * nth;
     const int row = idx / cpr, ch = idx - row * cpr;
     if (idx < total) *reinterpret_cast<u32x4*>(lds + row * a.pitch + ch * 16) = v[q];
   }
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_dx_seq_kernel(const Args a) {
   const Tile t = decode_tile(a, blockIdx.x);
   {
     constexpr int SB = 12;                                 // loads in flight per lane (the accumulators are not live yet)
-    const int total = t.rows * (3 * a.Cout / 8);
+    const int total = t.rows * a.cpr;
     for (int q0 = 0; q0 * NTH < ((CDX_ABLATE & 1) ? 0 : total); q0 += SB) {
       u32x4 v[SB];
       stage_load<SB>(a, t, q0, v);
@@ -218,6 +221,171 @@ __global__ __launch_bounds__(NTH, 2) void conv_dx_seq_kernel(const Args a) {
   }
   __syncthreads();
   tile_compute<NCI>(a, t, lds, wave, lane, false);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same kernel in EXACT fp32 (BASELINE configs[1], the headline): dy fp32, v_mfma_f32_32x32x2_f32 (bit-identical to an
+// fmaf chain), 8 waves = 8 k ranges, the fp32 image of 4 nodes x Lc steps takes 150 KiB (one block per CU).  Replaces
+// three accumulating window GEMMs that ran at 57 (block 1: 24 of 32 tile columns used) and 87 TFLOP/s (block 2).
+//   * k runs in steps of 8: a lane reads ONE float4 = k 8s + 4h .. 8s + 4h + 3 of its data row and feeds MFMA j (j = 0..3)
+//     with element j, i.e. MFMA j multiplies the k pair (8s + j, 8s + 4 + j); the weights are packed in the same order;
+//   * the eight partial sums meet in two rounds: waves 4..7 park theirs for waves 0..3 (96 KiB), then the scheme of the
+//     bf16 kernel among waves 0..3.
+constexpr int NTH32 = 512;
+
+template <int NCI>
+__global__ __launch_bounds__(NTH32, 2) void conv_dx_seq_f32_kernel(const Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const Tile t = decode_tile(a, blockIdx.x);
+  {
+    constexpr int SB = 10;
+    const int total = t.rows * a.cpr;
+    for (int q0 = 0; q0 * NTH32 < total; q0 += SB) {
+      u32x4 v[SB];
+      stage_load<SB>(a, t, q0, v);
+      stage_store<SB>(a, t, q0, v, lds);
+    }
+    if (tid < a.pitch / 16) *reinterpret_cast<uint4*>(lds + a.zero_off + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
+  }
+  __syncthreads();
+
+  const int spc = a.Cout / 8;                              // 8-wide k steps per kernel size and time offset
+  const int KS = 15 * spc;
+  const int s_beg = wave * (KS / 8), s_end = s_beg + KS / 8;
+  int d = 0, sd = s_beg;
+  while (sd >= seg_nact(d) * spc) {
+    sd -= seg_nact(d) * spc;
+    ++d;
+  }
+  const int ntt = t.tc >> 3;
+  f32x16 acc[MAXT];
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  const int tl0 = r >> 2;
+  constexpr int WD = 3;                                    // KS / 8 = 15 * Cout / 64 is a multiple of 15
+  const f32x4* wp = reinterpret_cast<const f32x4*>(a.wpack) + (int64_t)s_beg * NCI * 64 + lane;
+  f32x4 wf[WD][NCI];
+#pragma unroll
+  for (int u = 0; u < WD; ++u)
+#pragma unroll
+    for (int c = 0; c < NCI; ++c) wf[u][c] = wp[(u * NCI + c) * 64];
+  for (int s0 = s_beg; s0 < s_end; s0 += WD) {
+#pragma unroll
+    for (int u = 0; u < WD; ++u) {
+      const int delta = d - 3;
+      const int colb = ((3 - seg_nact(d)) * a.Cout + sd * 8 + 4 * h) * 4;     // byte offset inside the dy row
+      const int rbase = (t.t0 - t.ts_lo + delta) * 4 + r;
+#pragma unroll
+      for (int i = 0; i < MAXT / NCI; ++i) {
+        if (i < ntt) {
+          const int ts = t.t0 + 8 * i + tl0 + delta;
+          const bool ok = ts >= 0 && ts < a.Lc;
+          const int off = ok ? (rbase + 32 * i) * a.pitch + colb : a.zero_off + 16 * h;
+          const f32x4 df = *reinterpret_cast<const f32x4*>(lds + off);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int c = 0; c < NCI; ++c)
+              acc[i * NCI + c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[u][c][j], df[j], acc[i * NCI + c], 0, 0, 0);
+        }
+      }
+      if (s0 + u + WD < s_end) {
+#pragma unroll
+        for (int c = 0; c < NCI; ++c) wf[u][c] = wp[((u + WD) * NCI + c) * 64];
+      }
+      if (++sd == seg_nact(d) * spc) {
+        sd = 0;
+        ++d;
+      }
+    }
+    wp += WD * NCI * 64;
+  }
+  __syncthreads();                                         // the dy image is dead: it becomes the exchange buffer
+
+  float* part = reinterpret_cast<float*>(lds);
+  const int NT = ntt * NCI;
+  // round 1: waves 4..7 -> waves 0..3 (wave w adds the sums of wave w + 4): part[w - 4][T][e][lane]
+  if (wave >= 4) {
+#pragma unroll
+    for (int T = 0; T < MAXT; ++T)
+      if (T < NT)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) part[(((wave - 4) * NT + T) * 16 + e) * 64 + lane] = acc[T][e];
+  }
+  __syncthreads();
+  if (wave < 4) {
+#pragma unroll
+    for (int T = 0; T < MAXT; ++T)
+      if (T < NT)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[T][e] += part[((wave * NT + T) * 16 + e) * 64 + lane];
+  }
+  __syncthreads();
+  // round 2: among waves 0..3, tile T is finished by wave T % 4 (as in the bf16 kernel)
+  if (wave < 4) {
+#pragma unroll
+    for (int T = 0; T < MAXT; ++T) {
+      if (T < NT && (T & 3) != wave) {
+        const int slot = (wave - (T & 3) - 1) & 3;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) part[((T * 3 + slot) * 16 + e) * 64 + lane] = acc[T][e];
+      }
+    }
+  }
+  __syncthreads();
+  if (wave < 4) {
+#pragma unroll
+    for (int T = 0; T < MAXT; ++T) {
+      if (T < NT && (T & 3) == wave) {
+        f32x16 v = acc[T];
+#pragma unroll
+        for (int slot = 0; slot < 3; ++slot)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) v[e] += part[((T * 3 + slot) * 16 + e) * 64 + lane];
+        const int i = T / NCI, c = T % NCI;
+        const int tt = t.t0 + 8 * i + tl0, n = t.n0 + (r & 3);
+        if (n < a.N) {
+          float* orow = a.dinp + (((int64_t)t.b * a.Lc + tt) * a.N + n) * a.ld_in;
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const int ci = 32 * c + 8 * gq + 4 * h;
+            if (ci < a.ld_in)
+              *reinterpret_cast<float4*>(orow + ci) = make_float4(v[4 * gq], v[4 * gq + 1], v[4 * gq + 2], v[4 * gq + 3]);
+          }
+        }
+      }
+    }
+  }
+}
+
+// fp32 weights in the order of conv_dx_seq_f32_kernel: wpack[s][c][lane][j] = w_j[co][ci][tau] for k = 8 s + 4 (lane >> 5) + j
+__global__ __launch_bounds__(256) void conv_dx_pack_f32_kernel(const float* __restrict__ w3, const float* __restrict__ w5,
+                                                               const float* __restrict__ w7, float* __restrict__ wpack,
+                                                               int Cout, int Cin, int NCI) {
+  const int total = 15 * Cout * NCI * 32;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int j = i & 3, lane = (i >> 2) & 63;
+    const int sc = i >> 8, c = sc % NCI, s = sc / NCI;
+    int k = 8 * s + 4 * (lane >> 5) + j;
+    const int ci = 32 * c + (lane & 31);
+    int d = 0;
+    while (k >= seg_nact(d) * Cout) {
+      k -= seg_nact(d) * Cout;
+      ++d;
+    }
+    const int col = (3 - seg_nact(d)) * Cout + k;
+    const int jj = col / Cout, co = col - jj * Cout;
+    const int kj = 3 + 2 * jj, tau = (kj - 1) / 2 - (d - 3);
+    const float* w = jj == 0 ? w3 : (jj == 1 ? w5 : w7);
+    float v = 0.f;
+    if (ci < Cin && tau >= 0 && tau < kj) v = w[((int64_t)co * Cin + ci) * kj + tau];
+    wpack[i] = v;
+  }
 }
 
 // wpack[s][c][lane][e] = w_j[co][ci][tau]  for k = 16 s + 8 (lane >> 5) + e  -> (delta, j, co), tau = p_j - delta,
@@ -263,22 +431,24 @@ extern "C" int tecm_conv_dx_pack(const float* w3, const float* w5, const float* 
   return TECM_OK;
 }
 
-extern "C" int tecm_conv_dx_bf16(const TecmConvDx* p, void* stream) {
+static int conv_dx_launch(const TecmConvDx* p, void* stream, bool f32, const char* who) {
   using namespace tecm_convseq;
-  TECM_REQUIRE(p && p->dy && p->wpack && p->dinp, TECM_E_ARG, "tecm_conv_dx_bf16: null pointer");
-  TECM_REQUIRE(p->B > 0 && p->Lc > 0 && p->N > 0, TECM_E_ARG, "tecm_conv_dx_bf16: bad shape");
+  TECM_REQUIRE(p && p->dy && p->wpack && p->dinp, TECM_E_ARG, "%s: null pointer", who);
+  TECM_REQUIRE(p->B > 0 && p->Lc > 0 && p->N > 0, TECM_E_ARG, "%s: bad shape", who);
   TECM_REQUIRE(p->Cout % 64 == 0 && p->Cout > 0 && p->ld_in % 4 == 0 && p->ld_in > 0 && p->ld_in <= 64, TECM_E_ARG,
-               "tecm_conv_dx_bf16: Cout must be a multiple of 64 and ld_in a multiple of 4 up to 64");
-  TECM_REQUIRE(p->Lc % 8 == 0, TECM_E_ARG, "tecm_conv_dx_bf16: the sequence length must be a multiple of 8");
+               "%s: Cout must be a multiple of 64 and ld_in a multiple of 4 up to 64", who);
+  TECM_REQUIRE(p->Lc % 8 == 0, TECM_E_ARG, "%s: the sequence length must be a multiple of 8", who);
   TECM_REQUIRE(tecm_aligned(p->dy, 16) && tecm_aligned(p->wpack, 16) && tecm_aligned(p->dinp, 16), TECM_E_ALIGN,
-               "tecm_conv_dx_bf16: 16-byte aligned pointers");
+               "%s: 16-byte aligned pointers", who);
   Args a;
-  a.dy = static_cast<const __bf16*>(p->dy);
-  a.wpack = static_cast<const __bf16*>(p->wpack);
+  a.dy = p->dy;
+  a.wpack = p->wpack;
   a.dinp = p->dinp;
   a.B = p->B; a.Lc = p->Lc; a.N = p->N; a.Cout = p->Cout; a.ld_in = p->ld_in;
   a.NCI = (p->ld_in + 31) / 32;
-  a.pitch = 3 * p->Cout * 2 + 16;
+  a.row_bytes = 3 * p->Cout * (f32 ? 4 : 2);
+  a.cpr = a.row_bytes / 16;
+  a.pitch = a.row_bytes + 16;
   // time steps per tile: at most MAXT accumulator tiles per wave, and the staged rows (+ 3 halo steps each side) must
   // fit: two blocks per CU when that costs nothing (Lc <= 48 at Cout = 64, Lc <= 24 at Cout = 128), else one
   int TC = 8 * (MAXT / a.NCI);
@@ -286,30 +456,57 @@ extern "C" int tecm_conv_dx_bf16(const TecmConvDx* p, void* stream) {
   auto img_steps = [&](int tc) { return tc + 6 < p->Lc ? tc + 6 : p->Lc; };
   auto zero_of = [&](int tc) {                             // the shared zero row sits behind the image AND the exchange buffer
     const size_t img = (size_t)img_steps(tc) * NB * a.pitch;
-    const size_t xch = (size_t)(tc / 8) * a.NCI * 3 * 16 * 64 * 4;
+    const size_t xch = (size_t)(tc / 8) * a.NCI * (f32 ? 4 : 3) * 16 * 64 * 4;   // partial sums of 3 (fp32 round 1: 4) waves
     return img > xch ? img : xch;
   };
   while (TC > 8 && zero_of(TC) + a.pitch > 160 * 1024) TC -= 8;
   const size_t lds = zero_of(TC) + a.pitch;
-  TECM_REQUIRE(lds <= 160 * 1024, TECM_E_LDS, "tecm_conv_dx_bf16: %d channels need %zu B of LDS per tile", 3 * p->Cout, lds);
+  TECM_REQUIRE(lds <= 160 * 1024, TECM_E_LDS, "%s: %d channels need %zu B of LDS per tile", who, 3 * p->Cout, lds);
   a.TC = TC;
   a.zero_off = (int)zero_of(TC);
   a.nchunk = (p->Lc + TC - 1) / TC;
   a.nblk = (p->N + NB - 1) / NB;
   const int64_t tiles = (int64_t)p->B * a.nchunk * a.nblk;
-  TECM_REQUIRE(tiles < ((int64_t)1 << 31), TECM_E_ARG, "tecm_conv_dx_bf16: too many tiles");
+  TECM_REQUIRE(tiles < ((int64_t)1 << 31), TECM_E_ARG, "%s: too many tiles", who);
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dx_seq_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         160 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dx_seq_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dx_seq_f32_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dx_seq_f32_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        160 * 1024);
     attr_set = true;
   }
-  if (a.NCI == 1)
+  if (f32) {
+    if (a.NCI == 1)
+      hipLaunchKernelGGL(conv_dx_seq_f32_kernel<1>, dim3((unsigned)tiles), dim3(NTH32), lds, (hipStream_t)stream, a);
+    else
+      hipLaunchKernelGGL(conv_dx_seq_f32_kernel<2>, dim3((unsigned)tiles), dim3(NTH32), lds, (hipStream_t)stream, a);
+  } else if (a.NCI == 1) {
     hipLaunchKernelGGL(conv_dx_seq_kernel<1>, dim3((unsigned)tiles), dim3(NTH), lds, (hipStream_t)stream, a);
-  else
+  } else {
     hipLaunchKernelGGL(conv_dx_seq_kernel<2>, dim3((unsigned)tiles), dim3(NTH), lds, (hipStream_t)stream, a);
-  TECM_CHECK_LAUNCH("tecm_conv_dx_bf16");
+  }
+  TECM_CHECK_LAUNCH("tecm_conv_dx");
+  return TECM_OK;
+}
+
+extern "C" int tecm_conv_dx_bf16(const TecmConvDx* p, void* stream) { return conv_dx_launch(p, stream, false, "tecm_conv_dx_bf16"); }
+extern "C" int tecm_conv_dx_f32(const TecmConvDx* p, void* stream) { return conv_dx_launch(p, stream, true, "tecm_conv_dx_f32"); }
+
+extern "C" int tecm_conv_dx_pack_f32(const float* w3, const float* w5, const float* w7, float* wpack, int32_t Cout,
+                                     int32_t Cin, int32_t ld_in, void* stream) {
+  using namespace tecm_convseq;
+  TECM_REQUIRE(w3 && w5 && w7 && wpack, TECM_E_ARG, "tecm_conv_dx_pack_f32: null pointer");
+  TECM_REQUIRE(Cout > 0 && Cout % 64 == 0 && Cin > 0 && Cin <= ld_in && ld_in % 4 == 0, TECM_E_ARG,
+               "tecm_conv_dx_pack_f32: Cout must be a multiple of 64, Cin <= ld_in, ld_in a multiple of 4");
+  const int NCI = (ld_in + 31) / 32;
+  const int total = 15 * Cout * NCI * 32;
+  hipLaunchKernelGGL(conv_dx_pack_f32_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w3, w5, w7, wpack,
+                     Cout, Cin, NCI);
+  TECM_CHECK_LAUNCH("tecm_conv_dx_pack_f32");
   return TECM_OK;
 }

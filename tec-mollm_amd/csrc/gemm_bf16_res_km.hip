@@ -9,3 +9,7 @@ int tecm_gemm16_res_a_km_kn(const TecmGemm& g, hipStream_t st) {
 int tecm_gemm16_res_b_km_kn(const TecmGemm& g, hipStream_t st) {
   return tecm_gemm16::launch<TECM_A_KM, TECM_B_KN, true, false, 0, 1>(g, st);
 }
+// BOTH operands bf16: conv dW with A = dy and B = the bf16 copy of the block input through its window (round 3)
+int tecm_gemm16_res_ab_km_kn(const TecmGemm& g, hipStream_t st) {
+  return tecm_gemm16::launch<TECM_A_KM, TECM_B_KN, true, false, 1, 1>(g, st);
+}

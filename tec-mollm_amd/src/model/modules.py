@@ -19,7 +19,10 @@ from typing import List, Optional
 import torch
 import torch.nn as nn
 
+import os
+
 from tecmollm import functions as F_
+from tecmollm import ops as ops_
 from tecmollm import graph as graph_
 from tecmollm._lib import TecmError
 
@@ -103,6 +106,12 @@ class MultiScaleConvEmbedder(nn.Module):
 
     def forward_tm(self, inp: torch.Tensor, cin: int, need_dinp: bool = True, bf16: bool = False):
         inp16 = None
+        if int(bf16) == ops_.PREC_BF16 and inp.shape[-1] % 8 == 0 and os.environ.get("TECM_XS16", "1")[:1] != "0":
+            # bf16 mode: the first block's window GEMMs (three forward convs, three weight gradients: 15 tap reads of
+            # the spatial stage's output) read a bf16 copy rounded ONCE here -- the same bits their loaders would produce
+            inp16 = torch.empty(inp.shape, device=inp.device, dtype=torch.bfloat16)
+            rows = inp.numel() // inp.shape[-1]
+            ops_.cast_bf16(inp.detach(), inp.shape[-1], inp16, inp.shape[-1], rows, inp.shape[-1])
         for i, blk in enumerate(self.embedder):
             inp, inp16 = blk.forward_tm(inp, cin, need_dinp or i > 0, bf16, inp16)
             cin = blk.out_channels

@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TECM_LIB", os.path.join(_HERE, "libtecmollm_hip.so"))   # override for experiments
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_f32p = C.c_void_p
 
@@ -150,6 +150,8 @@ EXPORTS = {
     "tecm_conv_weight_unpack": (C.c_int, [c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "tecm_conv_dx_pack": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "tecm_conv_dx_bf16": (C.c_int, [C.POINTER(TecmConvDx), C.c_void_p]),
+    "tecm_conv_dx_pack_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "tecm_conv_dx_f32": (C.c_int, [C.POINTER(TecmConvDx), C.c_void_p]),
     "tecm_transpose_scale": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_float,
                                        C.c_void_p]),
     "tecm_dropout_apply": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int64, C.c_int32, C.POINTER(TecmDrop),

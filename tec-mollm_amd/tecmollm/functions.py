@@ -9,6 +9,7 @@ All activations after the spatial stage are time-major (B, T, N, C): row m = (b*
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 import weakref
 from typing import List, Optional
@@ -321,6 +322,7 @@ class ConvBlockFn(torch.autograd.Function):
             gemm(B * Lo * N, Cout, CT, act, CT, wf2, CT, out, Cout, a_win=win(N, Lc, Lo, stride, 1, CT, 0), bias=bf, bf16=bf16)
         ctx.save_for_backward(inp, y, act, stats, gamma, beta, wf, *packs)
         ctx.w357 = (w3.detach(), w5.detach(), w7.detach())       # raw (Cout, cin, k) weights: the fused d-inp kernel packs them
+        ctx.inp16 = inp16 if (side16 and inp16 is not None and ld_in % 8 == 0) else None   # dW reads it instead of inp
         ctx.dims = (B, Lc, N, ld_in, cin, Cout, stride, Lo, need_dinp, bf16)
         return out, out16
 
@@ -344,17 +346,21 @@ class ConvBlockFn(torch.autograd.Function):
         dy = torch.empty(B, Lc, N, CT, device=inp.device, dtype=act.dtype)
         dgamma, dbeta, dbconv = ops.groupnorm_gelu_bwd(dact, stride, y, gamma, beta, stats, dy, B, Lc, N, Cout)
         dinp = _empty(B, Lc, N, ld_in, like=inp) if need_dinp else None
-        # bf16 mode: d inp of the three kernel sizes in ONE launch that reads dy once (csrc/conv_seq.hip) instead of
-        # three accumulating window GEMMs; same operand roundings (dy bf16, weights rounded to bf16), fp32 accumulation
-        dx_seq = need_dinp and dy.dtype == torch.bfloat16 and ops.conv_dx_seq_ok(Lc, Cout, ld_in)
+        # d inp of the three kernel sizes in ONE launch that reads dy once (csrc/conv_seq.hip) instead of three
+        # accumulating window GEMMs: exact fp32 from an fp32 dy, the bf16 mode's roundings from a bf16 dy (the bf16x3 /
+        # bf16x6 modes keep the GEMM path)
+        dx_seq = need_dinp and ops.conv_dx_seq_ok(Lc, Cout, ld_in) and int(bf16) in (ops.PREC_FP32, ops.PREC_BF16) \
+            and (dy.dtype == torch.bfloat16 or int(bf16) == ops.PREC_FP32)
         if dx_seq:
-            ops.conv_dx_bf16(dy, ctx.w357[0], ctx.w357[1], ctx.w357[2], dinp, B, Lc, N, Cout, cin, ld_in)
+            ops.conv_dx(dy, ctx.w357[0], ctx.w357[1], ctx.w357[2], dinp, B, Lc, N, Cout, cin, ld_in)
         grads = []
         for j, (k, bp) in enumerate(((3, bp3), (5, bp5), (7, bp7))):
             K = k * ld_in
             db = dbconv[j * Cout:(j + 1) * Cout]
             dpack = _empty(Cout, K, like=inp)
-            gemm(Cout, K, M, dy, CT, inp, ld_in, dpack, K, a_layout=A_KM, b_layout=B_KN, a_off=j * Cout,
+            b_src = ctx.inp16 if (ctx.inp16 is not None and dy.dtype == torch.bfloat16
+                                  and os.environ.get("TECM_DW_B16", "1")[:1] != "0") else inp
+            gemm(Cout, K, M, dy, CT, b_src, ld_in, dpack, K, a_layout=A_KM, b_layout=B_KN, a_off=j * Cout,
                  b_win=win(N, Lc, Lc, 1, k, ld_in, (k - 1) // 2), split_k=pick_split_k(Cout, K, M, prec=bf16), bf16=bf16)
             dw = ops.conv_weight_unpack(dpack, Cout, ld_in, k)
             if ld_in != cin:

@@ -402,27 +402,34 @@ def conv_dx_seq_ok(Lc: int, Cout: int, ld_in: int) -> bool:
             and os.environ.get("TECM_CONV_SEQ", "1")[:1] != "0")
 
 
-def conv_dx_bf16(dy: torch.Tensor, w3: torch.Tensor, w5: torch.Tensor, w7: torch.Tensor, dinp: torch.Tensor, B: int,
-                 Lc: int, N: int, Cout: int, cin: int, ld_in: int) -> None:
+def conv_dx(dy: torch.Tensor, w3: torch.Tensor, w5: torch.Tensor, w7: torch.Tensor, dinp: torch.Tensor, B: int,
+            Lc: int, N: int, Cout: int, cin: int, ld_in: int) -> None:
     """dinp (B, Lc, N, ld_in) fp32 = input gradient of the three parallel Conv1d of a Multi_Scale_Conv_Block
-    (modules.py:43-60) from dy (B, Lc, N, 3*Cout) bf16, in one launch that reads dy once (bf16 mode)."""
-    if dy.dtype != torch.bfloat16 or dinp.dtype != torch.float32:
-        raise _lib.TecmError("conv_dx_bf16: dy is bf16, dinp fp32")
+    (modules.py:43-60) from dy (B, Lc, N, 3*Cout), in one launch that reads dy once (csrc/conv_seq.hip).  dy bf16: the
+    bf16 mode's arithmetic (weights rounded to bf16, fp32 accumulate); dy fp32: exact fp32."""
+    if dinp.dtype != torch.float32 or dy.dtype not in (torch.bfloat16, torch.float32):
+        raise _lib.TecmError("conv_dx: dy is bf16 or fp32, dinp fp32")
+    f32 = dy.dtype == torch.float32
     nci = (ld_in + 31) // 32
-    wpack = torch.empty(15 * Cout * nci * 32, device=dy.device, dtype=torch.bfloat16)
-    check(lib().tecm_conv_dx_pack(w3.data_ptr(), w5.data_ptr(), w7.data_ptr(), wpack.data_ptr(), Cout, cin, ld_in,
-                                  stream_ptr()), "tecm_conv_dx_pack")
+    wpack = torch.empty(15 * Cout * nci * 32, device=dy.device, dtype=dy.dtype)
+    pack, run, what = ((lib().tecm_conv_dx_pack_f32, lib().tecm_conv_dx_f32, "tecm_conv_dx_f32") if f32 else
+                       (lib().tecm_conv_dx_pack, lib().tecm_conv_dx_bf16, "tecm_conv_dx_bf16"))
+    check(pack(w3.data_ptr(), w5.data_ptr(), w7.data_ptr(), wpack.data_ptr(), Cout, cin, ld_in, stream_ptr()), what + "/pack")
     d = _lib.TecmConvDx(dy=dy.data_ptr(), wpack=wpack.data_ptr(), dinp=dinp.data_ptr(), B=B, Lc=Lc, N=N, Cout=Cout,
                         ld_in=ld_in)
     if _timing is None:
-        check(lib().tecm_conv_dx_bf16(C.byref(d), stream_ptr()), "tecm_conv_dx_bf16")
+        check(run(C.byref(d), stream_ptr()), what)
         return
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    check(lib().tecm_conv_dx_bf16(C.byref(d), stream_ptr()), "tecm_conv_dx_bf16")
+    check(run(C.byref(d), stream_ptr()), what)
     e1.record()
-    name = "conv_dx_seq_kernel" + (f" M={B * Lc * N} N={ld_in} K={15 * Cout}" if _timing_detail else "")
+    name = ("conv_dx_seq_f32_kernel" if f32 else "conv_dx_seq_kernel") + \
+        (f" M={B * Lc * N} N={ld_in} K={15 * Cout}" if _timing_detail else "")
     _timing.append((name, 2.0 * B * Lc * N * ld_in * 15 * Cout, e0, e1))
+
+
+conv_dx_bf16 = conv_dx      # round-3 name (tests)
 
 
 def transpose_scale(src: torch.Tensor, lds: int, dst: torch.Tensor, ldd: int, rows: int, cols: int, scale: float,

@@ -265,35 +265,39 @@ def test_groupnorm_gelu_bf16_outputs(dev, Bn, L, N, Cout, stride):
         ops.groupnorm_gelu_fwd(y.bfloat16(), g, b, act16, st16, Bn, L, N, Cout)
 
 
+@pytest.mark.parametrize("f32", [False, True], ids=["bf16", "fp32"])
 @pytest.mark.parametrize("Bn,Lc,N,cin,ld_in,Cout", [(2, 48, 5, 22, 24, 64), (1, 24, 9, 64, 64, 128), (1, 96, 3, 22, 24, 64),
                                                   (2, 8, 4, 22, 24, 64), (1, 48, 6, 64, 64, 128), (1, 16, 2911, 22, 24, 64)])
-def test_conv_dx_sequence_tile_kernel(dev, Bn, Lc, N, cin, ld_in, Cout):
-    """csrc/conv_seq.hip: the input gradient of the three parallel Conv1d (modules.py:43-60) from a bf16 dy in one launch,
-    against an fp64 conv-backward of the same bf16-rounded operands (2e-4) and against the three accumulating window GEMMs
-    it replaces (same operands, another summation order: 1e-5).  Ragged node blocks (N % 4 != 0), time chunks (Lc = 96:
-    40 + 40 + 16 steps with halos), both channel widths, the padding columns (cin .. ld_in) exactly zero."""
+def test_conv_dx_sequence_tile_kernel(dev, Bn, Lc, N, cin, ld_in, Cout, f32):
+    """csrc/conv_seq.hip: the input gradient of the three parallel Conv1d (modules.py:43-60) in one launch that reads dy
+    once -- bf16 dy (bf16 mode: operands rounded to bf16, fp32 accumulate) and fp32 dy (exact f32 MFMA) -- against an
+    fp64 conv-backward of the same operands (2e-4 / 2e-5) and against the three accumulating window GEMMs it replaces
+    (same operands, another summation order: 1e-5).  Ragged node blocks (N % 4 != 0), time chunks (Lc = 96 with halos),
+    both channel widths, the padding columns (cin .. ld_in) exactly zero."""
     from tecmollm import ops
     g = torch.Generator().manual_seed(Lc * 1000 + N)
     CT = 3 * Cout
-    dy = (torch.randn(Bn, Lc, N, CT, generator=g) * 0.5).bfloat16()
+    dy = torch.randn(Bn, Lc, N, CT, generator=g) * 0.5
+    dy = dy if f32 else dy.bfloat16()
     ws = [torch.randn(Cout, cin, k, generator=g) / (cin * k) ** 0.5 for k in (3, 5, 7)]
-    # fp64 reference on the rounded operands, sequence-major
+    # fp64 reference on the operands as the kernel sees them, sequence-major
     S = Bn * N
     dys = dy.double().permute(0, 2, 3, 1).reshape(S, CT, Lc)
     ref = torch.zeros(S, cin, Lc, dtype=torch.float64)
     for j, (k, w) in enumerate(zip((3, 5, 7), ws)):
-        ref += torch.nn.grad.conv1d_input((S, cin, Lc), w.bfloat16().double(), dys[:, j * Cout:(j + 1) * Cout].contiguous(),
-                                          padding=(k - 1) // 2)
+        wk = w.double() if f32 else w.bfloat16().double()
+        ref += torch.nn.grad.conv1d_input((S, cin, Lc), wk, dys[:, j * Cout:(j + 1) * Cout].contiguous(), padding=(k - 1) // 2)
     ref = ref.reshape(Bn, N, cin, Lc).permute(0, 3, 1, 2)                      # (B, Lc, N, cin)
     dyd = dy.to(dev)
     wd = [w.to(dev) for w in ws]
     out = torch.full((Bn, Lc, N, ld_in), float("nan"), device=dev)
     assert ops.conv_dx_seq_ok(Lc, Cout, ld_in)
-    ops.conv_dx_bf16(dyd, wd[0], wd[1], wd[2], out, Bn, Lc, N, Cout, cin, ld_in)
+    ops.conv_dx(dyd, wd[0], wd[1], wd[2], out, Bn, Lc, N, Cout, cin, ld_in)
     torch.cuda.synchronize()
     assert torch.isfinite(out).all()
-    assert _rel(out[..., :cin], ref) < TOL
-    assert float(out[..., cin:].abs().max()) == 0.0 if ld_in > cin else True
+    assert _rel(out[..., :cin], ref) < (2e-5 if f32 else TOL)
+    if ld_in > cin:
+        assert float(out[..., cin:].abs().max()) == 0.0
     # the window-GEMM path on the same tensors
     M = Bn * Lc * N
     old = torch.empty(Bn, Lc, N, ld_in, device=dev)
@@ -301,5 +305,5 @@ def test_conv_dx_sequence_tile_kernel(dev, Bn, Lc, N, cin, ld_in, Cout):
         wp = w if ld_in == cin else torch.nn.functional.pad(w, (0, 0, 0, ld_in - cin))
         _, bp = ops.conv_weight_pack(wp.contiguous(), want_bwd=True)
         ops.gemm(M, ld_in, k * Cout, dyd, CT, bp, ld_in, old, ld_in, b_layout=ops.B_KN, a_off=j * Cout,
-                 a_win=ops.win(N, Lc, Lc, 1, k, Cout, (k - 1) // 2), accumulate=(j > 0), bf16=True)
+                 a_win=ops.win(N, Lc, Lc, 1, k, Cout, (k - 1) // 2), accumulate=(j > 0), bf16=not f32)
     assert _rel(out, old) < 1e-5

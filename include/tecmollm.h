@@ -33,7 +33,7 @@ extern "C" {
 #define TECM_E_LAUNCH (-3)     /* hipGetLastError() != hipSuccess after the launch       */
 #define TECM_E_LDS (-4)        /* problem does not fit the 160 KiB LDS budget            */
 
-#define TECM_ABI_VERSION 8
+#define TECM_ABI_VERSION 9
 int tecm_abi_version(void);
 /* Human-readable text for the last error on this thread (host pointer, never NULL). */
 const char* tecm_last_error(void);
@@ -265,6 +265,20 @@ typedef struct TecmConvDx {
 int tecm_conv_dx_pack(const float* w3, const float* w5, const float* w7, void* wpack, int32_t Cout, int32_t Cin,
                       int32_t ld_in, void* stream);
 int tecm_conv_dx_bf16(const TecmConvDx* p, void* stream);
+/* Forward of the same three Conv1d in ONE launch, bf16 mode: y (B, Lc, N, 3*Cout) fp32 = bias + conv(inp), inp bf16
+ * (B, Lc, N, ld_in) with the real channels first (columns >= Cin are ignored: their weights are packed as zeros); bias =
+ * b3 | b5 | b7 (3*Cout floats); wpack from tecm_conv_fwd_pack: sum_j ceil(k_j*ld_in/16) * Cout/32 * 512 bf16 values.
+ * Cout % 32 == 0, Cout <= 128, ld_in % 8 == 0, Lc % 8 == 0. */
+typedef struct TecmConvFwd {
+  const void* inp;
+  const void* wpack;
+  const float* bias;
+  float* y;
+  int32_t B, Lc, N, Cout, ld_in, _pad;
+} TecmConvFwd;
+int tecm_conv_fwd_pack(const float* w3, const float* w5, const float* w7, void* wpack, int32_t Cout, int32_t Cin,
+                       int32_t ld_in, void* stream);
+int tecm_conv_fwd_bf16(const TecmConvFwd* p, void* stream);
 /* The same in exact fp32 (BASELINE configs[1]): dy fp32, v_mfma_f32_32x32x2_f32; wpack from tecm_conv_dx_pack_f32
  * (15*Cout * 32*ceil(ld_in/32) floats). */
 int tecm_conv_dx_pack_f32(const float* w3, const float* w5, const float* w7, float* wpack, int32_t Cout, int32_t Cin,

@@ -294,11 +294,19 @@ class ConvBlockFn(torch.autograd.Function):
         side16 = r16
         y = _empty(B, Lc, N, CT, like=inp)
         packs = []
+        # bf16 mode with a bf16 copy of the input: the three kernel sizes in ONE launch that stages the input rows once
+        # and writes whole rows of y (csrc/conv_seq.hip); otherwise three window GEMMs, one 64- / 128-column slice each
+        fwd_seq = side16 and inp16 is not None and ops.conv_fwd_seq_ok(Lc, Cout, ld_in)
+        if fwd_seq:
+            ops.conv_fwd_bf16(inp16, w3.detach(), w5.detach(), w7.detach(), torch.cat([b3, b5, b7]).detach(), y, B, Lc, N,
+                              Cout, cin, ld_in)
         for j, (w, b) in enumerate(zip(ws, bs)):
             k = w.shape[2]
             wp = w if ld_in == cin else torch.nn.functional.pad(w, (0, 0, 0, ld_in - cin))
             fp, bp = ops.conv_weight_pack(wp.contiguous(), want_bwd=True)
             packs.append(bp)
+            if fwd_seq:
+                continue
             a_in = inp16 if (inp16 is not None and side16 and ld_in % 8 == 0) else inp
             gemm(M, Cout, k * ld_in, a_in, ld_in, fp, k * ld_in, y, CT, c_off=j * Cout,
                  a_win=win(N, Lc, Lc, 1, k, ld_in, (k - 1) // 2), bias=b, bf16=bf16)

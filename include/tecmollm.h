@@ -33,7 +33,7 @@ extern "C" {
 #define TECM_E_LAUNCH (-3)     /* hipGetLastError() != hipSuccess after the launch       */
 #define TECM_E_LDS (-4)        /* problem does not fit the 160 KiB LDS budget            */
 
-#define TECM_ABI_VERSION 9
+#define TECM_ABI_VERSION 10
 int tecm_abi_version(void);
 /* Human-readable text for the last error on this thread (host pointer, never NULL). */
 const char* tecm_last_error(void);
@@ -279,6 +279,11 @@ typedef struct TecmConvFwd {
 int tecm_conv_fwd_pack(const float* w3, const float* w5, const float* w7, void* wpack, int32_t Cout, int32_t Cin,
                        int32_t ld_in, void* stream);
 int tecm_conv_fwd_bf16(const TecmConvFwd* p, void* stream);
+/* ... and in exact fp32 (BASELINE configs[1], also the eval path): inp fp32, v_mfma_f32_32x32x2_f32; wpack from
+ * tecm_conv_fwd_pack_f32: sum_j (k_j*ld_in/8) * Cout/32 * 256 floats. */
+int tecm_conv_fwd_pack_f32(const float* w3, const float* w5, const float* w7, float* wpack, int32_t Cout, int32_t Cin,
+                           int32_t ld_in, void* stream);
+int tecm_conv_fwd_f32(const TecmConvFwd* p, void* stream);
 /* The same in exact fp32 (BASELINE configs[1]): dy fp32, v_mfma_f32_32x32x2_f32; wpack from tecm_conv_dx_pack_f32
  * (15*Cout * 32*ceil(ld_in/32) floats). */
 int tecm_conv_dx_pack_f32(const float* w3, const float* w5, const float* w7, float* wpack, int32_t Cout, int32_t Cin,

@@ -433,8 +433,8 @@ namespace tecm_convseq {
 
 constexpr int FMAXU = 12;      // units: 3 kernel sizes x Cout / 32 channel blocks (Cout <= 128)
 struct FArgs {
-  const __bf16* inp;           // bf16 (B, Lc, N, ld_in)
-  const __bf16* wpack;
+  const void* inp;             // bf16 or fp32 (B, Lc, N, ld_in)
+  const void* wpack;           // fragment-ordered weights, the element type of inp
   const float* bias;           // [3 * Cout]: b3 | b5 | b7
   float* y;                    // fp32 (B, Lc, N, 3 * Cout)
   int B, Lc, N, Cout, ld_in, TC, nchunk, nblk, pitch;
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_fwd_seq_kernel(const FArgs a) {
       const int ng = min(n0 + (row & 3), a.N - 1);
       u32x4 v = {0u, 0u, 0u, 0u};
       if (ts >= 0 && ts < a.Lc)
-        v = *reinterpret_cast<const u32x4*>(a.inp + (((int64_t)b * a.Lc + ts) * a.N + ng) * a.ld_in + ch * 8);
+        v = *reinterpret_cast<const u32x4*>(static_cast<const __bf16*>(a.inp) + (((int64_t)b * a.Lc + ts) * a.N + ng) * a.ld_in + ch * 8);
       *reinterpret_cast<u32x4*>(lds + row * a.pitch + ch * 16) = v;
     }
   }
@@ -525,6 +525,115 @@ __global__ __launch_bounds__(NTH, 2) void conv_fwd_seq_kernel(const FArgs a) {
   }
 }
 
+// The forward in EXACT fp32 (BASELINE configs[1]; also the eval / inference path): input fp32, v_mfma_f32_32x32x2_f32, k in
+// steps of 8 (a lane reads one float4 = k 8 s + 4 h + 0..3 and feeds MFMA j with element j; the weights are packed in the
+// same order).  k_j * ld_in is a multiple of 8 for every kernel size, so there is no k padding and no extra halo step.
+__global__ __launch_bounds__(NTH, 2) void conv_fwd_seq_f32_kernel(const FArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  int tile = blockIdx.x;
+  const int nbk = tile % a.nblk;
+  tile /= a.nblk;
+  const int chunk = tile % a.nchunk, b = tile / a.nchunk;
+  const int n0 = nbk * NB, t0 = chunk * a.TC;
+  const int tc = min(a.TC, a.Lc - t0);
+  const int steps = tc + 7;
+  const int CT = 3 * a.Cout;
+  {
+    const int cpr = a.ld_in / 4;                           // 16-byte chunks per fp32 row
+    const int total = steps * NB * cpr;
+    const float* src = static_cast<const float*>(a.inp);
+    for (int idx = tid; idx < total; idx += NTH) {
+      const int row = idx / cpr, ch = idx - row * cpr;
+      const int ts = t0 - 3 + (row >> 2);
+      const int ng = min(n0 + (row & 3), a.N - 1);
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (ts >= 0 && ts < a.Lc)
+        v = *reinterpret_cast<const u32x4*>(src + (((int64_t)b * a.Lc + ts) * a.N + ng) * a.ld_in + ch * 4);
+      *reinterpret_cast<u32x4*>(lds + row * a.pitch + ch * 16) = v;
+    }
+  }
+  __syncthreads();
+
+  const int ntt = tc >> 3;
+  const int cpt = a.ld_in / 4;                             // float4 chunks per tap
+  const unsigned cpt_magic = (unsigned)((65536 + cpt - 1) / cpt);
+#pragma unroll 1
+  for (int ui = 0; ui < 3; ++ui) {
+    const int u = (int)((a.assign >> (12 * wave + 4 * ui)) & 15ull);
+    if (u == 15) break;
+    const int j = u / a.nb32, kb = u - j * a.nb32;
+    const int pad = j + 1, col0 = j * a.Cout + 32 * kb;
+    const int st3 = 3 * a.ld_in / 8, st5 = 5 * a.ld_in / 8, st7 = 7 * a.ld_in / 8;
+    const int nsteps = j == 0 ? st3 : (j == 1 ? st5 : st7);
+    const int woff = (j == 0 ? 0 : (j == 1 ? st3 : st3 + st5)) * a.nb32 + kb * nsteps;
+    f32x16 acc[MAXT];
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    const f32x4* wp = reinterpret_cast<const f32x4*>(a.wpack) + (int64_t)woff * 64 + lane;
+    f32x4 wf = wp[0];
+    for (int s = 0; s < nsteps; ++s) {
+      f32x4 wn = wf;
+      if (s + 1 < nsteps) wn = wp[(s + 1) * 64];
+      const int q = 2 * s + h;
+      const int tap = (int)((q * cpt_magic) >> 16), c4 = q - tap * cpt;
+      const int off0 = ((tap - pad + 3) * 4 + r) * a.pitch + c4 * 16;
+#pragma unroll
+      for (int i = 0; i < MAXT; ++i) {
+        if (i < ntt) {
+          const f32x4 df = *reinterpret_cast<const f32x4*>(lds + off0 + 32 * i * a.pitch);
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(df[jj], wf[jj], acc[i], 0, 0, 0);
+        }
+      }
+      wf = wn;
+    }
+    const float bv = a.bias[col0 + r];
+    float* yb = a.y + (((int64_t)b * a.Lc + t0 + h) * a.N + n0) * CT + col0 + r;
+    const int tstride = a.N * CT;
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+      if (i < ntt) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int n = e & 3;
+          if (n0 + n < a.N) yb[(8 * i + 2 * (e >> 2)) * tstride + n * CT] = acc[i][e] + bv;
+        }
+      }
+    }
+  }
+}
+
+// fp32 weights in the order of conv_fwd_seq_f32_kernel: k = 8 s + 4 (lane >> 5) + jj = tap * ld_in + ci
+__global__ __launch_bounds__(256) void conv_fwd_pack_f32_kernel(const float* __restrict__ w3, const float* __restrict__ w5,
+                                                                const float* __restrict__ w7, float* __restrict__ wpack,
+                                                                int Cout, int Cin, int ld_in) {
+  const int nblk = Cout / 32;
+  int steps[3], base[3], tot = 0;
+  for (int j = 0; j < 3; ++j) {
+    steps[j] = (3 + 2 * j) * ld_in / 8;
+    base[j] = tot;
+    tot += steps[j] * nblk;
+  }
+  const int total = tot * 256;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int jj = i & 3, lane = (i >> 2) & 63, f = i >> 8;
+    int j = 2;
+    if (f < base[1]) j = 0; else if (f < base[2]) j = 1;
+    const int fl = f - base[j], blk = fl / steps[j], s = fl - blk * steps[j];
+    const int k = 8 * s + 4 * (lane >> 5) + jj;
+    const int tap = k / ld_in, ci = k - tap * ld_in, kj = 3 + 2 * j;
+    const float* w = j == 0 ? w3 : (j == 1 ? w5 : w7);
+    float v = 0.f;
+    if (tap < kj && ci < Cin) v = w[((int64_t)(32 * blk + (lane & 31)) * Cin + ci) * kj + tap];
+    wpack[i] = v;
+  }
+}
+
 // wpack[unit][s][lane][e] = w_j[32 blk + (lane & 31)][ci][tap] for k = 16 s + 8 (lane >> 5) + e = tap * ld_in + ci
 __global__ __launch_bounds__(256) void conv_fwd_pack_kernel(const float* __restrict__ w3, const float* __restrict__ w5,
                                                             const float* __restrict__ w7, __bf16* __restrict__ wpack,
@@ -568,28 +677,28 @@ extern "C" int tecm_conv_fwd_pack(const float* w3, const float* w5, const float*
   return TECM_OK;
 }
 
-extern "C" int tecm_conv_fwd_bf16(const TecmConvFwd* p, void* stream) {
+static int conv_fwd_launch(const TecmConvFwd* p, void* stream, bool f32, const char* who) {
   using namespace tecm_convseq;
-  TECM_REQUIRE(p && p->inp && p->wpack && p->bias && p->y, TECM_E_ARG, "tecm_conv_fwd_bf16: null pointer");
+  TECM_REQUIRE(p && p->inp && p->wpack && p->bias && p->y, TECM_E_ARG, "%s: null pointer", who);
   TECM_REQUIRE(p->B > 0 && p->Lc > 0 && p->N > 0 && p->Lc % 8 == 0, TECM_E_ARG,
-               "tecm_conv_fwd_bf16: bad shape (the sequence length must be a multiple of 8)");
+               "%s: bad shape (the sequence length must be a multiple of 8)", who);
   TECM_REQUIRE(p->Cout % 32 == 0 && p->Cout > 0 && p->Cout <= 128 && p->ld_in % 8 == 0 && p->ld_in > 0 && p->ld_in <= 128,
-               TECM_E_ARG, "tecm_conv_fwd_bf16: Cout a multiple of 32 up to 128, ld_in a multiple of 8 up to 128");
-  TECM_REQUIRE(tecm_aligned(p->inp, 16) && tecm_aligned(p->wpack, 16), TECM_E_ALIGN, "tecm_conv_fwd_bf16: 16-byte aligned pointers");
+               TECM_E_ARG, "%s: Cout a multiple of 32 up to 128, ld_in a multiple of 8 up to 128", who);
+  TECM_REQUIRE(tecm_aligned(p->inp, 16) && tecm_aligned(p->wpack, 16), TECM_E_ALIGN, "%s: 16-byte aligned pointers", who);
   FArgs a;
-  a.inp = static_cast<const __bf16*>(p->inp);
-  a.wpack = static_cast<const __bf16*>(p->wpack);
+  a.inp = p->inp;
+  a.wpack = p->wpack;
   a.bias = p->bias;
   a.y = p->y;
   a.B = p->B; a.Lc = p->Lc; a.N = p->N; a.Cout = p->Cout; a.ld_in = p->ld_in;
-  int slots = p->ld_in * 2 / 16;                           // row pitch in 16-byte slots, odd: conflict-free ds_read_b128
+  int slots = p->ld_in * (f32 ? 4 : 2) / 16;                           // row pitch in 16-byte slots, odd: conflict-free ds_read_b128
   if (slots % 2 == 0) ++slots;
   a.pitch = slots * 16;
   a.TC = 8 * MAXT < p->Lc ? 8 * MAXT : p->Lc;
   a.nchunk = (p->Lc + a.TC - 1) / a.TC;
   a.nblk = (p->N + NB - 1) / NB;
   const size_t lds = (size_t)(a.TC + 7) * NB * a.pitch;
-  TECM_REQUIRE(lds <= 64 * 1024, TECM_E_LDS, "tecm_conv_fwd_bf16: %zu B of LDS per tile", lds);
+  TECM_REQUIRE(lds <= 64 * 1024, TECM_E_LDS, "%s: %zu B of LDS per tile", who, lds);
   // units (kernel size j, 32-channel block), longest first, each to the least loaded wave
   const int nb32 = p->Cout / 32;
   a.nb32 = nb32;
@@ -597,20 +706,39 @@ extern "C" int tecm_conv_fwd_bf16(const TecmConvFwd* p, void* stream) {
   int load[4] = {0, 0, 0, 0}, cnt[4] = {0, 0, 0, 0};
   unsigned long long assign = ~0ull;
   for (int u = nunits - 1; u >= 0; --u) {                  // kernel size 7 first
-    const int j = u / nb32, st = ((3 + 2 * j) * p->ld_in + 15) / 16;
+    const int j = u / nb32, st = f32 ? (3 + 2 * j) * p->ld_in / 8 : ((3 + 2 * j) * p->ld_in + 15) / 16;
     int best = -1;
     for (int w = 0; w < 4; ++w)
       if (cnt[w] < 3 && (best < 0 || load[w] < load[best])) best = w;
-    TECM_REQUIRE(best >= 0, TECM_E_ARG, "tecm_conv_fwd_bf16: more than 12 (kernel size, channel block) units");
+    TECM_REQUIRE(best >= 0, TECM_E_ARG, "%s: more than 12 (kernel size, channel block) units", who);
     const int sh = 12 * best + 4 * cnt[best]++;
     assign = (assign & ~(15ull << sh)) | ((unsigned long long)u << sh);
     load[best] += st;
   }
   a.assign = assign;
   const int64_t tiles = (int64_t)p->B * a.nchunk * a.nblk;
-  TECM_REQUIRE(tiles < ((int64_t)1 << 31), TECM_E_ARG, "tecm_conv_fwd_bf16: too many tiles");
-  hipLaunchKernelGGL(conv_fwd_seq_kernel, dim3((unsigned)tiles), dim3(NTH), lds, (hipStream_t)stream, a);
-  TECM_CHECK_LAUNCH("tecm_conv_fwd_bf16");
+  TECM_REQUIRE(tiles < ((int64_t)1 << 31), TECM_E_ARG, "%s: too many tiles", who);
+  if (f32) hipLaunchKernelGGL(conv_fwd_seq_f32_kernel, dim3((unsigned)tiles), dim3(NTH), lds, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(conv_fwd_seq_kernel, dim3((unsigned)tiles), dim3(NTH), lds, (hipStream_t)stream, a);
+  TECM_CHECK_LAUNCH("tecm_conv_fwd");
+  return TECM_OK;
+}
+
+extern "C" int tecm_conv_fwd_bf16(const TecmConvFwd* p, void* stream) { return conv_fwd_launch(p, stream, false, "tecm_conv_fwd_bf16"); }
+extern "C" int tecm_conv_fwd_f32(const TecmConvFwd* p, void* stream) { return conv_fwd_launch(p, stream, true, "tecm_conv_fwd_f32"); }
+
+extern "C" int tecm_conv_fwd_pack_f32(const float* w3, const float* w5, const float* w7, float* wpack, int32_t Cout,
+                                      int32_t Cin, int32_t ld_in, void* stream) {
+  using namespace tecm_convseq;
+  TECM_REQUIRE(w3 && w5 && w7 && wpack, TECM_E_ARG, "tecm_conv_fwd_pack_f32: null pointer");
+  TECM_REQUIRE(Cout > 0 && Cout % 32 == 0 && Cout <= 128 && Cin > 0 && Cin <= ld_in && ld_in % 8 == 0, TECM_E_ARG,
+               "tecm_conv_fwd_pack_f32: Cout a multiple of 32 up to 128, Cin <= ld_in, ld_in a multiple of 8");
+  int tot = 0;
+  for (int j = 0; j < 3; ++j) tot += ((3 + 2 * j) * ld_in / 8) * (Cout / 32);
+  const int total = tot * 256;
+  hipLaunchKernelGGL(conv_fwd_pack_f32_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w3, w5, w7, wpack,
+                     Cout, Cin, ld_in);
+  TECM_CHECK_LAUNCH("tecm_conv_fwd_pack_f32");
   return TECM_OK;
 }
 

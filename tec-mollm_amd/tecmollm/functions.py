@@ -294,12 +294,14 @@ class ConvBlockFn(torch.autograd.Function):
         side16 = r16
         y = _empty(B, Lc, N, CT, like=inp)
         packs = []
-        # bf16 mode with a bf16 copy of the input: the three kernel sizes in ONE launch that stages the input rows once
-        # and writes whole rows of y (csrc/conv_seq.hip); otherwise three window GEMMs, one 64- / 128-column slice each
-        fwd_seq = side16 and inp16 is not None and ops.conv_fwd_seq_ok(Lc, Cout, ld_in)
+        # the three kernel sizes in ONE launch that stages the input rows once and writes whole rows of y
+        # (csrc/conv_seq.hip): exact fp32 from the fp32 input, the bf16 mode's arithmetic from the bf16 copy of the input;
+        # otherwise (bf16x3 / bf16x6 modes, odd shapes) three window GEMMs, one 64- / 128-column slice each
+        seq_in = inp16 if (side16 and inp16 is not None) else (inp if int(bf16) == ops.PREC_FP32 else None)
+        fwd_seq = seq_in is not None and ops.conv_fwd_seq_ok(Lc, Cout, ld_in)
         if fwd_seq:
-            ops.conv_fwd_bf16(inp16, w3.detach(), w5.detach(), w7.detach(), torch.cat([b3, b5, b7]).detach(), y, B, Lc, N,
-                              Cout, cin, ld_in)
+            ops.conv_fwd(seq_in.detach(), w3.detach(), w5.detach(), w7.detach(), torch.cat([b3, b5, b7]).detach(), y, B, Lc,
+                         N, Cout, cin, ld_in)
         for j, (w, b) in enumerate(zip(ws, bs)):
             k = w.shape[2]
             wp = w if ld_in == cin else torch.nn.functional.pad(w, (0, 0, 0, ld_in - cin))

@@ -437,27 +437,37 @@ def conv_fwd_seq_ok(Lc: int, Cout: int, ld_in: int) -> bool:
             and os.environ.get("TECM_CONV_SEQ", "1")[:1] != "0" and os.environ.get("TECM_CONV_FWD_SEQ", "1")[:1] != "0")
 
 
-def conv_fwd_bf16(inp16: torch.Tensor, w3: torch.Tensor, w5: torch.Tensor, w7: torch.Tensor, bias: torch.Tensor,
-                  y: torch.Tensor, B: int, Lc: int, N: int, Cout: int, cin: int, ld_in: int) -> None:
+def conv_fwd(inp: torch.Tensor, w3: torch.Tensor, w5: torch.Tensor, w7: torch.Tensor, bias: torch.Tensor,
+             y: torch.Tensor, B: int, Lc: int, N: int, Cout: int, cin: int, ld_in: int) -> None:
     """y (B, Lc, N, 3*Cout) fp32 = the three parallel Conv1d (k = 3, 5, 7) of a Multi_Scale_Conv_Block (modules.py:43-60)
-    of inp16 (B, Lc, N, ld_in) bf16, bias (3*Cout) included, in one launch (bf16 mode; csrc/conv_seq.hip)."""
-    if inp16.dtype != torch.bfloat16 or y.dtype != torch.float32:
-        raise _lib.TecmError("conv_fwd_bf16: inp16 is bf16, y fp32")
-    nfrag = sum((((3 + 2 * j) * ld_in + 15) // 16) * (Cout // 32) for j in range(3))
-    wpack = torch.empty(nfrag * 512, device=y.device, dtype=torch.bfloat16)
-    check(lib().tecm_conv_fwd_pack(w3.data_ptr(), w5.data_ptr(), w7.data_ptr(), wpack.data_ptr(), Cout, cin, ld_in,
-                                   stream_ptr()), "tecm_conv_fwd_pack")
-    d = _lib.TecmConvFwd(inp=inp16.data_ptr(), wpack=wpack.data_ptr(), bias=bias.data_ptr(), y=y.data_ptr(), B=B, Lc=Lc,
+    of inp (B, Lc, N, ld_in), bias (3*Cout) included, in one launch (csrc/conv_seq.hip).  inp bf16: the bf16 mode's
+    arithmetic; inp fp32: exact fp32."""
+    if inp.dtype not in (torch.bfloat16, torch.float32) or y.dtype != torch.float32:
+        raise _lib.TecmError("conv_fwd: inp is bf16 or fp32, y fp32")
+    f32 = inp.dtype == torch.float32
+    if f32:
+        nval = sum(((3 + 2 * j) * ld_in // 8) * (Cout // 32) for j in range(3)) * 256
+        pack, run, what = lib().tecm_conv_fwd_pack_f32, lib().tecm_conv_fwd_f32, "tecm_conv_fwd_f32"
+    else:
+        nval = sum((((3 + 2 * j) * ld_in + 15) // 16) * (Cout // 32) for j in range(3)) * 512
+        pack, run, what = lib().tecm_conv_fwd_pack, lib().tecm_conv_fwd_bf16, "tecm_conv_fwd_bf16"
+    wpack = torch.empty(nval, device=y.device, dtype=inp.dtype)
+    check(pack(w3.data_ptr(), w5.data_ptr(), w7.data_ptr(), wpack.data_ptr(), Cout, cin, ld_in, stream_ptr()), what + "/pack")
+    d = _lib.TecmConvFwd(inp=inp.data_ptr(), wpack=wpack.data_ptr(), bias=bias.data_ptr(), y=y.data_ptr(), B=B, Lc=Lc,
                          N=N, Cout=Cout, ld_in=ld_in)
     if _timing is None:
-        check(lib().tecm_conv_fwd_bf16(C.byref(d), stream_ptr()), "tecm_conv_fwd_bf16")
+        check(run(C.byref(d), stream_ptr()), what)
         return
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    check(lib().tecm_conv_fwd_bf16(C.byref(d), stream_ptr()), "tecm_conv_fwd_bf16")
+    check(run(C.byref(d), stream_ptr()), what)
     e1.record()
-    name = "conv_fwd_seq_kernel" + (f" M={B * Lc * N} N={3 * Cout} K={5 * ld_in}(avg)" if _timing_detail else "")
-    _timing.append((name, 2.0 * B * Lc * N * Cout * 15 * cin, e0, e1))
+    name = ("conv_fwd_seq_f32_kernel" if f32 else "conv_fwd_seq_kernel") + \
+        (f" M={B * Lc * N} N={3 * Cout} K={5 * ld_in}(avg)" if _timing_detail else "")
+    _timing.append((name, 2.0 * B * Lc * N * Cout * 15 * ld_in, e0, e1))
+
+
+conv_fwd_bf16 = conv_fwd    # round-3 name (tests)
 
 
 def transpose_scale(src: torch.Tensor, lds: int, dst: torch.Tensor, ldd: int, rows: int, cols: int, scale: float,

@@ -309,9 +309,10 @@ def test_conv_dx_sequence_tile_kernel(dev, Bn, Lc, N, cin, ld_in, Cout, f32):
     assert _rel(out, old) < 1e-5
 
 
+@pytest.mark.parametrize("f32", [False, True], ids=["bf16", "fp32"])
 @pytest.mark.parametrize("Bn,Lc,N,cin,ld_in,Cout", [(2, 48, 5, 22, 24, 64), (1, 24, 9, 64, 64, 128), (1, 96, 3, 22, 24, 64),
                                                   (2, 8, 4, 22, 24, 64), (1, 16, 2911, 22, 24, 64), (1, 48, 7, 64, 64, 128)])
-def test_conv_fwd_sequence_tile_kernel(dev, Bn, Lc, N, cin, ld_in, Cout):
+def test_conv_fwd_sequence_tile_kernel(dev, Bn, Lc, N, cin, ld_in, Cout, f32):
     """csrc/conv_seq.hip: the three parallel Conv1d (k = 3, 5, 7, modules.py:43-60) of a bf16 input in one launch (bias
     included, whole rows of y written once) against an fp64 convolution of the same bf16-rounded operands (2e-4) and
     against the three window GEMMs it replaces (same operands, same k order: 1e-5).  Ragged node blocks, time chunks
@@ -320,12 +321,12 @@ def test_conv_fwd_sequence_tile_kernel(dev, Bn, Lc, N, cin, ld_in, Cout):
     g = torch.Generator().manual_seed(Lc * 1000 + N + 1)
     CT = 3 * Cout
     x = torch.randn(Bn, Lc, N, ld_in, generator=g)
-    x16 = x.bfloat16()
+    x16 = x if f32 else x.bfloat16()
     ws = [torch.randn(Cout, cin, k, generator=g) / (cin * k) ** 0.5 for k in (3, 5, 7)]
     bs = [torch.randn(Cout, generator=g) * 0.1 for _ in range(3)]
     S = Bn * N
     xs = x16[..., :cin].double().permute(0, 2, 3, 1).reshape(S, cin, Lc)
-    ref = torch.cat([torch.nn.functional.conv1d(xs, w.bfloat16().double(), b.double(), padding=(k - 1) // 2)
+    ref = torch.cat([torch.nn.functional.conv1d(xs, (w if f32 else w.bfloat16()).double(), b.double(), padding=(k - 1) // 2)
                      for k, w, b in zip((3, 5, 7), ws, bs)], dim=1)                       # (S, CT, Lc)
     ref = ref.reshape(Bn, N, CT, Lc).permute(0, 3, 1, 2)                                # (B, Lc, N, CT)
     xd = x16.to(dev)
@@ -333,15 +334,15 @@ def test_conv_fwd_sequence_tile_kernel(dev, Bn, Lc, N, cin, ld_in, Cout):
     bias = torch.cat(bs).to(dev)
     y = torch.full((Bn, Lc, N, CT), float("nan"), device=dev)
     assert ops.conv_fwd_seq_ok(Lc, Cout, ld_in)
-    ops.conv_fwd_bf16(xd, wd[0], wd[1], wd[2], bias, y, Bn, Lc, N, Cout, cin, ld_in)
+    ops.conv_fwd(xd, wd[0], wd[1], wd[2], bias, y, Bn, Lc, N, Cout, cin, ld_in)
     torch.cuda.synchronize()
     assert torch.isfinite(y).all()
-    assert _rel(y, ref) < TOL
+    assert _rel(y, ref) < (2e-5 if f32 else TOL)
     M = Bn * Lc * N
     old = torch.empty(Bn, Lc, N, CT, device=dev)
     for j, (k, w) in enumerate(zip((3, 5, 7), wd)):
         wp = w if ld_in == cin else torch.nn.functional.pad(w, (0, 0, 0, ld_in - cin))
         fp, _ = ops.conv_weight_pack(wp.contiguous(), want_bwd=False)
         ops.gemm(M, Cout, k * ld_in, xd, ld_in, fp, k * ld_in, old, CT, c_off=j * Cout,
-                 a_win=ops.win(N, Lc, Lc, 1, k, ld_in, (k - 1) // 2), bias=bias[j * Cout:(j + 1) * Cout].contiguous(), bf16=True)
+                 a_win=ops.win(N, Lc, Lc, 1, k, ld_in, (k - 1) // 2), bias=bias[j * Cout:(j + 1) * Cout].contiguous(), bf16=not f32)
     assert _rel(y, old) < 1e-5

@@ -435,7 +435,18 @@ def test_bench_multi_gpu_launcher_fails_loudly_without_gpus():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TECM_DIST_BACKEND")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode != 0 and "visible GPUs" in r.stderr and not r.stdout.strip()
+    # the launcher counts GPUs from sysfs; where the KFD topology is not readable (this container) the ranks refuse
+    assert r.returncode != 0 and not r.stdout.strip()
+    assert "visible GPUs" in r.stderr or "needs MI355X GPUs" in r.stderr
+    # a readable topology with ONE GPU: the launcher itself refuses, before starting any rank
+    import tempfile
+    with tempfile.TemporaryDirectory() as topo:
+        for i, simd in enumerate((0, 1024)):
+            os.makedirs(os.path.join(topo, str(i)))
+            open(os.path.join(topo, str(i), "properties"), "w").write(f"simd_count {simd}\n")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                           env=dict(env, TECM_KFD_TOPOLOGY=topo), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "needs 2 visible GPUs" in r.stderr and not r.stdout.strip()
     # under torchrun-style env with a mismatching --gpus the rank refuses as well
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"],
                        env=dict(env, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)

@@ -8,6 +8,7 @@ namespace {
 // Lane = output element (coalesced over each slab), the block's 4 waves take the slabs in turn with four loads in
 // flight each: a dW GEMM of this path has up to 256 slabs of a few thousand elements, so one thread walking all
 // slabs of its element is a serial chain of ~64 dependent-latency steps (36 us per call, 17 calls per step).
+template <int U>   // slabs in flight per lane; the four waves cover 4*U splits per round of memory latency
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const TecmGemm g, int splits) {
   __shared__ float red[4][64];
   const int64_t total = g.M * g.N;
@@ -15,15 +16,24 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const TecmGemm g, in
   const tecm_gemm::DropCtx odc = tecm_gemm::make_drop(g.out_drop);
   for (int64_t i0 = (int64_t)blockIdx.x * 64; i0 < total; i0 += (int64_t)gridDim.x * 64) {
     const int64_t i = i0 + lane;
-    float v4[4] = {0.f, 0.f, 0.f, 0.f};
-    if (i < total) {
-      for (int s = wave; s < splits; s += 16) {
+    float v16[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (s + 4 * u < splits) v4[u] += g.workspace[(int64_t)(s + 4 * u) * total + i];
+    for (int u = 0; u < U; ++u) v16[u] = 0.f;
+    if (i < total) {
+      for (int s = wave; s < splits; s += 4 * U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {                  // clamped slab + select: the bound is wave-uniform, an `if` would be
+          const int sl = s + 4 * u;                     // a branch (and a wait) per load
+          const float v = g.workspace[(int64_t)(sl < splits ? sl : splits - 1) * total + i];
+          v16[u] += sl < splits ? v : 0.f;
+        }
       }
     }
-    red[wave][lane] = (v4[0] + v4[1]) + (v4[2] + v4[3]);
+#pragma unroll
+    for (int u = U / 2; u > 0; u >>= 1)
+#pragma unroll
+      for (int v = 0; v < u; ++v) v16[v] += v16[v + u];
+    red[wave][lane] = v16[0];
     __syncthreads();
     if (wave == 0 && i < total) {
       const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
@@ -189,7 +199,12 @@ static int gemm_entry(const TecmGemm* d, void* stream, int mode) {
     const int64_t total = g.M * g.N;
     const int64_t want = (total + 63) / 64;
     const int blocks = (int)(want < 4096 ? want : 4096);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, gk, splits);
+    if (splits > 32)
+      hipLaunchKernelGGL(splitk_reduce_kernel<16>, dim3(blocks), dim3(256), 0, st, gk, splits);
+    else if (splits > 16)
+      hipLaunchKernelGGL(splitk_reduce_kernel<8>, dim3(blocks), dim3(256), 0, st, gk, splits);
+    else
+      hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(blocks), dim3(256), 0, st, gk, splits);
     TECM_CHECK_LAUNCH("tecm_gemm_f32/splitk_reduce");
   }
   if (erf) {

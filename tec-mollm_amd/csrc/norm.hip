@@ -723,33 +723,38 @@ __global__ __launch_bounds__(256) void colsum_stage1_v4(const float* __restrict_
   }
 }
 
-__global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ ws, int RB, int nseg, int C,
+// stage 2: 512 threads = 8 waves per 64 columns, 32 loads in flight per lane: 1024 partial rows are four rounds of
+// memory latency (the first version -- 4 waves, 16 in flight -- took sixteen: 23 us per launch, 68 launches a step).
+__global__ __launch_bounds__(512) void colsum_stage2(const float* __restrict__ ws, int RB, int nseg, int C,
                                                      float* __restrict__ out, int64_t ldo, int accumulate,
                                                      float scale) {
-  __shared__ float red[4][64];
+  __shared__ float red[8][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane, s = blockIdx.y;
   float acc = 0.f;
   if (c < C) {
-    // up to 1024 partial rows: sixteen loads in flight per lane, or the pass is a chain of dependent-latency steps
-    float a16[16];
+    float a32[32];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) a16[u] = 0.f;
-    for (int rb = wave; rb < RB; rb += 64) {
+    for (int u = 0; u < 32; ++u) a32[u] = 0.f;
+    for (int rb = wave; rb < RB; rb += 256) {
 #pragma unroll
-      for (int u = 0; u < 16; ++u)
-        if (rb + 4 * u < RB) a16[u] += ws[((int64_t)s * RB + rb + 4 * u) * C + c];
+      for (int u = 0; u < 32; ++u) {                    // clamped row + select, not `if`: the bound is wave-uniform, a branch
+        const int r = rb + 8 * u;                       // per load would put a wait between every two of them
+        const float v = ws[((int64_t)s * RB + (r < RB ? r : RB - 1)) * C + c];
+        a32[u] += r < RB ? v : 0.f;
+      }
     }
 #pragma unroll
-    for (int u = 8; u > 0; u >>= 1)
+    for (int u = 16; u > 0; u >>= 1)
 #pragma unroll
-      for (int v = 0; v < u; ++v) a16[v] += a16[v + u];
-    acc = a16[0];
+      for (int v = 0; v < u; ++v) a32[v] += a32[v + u];
+    acc = a32[0];
   }
   red[wave][lane] = acc;
   __syncthreads();
   if (wave == 0 && c < C) {
-    const float v = ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) * scale;
+    const float v = (((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) +
+                     ((red[4][lane] + red[5][lane]) + (red[6][lane] + red[7][lane]))) * scale;
     float* o = out + (int64_t)s * ldo + c;
     *o = accumulate ? *o + v : v;
   }
@@ -985,7 +990,7 @@ extern "C" int tecm_colsum(const float* in, int64_t ld, int64_t outer, int64_t i
     hipLaunchKernelGGL(colsum_stage1_v4, dim3((unsigned)rb4, nseg), dim3(256), 0, st, in, ld, outer, inner, nseg, C,
                        idc, workspace, chunk4);
     TECM_CHECK_LAUNCH("tecm_colsum/stage1_v4");
-    hipLaunchKernelGGL(colsum_stage2, dim3(colblocks, nseg), dim3(256), 0, st, workspace, (int)rb4, nseg, C, out, ldo,
+    hipLaunchKernelGGL(colsum_stage2, dim3(colblocks, nseg), dim3(512), 0, st, workspace, (int)rb4, nseg, C, out, ldo,
                        accumulate, scale);
     TECM_CHECK_LAUNCH("tecm_colsum/stage2");
     return TECM_OK;
@@ -993,7 +998,7 @@ extern "C" int tecm_colsum(const float* in, int64_t ld, int64_t outer, int64_t i
   hipLaunchKernelGGL(colsum_stage1, dim3(colblocks, (unsigned)rb, nseg), dim3(256), 0, st, in, ld, outer, inner, nseg,
                      C, idc, workspace, chunk);
   TECM_CHECK_LAUNCH("tecm_colsum/stage1");
-  hipLaunchKernelGGL(colsum_stage2, dim3(colblocks, nseg), dim3(256), 0, st, workspace, (int)rb, nseg, C, out, ldo,
+  hipLaunchKernelGGL(colsum_stage2, dim3(colblocks, nseg), dim3(512), 0, st, workspace, (int)rb, nseg, C, out, ldo,
                      accumulate, scale);
   TECM_CHECK_LAUNCH("tecm_colsum/stage2");
   return TECM_OK;

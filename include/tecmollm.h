@@ -33,7 +33,7 @@ extern "C" {
 #define TECM_E_LAUNCH (-3)     /* hipGetLastError() != hipSuccess after the launch       */
 #define TECM_E_LDS (-4)        /* problem does not fit the 160 KiB LDS budget            */
 
-#define TECM_ABI_VERSION 10
+#define TECM_ABI_VERSION 11
 int tecm_abi_version(void);
 /* Human-readable text for the last error on this thread (host pointer, never NULL). */
 const char* tecm_last_error(void);
@@ -82,10 +82,16 @@ enum { TECM_ACT_NONE = 0, TECM_ACT_GELU_ERF = 1, TECM_ACT_GELU_TANH = 2 };
  * 16-byte aligned, K % 8 == 0); the call must be the plain MK x NK contraction.  TECM_IO_C_BF16 writes C as bf16
  * (ldc in bf16 elements; needs the float4-friendly epilogue, no residual / accumulate / c_win / split_k); preact,
  * dact_src, bias stay fp32.  Rounding an activation once where it is produced instead of at every consumer's
- * loader gives bit-identical results at half the bytes. */
+ * loader gives bit-identical results at half the bytes.
+ * TECM_IO_PRE_BF16: `preact` and `dact_src` are bf16 tensors (ldp / ldd in bf16 elements, multiples of 4, 8-byte
+ * aligned; float4-friendly epilogue, tanh-GELU only, no split_k).  The value is rounded to bf16 BEFORE the
+ * activation -- the store is `preact = bf16(v); v = act(float(preact))` -- so the forward's act() and the
+ * backward's act'() are evaluated at the same point: what torch.autocast does to the output of a Linear that
+ * feeds an activation (train.py:68), and what the bf16-emulating oracle (oracle/ref_cpu.BF16) restates. */
 #define TECM_IO_A_BF16 1
 #define TECM_IO_B_BF16 2
 #define TECM_IO_C_BF16 4
+#define TECM_IO_PRE_BF16 8
 typedef struct TecmGemm {
   int64_t M, N, K;
   const float* A; int64_t lda; int32_t a_layout; int32_t io_bf16; TecmWin a_win; TecmDrop a_drop;

@@ -149,7 +149,8 @@ def _ident(t: torch.Tensor) -> torch.Tensor:
 class Rounding:
     """Operand rounding of the dense contractions as a PAIR: `fwd` is applied to both operands of a forward
     contraction, `bwd` to both operands of the two contractions its backward consists of (dX = dY.W^T and
-    dW = X^T.dY).  Accumulation, bias, activation, dropout, norms, softmax and the GATv2 stage are fp32 in every mode.
+    dW = X^T.dY).  Accumulation, bias, activation, dropout, norms, softmax and the GATv2 stage are fp32 in every mode;
+    the one activation INPUT that is rounded is the GPT-2 c_fc output (`stored`, below).
     FP32 = the reference's CPU arithmetic.  BF16 = what `torch.autocast('cuda', bfloat16)` (train.py:68) does to the
     operands of Linear / Conv1d / matmul, forward AND backward, as the MI355X bf16 mode implements it: fp32 outputs,
     bf16 operands.  A tensor the HIP path stores in HBM as bf16 (LN outputs, attention context, gelu(c_fc), conv
@@ -171,6 +172,23 @@ BF16_FORWARD_ONLY = Rounding(bf16_round, None, "bf16-forward-only")   # forward 
 
 def _r(fn, t):
     return t if fn is None else fn(t)
+
+
+class _StoreRounded(torch.autograd.Function):
+    """A tensor kept in bf16 between its producer and a NON-contraction reader (the c_fc output GELU is evaluated
+    at, forward and backward): rounded where it is stored, gradient passed through unchanged."""
+
+    @staticmethod
+    def forward(ctx, t, fn):
+        return fn(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+def stored(t: torch.Tensor, q: "Rounding") -> torch.Tensor:
+    return t if q.fwd is None else _StoreRounded.apply(t, q.fwd)
 
 
 class _MatMul(torch.autograd.Function):
@@ -306,7 +324,8 @@ def gpt2_lora(h: torch.Tensor, p: Params, n_layers: int, q: Rounding = FP32, mas
         ctx = (w @ v).transpose(1, 2).reshape(S, T, D)
         h = h + _mul(mm(ctx, p[pre + "attn.c_proj.weight"], q) + p[pre + "attn.c_proj.bias"], masks, f"res1_{i}")
         u = F.layer_norm(h, (D,), p[pre + "ln_2.weight"], p[pre + "ln_2.bias"], LN_EPS)
-        f = gelu_new(mm(u, p[pre + "mlp.c_fc.weight"], q) + p[pre + "mlp.c_fc.bias"])
+        # autocast's c_fc output IS a bf16 tensor (train.py:68): GELU and its derivative see the rounded value
+        f = gelu_new(stored(mm(u, p[pre + "mlp.c_fc.weight"], q) + p[pre + "mlp.c_fc.bias"], q))
         h = h + _mul(mm(f, p[pre + "mlp.c_proj.weight"], q) + p[pre + "mlp.c_proj.bias"], masks, f"res2_{i}")
     return F.layer_norm(h, (D,), p[P_GPT + "ln_f.weight"], p[P_GPT + "ln_f.bias"], LN_EPS)
 

@@ -131,8 +131,11 @@ static int gemm_entry(const TecmGemm* d, void* stream, int mode) {
   // float4 epilogue only when everything it touches is 16-byte friendly
   auto ok4 = [](const void* p, int64_t ld) { return p == nullptr || (tecm_aligned(p, 16) && ld % 4 == 0); };
   const bool c16 = (g.io_bf16 & TECM_IO_C_BF16) != 0;
-  const bool vec4 = g.N % 4 == 0 && (c16 ? (tecm_aligned(g.C, 8) && g.ldc % 4 == 0) : ok4(g.C, g.ldc)) && ok4(g.bias, 4) && ok4(g.rowbias, g.rb_ld) &&
-                    ok4(g.preact, g.ldp) && ok4(g.dact_src, g.ldd) && ok4(g.residual, g.ldr) &&
+  const bool p16 = (g.io_bf16 & TECM_IO_PRE_BF16) != 0;
+  auto ok4h = [](const void* p, int64_t ld) { return p == nullptr || (tecm_aligned(p, 8) && ld % 4 == 0); };   // bf16 quads
+  const bool vec4 = g.N % 4 == 0 && (c16 ? ok4h(g.C, g.ldc) : ok4(g.C, g.ldc)) && ok4(g.bias, 4) && ok4(g.rowbias, g.rb_ld) &&
+                    (p16 ? ok4h(g.preact, g.ldp) && ok4h(g.dact_src, g.ldd) : ok4(g.preact, g.ldp) && ok4(g.dact_src, g.ldd)) &&
+                    ok4(g.residual, g.ldr) &&
                     (!g.c_win.enabled || g.c_win.Cw % 4 == 0) &&
                     (g.split_k <= 1 || tecm_aligned(g.workspace, 16));
   if (c16) TECM_REQUIRE(vec4, TECM_E_ALIGN, "tecm_gemm_bf16: bf16 C needs 16-byte friendly epilogue operands");
@@ -145,7 +148,7 @@ static int gemm_entry(const TecmGemm* d, void* stream, int mode) {
     TECM_REQUIRE(avec == 4 && bvec == 4, TECM_E_ALIGN,
                  "tecm_gemm_bf16x3: operands must be 16-byte aligned with leading dims / K multiples of 4");
   }
-  const int io = g.io_bf16 & (TECM_IO_A_BF16 | TECM_IO_B_BF16 | TECM_IO_C_BF16);
+  const int io = g.io_bf16 & (TECM_IO_A_BF16 | TECM_IO_B_BF16 | TECM_IO_C_BF16 | TECM_IO_PRE_BF16);
   TECM_REQUIRE(io == g.io_bf16, TECM_E_ARG, "tecm_gemm: unknown io_bf16 bits");
   if (io) {
     TECM_REQUIRE(bf16, TECM_E_ARG, "tecm_gemm: bf16 tensors in HBM are served by tecm_gemm_bf16 only");
@@ -163,6 +166,10 @@ static int gemm_entry(const TecmGemm* d, void* stream, int mode) {
       TECM_REQUIRE((g.b_layout == TECM_B_NK ? g.K : g.N) % 8 == 0 && (!g.b_win.enabled || g.b_win.Cw % 8 == 0), TECM_E_ARG,
                    "tecm_gemm_bf16: bf16 B needs its contiguous extent (K for NK, N for KN) and b_win.Cw to be multiples of 8");
     }
+    if (io & TECM_IO_PRE_BF16)
+      TECM_REQUIRE(vec4 && (g.preact || g.dact_src) && g.split_k <= 1 && g.act != TECM_ACT_GELU_ERF && !g.c_win.enabled &&
+                       !g.rowbias,
+                   TECM_E_ARG, "tecm_gemm_bf16: a bf16 preact / dact_src needs the 16-byte friendly plain tanh-GELU epilogue");
     if (io & TECM_IO_C_BF16)
       TECM_REQUIRE(vec4 && !g.residual && !g.accumulate && !g.c_win.enabled && g.split_k <= 1 &&
                        g.act != TECM_ACT_GELU_ERF,

@@ -449,9 +449,25 @@ __device__ __forceinline__ void epi_vec4(const TecmGemm& g, const DropCtx& odc, 
     const float4 t = *reinterpret_cast<const float4*>(r.rb + n);
     o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w;
   }
-  if (g.preact) *reinterpret_cast<float4*>(g.preact + r.m * g.ldp + n) = make_float4(o[0], o[1], o[2], o[3]);
+  const bool p16 = (g.io_bf16 & TECM_IO_PRE_BF16) != 0;
+  if (g.preact) {
+    if (p16) {                             // bf16 pre-activation: act() below is evaluated at the ROUNDED value, the
+      tecm_bf16x4 h;                       // point the backward's act'() reads back
+      h[0] = (__bf16)o[0]; h[1] = (__bf16)o[1]; h[2] = (__bf16)o[2]; h[3] = (__bf16)o[3];
+      *reinterpret_cast<tecm_bf16x4*>(reinterpret_cast<__bf16*>(g.preact) + r.m * g.ldp + n) = h;
+      o[0] = (float)h[0]; o[1] = (float)h[1]; o[2] = (float)h[2]; o[3] = (float)h[3];
+    } else {
+      *reinterpret_cast<float4*>(g.preact + r.m * g.ldp + n) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
   if (g.dact_src) {
-    const float4 t = *reinterpret_cast<const float4*>(g.dact_src + r.m * g.ldd + n);
+    float4 t;
+    if (p16) {
+      const tecm_bf16x4 h = *reinterpret_cast<const tecm_bf16x4*>(reinterpret_cast<const __bf16*>(g.dact_src) + r.m * g.ldd + n);
+      t = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+    } else {
+      t = *reinterpret_cast<const float4*>(g.dact_src + r.m * g.ldd + n);
+    }
     o[0] *= dgelu_tanh(t.x); o[1] *= dgelu_tanh(t.y);
     o[2] *= dgelu_tanh(t.z); o[3] *= dgelu_tanh(t.w);
   } else if (g.act) {
@@ -508,6 +524,17 @@ __device__ __forceinline__ void epi_fast_load(const TecmGemm& g, int lrow, int64
     if (!ecol.ok) return;
     const float* src = MODE == 1 ? g.residual : (MODE == 2 ? g.dact_src : g.C);
     const int64_t ld = MODE == 1 ? g.ldr : (MODE == 2 ? g.ldd : g.ldc);
+    if (MODE == 2 && (g.io_bf16 & TECM_IO_PRE_BF16)) {   // bf16 GELU' source: the RAW 8 bytes travel in in[].x/.y and are
+#pragma unroll                                            // widened where they are used (converting here would be a wait)
+      for (int it = 0; it < NIT; ++it) {
+        int64_t m = mrow0 + it * RPI + lrow;
+        m = m < g.M ? m : g.M - 1;
+        const float2 raw = *reinterpret_cast<const float2*>(reinterpret_cast<const __bf16*>(src) + m * ld + ecol.n);
+        in[it].x = raw.x;
+        in[it].y = raw.y;
+      }
+      return;
+    }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       int64_t m = mrow0 + it * RPI + lrow;
@@ -523,6 +550,7 @@ __device__ __forceinline__ void epi_fast_rows(const TecmGemm& g, const DropCtx& 
   if (!ecol.ok) return;
   const int32_t n = ecol.n;
   const bool c16 = (g.io_bf16 & TECM_IO_C_BF16) != 0;
+  const bool p16 = (g.io_bf16 & TECM_IO_PRE_BF16) != 0;
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int rl = it * RPI + lrow;
@@ -534,7 +562,16 @@ __device__ __forceinline__ void epi_fast_rows(const TecmGemm& g, const DropCtx& 
       continue;
     }
     float o[4] = {v.x * g.alpha + bias4.x, v.y * g.alpha + bias4.y, v.z * g.alpha + bias4.z, v.w * g.alpha + bias4.w};
-    if (g.preact && row_ok) {
+    if (g.preact && p16) {                             // bf16 pre-activation (see epi_vec4)
+      tecm_bf16x4 hv;
+      hv[0] = (__bf16)o[0]; hv[1] = (__bf16)o[1]; hv[2] = (__bf16)o[2]; hv[3] = (__bf16)o[3];
+      if (row_ok) {
+        tecm_bf16x4* dst = reinterpret_cast<tecm_bf16x4*>(reinterpret_cast<__bf16*>(g.preact) + m * g.ldp + n);
+        if constexpr (NT) __builtin_nontemporal_store(hv, dst);
+        else *dst = hv;
+      }
+      o[0] = (float)hv[0]; o[1] = (float)hv[1]; o[2] = (float)hv[2]; o[3] = (float)hv[3];
+    } else if (g.preact && row_ok) {
       if constexpr (NT) {                              // streamed past L2: the operand panels stay (bf16 LDS-DMA kernel)
         f32x4 nv = {o[0], o[1], o[2], o[3]};
         __builtin_nontemporal_store(nv, reinterpret_cast<f32x4*>(g.preact + m * g.ldp + n));
@@ -543,8 +580,14 @@ __device__ __forceinline__ void epi_fast_rows(const TecmGemm& g, const DropCtx& 
       }
     }
     if constexpr (MODE == 2) {
-      o[0] *= dgelu_tanh(in[it].x); o[1] *= dgelu_tanh(in[it].y);
-      o[2] *= dgelu_tanh(in[it].z); o[3] *= dgelu_tanh(in[it].w);
+      float t0 = in[it].x, t1 = in[it].y, t2 = in[it].z, t3 = in[it].w;
+      if (p16) {                                       // widen the raw bf16 quad carried in .x/.y
+        const uint32_t lo = __builtin_bit_cast(uint32_t, in[it].x), hi = __builtin_bit_cast(uint32_t, in[it].y);
+        t0 = __builtin_bit_cast(float, lo << 16); t1 = __builtin_bit_cast(float, lo & 0xffff0000u);
+        t2 = __builtin_bit_cast(float, hi << 16); t3 = __builtin_bit_cast(float, hi & 0xffff0000u);
+      }
+      o[0] *= dgelu_tanh(t0); o[1] *= dgelu_tanh(t1);
+      o[2] *= dgelu_tanh(t2); o[3] *= dgelu_tanh(t3);
     } else {
       if (g.act) {
 #pragma unroll

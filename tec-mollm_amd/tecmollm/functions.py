@@ -21,6 +21,8 @@ from ._lib import TecmSpatial, TecmSpatialGrads, check, lib, stream_ptr
 from .graph import GraphMeta
 from .ops import (A_KM, A_MK, ACT_GELU_ERF, ACT_GELU_TANH, B_KN, B_NK, colsum, drop, gemm, pick_split_k, win)
 
+PRE16 = os.environ.get("TECM_PRE16", "1")[:1] != "0"     # diagnostics: "0" keeps the GPT-2 MLP pre-activation fp32
+
 import ctypes as C
 
 CP = 24            # C = 22 feature channels padded to a multiple of 4 floats (16-byte rows)
@@ -568,9 +570,11 @@ class GPT2StackFn(torch.autograd.Function):
             else:
                 u2 = _empty(M, D, like=h)
                 ops.layernorm_fwd(h2, D, ln2w, ln2b, u2, D, st2, M, D)
-            a = _empty(M, F4, like=h)
-            # gelu(fc) is only ever read by the c_proj GEMM: in bf16 mode it is written as bf16
+            # gelu(fc) is only ever read by the c_proj GEMM: in bf16 mode it is written as bf16.  The pre-activation
+            # the backward differentiates GELU at is bf16 too (TECM_IO_PRE_BF16: rounded BEFORE the activation, as
+            # autocast's bf16 Linear output is) -- a third less to write here, half as much to read back there.
             f16 = b16 and Wfc_f.dtype == torch.bfloat16 and Wpr_f.dtype == torch.bfloat16
+            a = torch.empty(M, F4, device=h.device, dtype=torch.bfloat16 if f16 and PRE16 else torch.float32)
             f = torch.empty(M, F4, device=h.device, dtype=torch.bfloat16 if f16 else torch.float32)
             gemm(M, F4, D, u2, D, Wfc_f, ldfc_f, f, F4, b_layout=lay_fc, bias=bfc, preact=(a, F4), act=ACT_GELU_TANH,
                  bf16=plan.bf16)

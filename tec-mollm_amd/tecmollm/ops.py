@@ -67,6 +67,11 @@ def gemm(M: int, N: int, K: int, A: torch.Tensor, lda: int, B: torch.Tensor, ldb
     g.M, g.N, g.K = M, N, K
     io = (IO_A_BF16 if A.dtype == torch.bfloat16 else 0) | (IO_B_BF16 if B.dtype == torch.bfloat16 else 0) | \
          (IO_C_BF16 if Cout.dtype == torch.bfloat16 else 0)
+    pre = preact if preact is not None else dact_src
+    if pre is not None and pre[0].dtype == torch.bfloat16:
+        if preact is not None and dact_src is not None and dact_src[0].dtype != torch.bfloat16:
+            raise ValueError("gemm: preact and dact_src must share a dtype")
+        io |= IO_PRE_BF16
     if io:
         if int(bf16) != PREC_BF16:
             raise _lib.TecmError("bf16 tensors are accepted by the bf16 GEMM only")
@@ -121,7 +126,7 @@ def gemm(M: int, N: int, K: int, A: torch.Tensor, lda: int, B: torch.Tensor, ldb
 
 
 PREC_FP32, PREC_BF16, PREC_BF16X3, PREC_BF16X6 = 0, 1, 2, 3
-IO_A_BF16, IO_B_BF16, IO_C_BF16 = 1, 2, 4       # TecmGemm.io_bf16
+IO_A_BF16, IO_B_BF16, IO_C_BF16, IO_PRE_BF16 = 1, 2, 4, 8       # TecmGemm.io_bf16
 GROUP_M = 0          # m-tiles per L2 super-tile of the fp32 GEMM (0 = the kernel's default, 8); tools/ sweep it
 BF16_MIN_N = 64
 

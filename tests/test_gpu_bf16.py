@@ -162,6 +162,13 @@ def test_bf16_dma_kernel_matches_the_register_staged_kernel_bit_for_bit(dev, M, 
         d16 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
         ops.gemm(M, N, K, A16, K, B16, K, d16, N, act=ops.ACT_GELU_TANH, dact_src=(pre_src, N), bf16=True)
         outs.append(d16)
+        # bf16 pre-activation (TECM_IO_PRE_BF16): the forward store and the backward read of the GPT-2 MLP
+        e16, pre16 = torch.empty(M, N, device=dev, dtype=torch.bfloat16), torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        ops.gemm(M, N, K, A16, K, B16, K, e16, N, bias=bias, act=ops.ACT_GELU_TANH, preact=(pre16, N), bf16=True)
+        outs += [e16, pre16]
+        f16 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        ops.gemm(M, N, K, A16, K, B16, K, f16, N, act=ops.ACT_GELU_TANH, dact_src=(pre_src.bfloat16(), N), bf16=True)
+        outs.append(f16)
         torch.cuda.synchronize()
         return outs
 
@@ -173,6 +180,33 @@ def test_bf16_dma_kernel_matches_the_register_staged_kernel_bit_for_bit(dev, M, 
         assert torch.equal(g_, w_)
     ref = A16.double() @ B16.double().t()
     assert _rel(want[1], ref + bias.double()) < TOL
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 256, 96), (1000, 3072, 768), (77, 64, 72)])
+def test_bf16_preactivation_is_rounded_before_the_activation(dev, M, N, K):
+    """TECM_IO_PRE_BF16: preact = bf16(acc + bias), C = gelu(float(preact)); the backward form multiplies by gelu'
+    evaluated at the same bf16 values.  The stored pre-activation equals the fp32 one rounded (RNE) bit for bit."""
+    from tecmollm import ops
+    A16, B16 = _rand(M, K, dev=dev, seed=1).bfloat16(), _rand(N, K, dev=dev, seed=2, scale=0.2).bfloat16()
+    bias = _rand(N, dev=dev, seed=4)
+    c32, pre32 = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
+    ops.gemm(M, N, K, A16, K, B16, K, c32, N, bias=bias, act=ops.ACT_GELU_TANH, preact=(pre32, N), bf16=True)
+    c, pre16 = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    ops.gemm(M, N, K, A16, K, B16, K, c, N, bias=bias, act=ops.ACT_GELU_TANH, preact=(pre16, N), bf16=True)
+    assert torch.equal(pre16, pre32.bfloat16())
+    ref = torch.nn.functional.gelu(pre16.double(), approximate="tanh")
+    assert float((c.double() - ref).abs().max()) < 2e-6 * max(1.0, float(ref.abs().max()))
+    # backward form: d = (A.B^T) * gelu'(pre16) against autograd's derivative at the rounded point
+    d, d32 = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
+    ops.gemm(M, N, K, A16, K, B16, K, d, N, act=ops.ACT_GELU_TANH, dact_src=(pre16, N), bf16=True)
+    ops.gemm(M, N, K, A16, K, B16, K, d32, N, act=ops.ACT_GELU_TANH, dact_src=(pre16.float(), N), bf16=True)
+    assert torch.equal(d, d32)
+    x = pre16.double().requires_grad_(True)
+    torch.nn.functional.gelu(x, approximate="tanh").sum().backward()
+    want = (A16.double() @ B16.double().t()) * x.grad
+    assert _rel(d, want) < TOL
+    with pytest.raises(Exception):       # the fp32 kernel has no bf16 pre-activation
+        ops.gemm(M, N, K, A16.float(), K, B16.float(), K, c, N, act=ops.ACT_GELU_TANH, preact=(pre16, N))
 
 
 @pytest.mark.parametrize("Bn,L,N,Cin,Cout,k", [(2, 48, 5, 24, 64, 3), (2, 24, 7, 64, 128, 7), (1, 48, 300, 24, 64, 5)])

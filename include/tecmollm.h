@@ -33,7 +33,7 @@ extern "C" {
 #define TECM_E_LAUNCH (-3)     /* hipGetLastError() != hipSuccess after the launch       */
 #define TECM_E_LDS (-4)        /* problem does not fit the 160 KiB LDS budget            */
 
-#define TECM_ABI_VERSION 11
+#define TECM_ABI_VERSION 12
 int tecm_abi_version(void);
 /* Human-readable text for the last error on this thread (host pointer, never NULL). */
 const char* tecm_last_error(void);
@@ -295,6 +295,26 @@ int tecm_conv_fwd_f32(const TecmConvFwd* p, void* stream);
 int tecm_conv_dx_pack_f32(const float* w3, const float* w5, const float* w7, float* wpack, int32_t Cout, int32_t Cin,
                           int32_t ld_in, void* stream);
 int tecm_conv_dx_f32(const TecmConvDx* p, void* stream);
+
+/* Weight gradient of the same three Conv1d in ONE launch pair, bf16 mode (replaces the three split-K window GEMMs
+ * dY^T . window(inp) behind nn.Conv1d's autograd, modules.py:27,36):
+ *   dw_j[co, ci, tau] = sum_{b,t,n} dy[b, t, n, j*Cout + co] * inp[b, t + tau - (k_j-1)/2, n, ci]     (zero outside [0, Lc))
+ * inp bf16 (B, Lc, N, ld_in), dy bf16 (B, Lc, N, 3*Cout), dw3 / dw5 / dw7 fp32 (Cout, Cin, 3 / 5 / 7) -- only the Cin
+ * real channels are written.  A persistent kernel of num_blocks thread blocks (one per CU is the intended use) keeps
+ * all 15 taps' accumulators in registers and leaves one slab per block in `workspace`
+ * (tecm_conv_dw_workspace(Cout, ld_in, num_blocks) floats); a second kernel adds the slabs in a fixed order.
+ * (ld_in, Cout) in {24, 64} x {64, 128}; Lc % 4 == 0, Lc <= 48; 16-byte aligned tensors. */
+typedef struct TecmConvDw {
+  const void* inp;
+  const void* dy;
+  float* workspace;
+  float* dw3;
+  float* dw5;
+  float* dw7;
+  int32_t B, Lc, N, Cout, Cin, ld_in, num_blocks, _pad;
+} TecmConvDw;
+int64_t tecm_conv_dw_workspace(int32_t Cout, int32_t ld_in, int32_t num_blocks);
+int tecm_conv_dw_bf16(const TecmConvDw* p, void* stream);
 
 /* dst (bf16) [r][c] = round-to-nearest-even(src [r][c]) for a (rows, cols) block; cols % 4 == 0.  The cast torch.autocast
  * inserts in front of a Linear / Conv1D input (reference train.py:68), done once for a tensor a bf16 GEMM will read (here:

@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TECM_LIB", os.path.join(_HERE, "libtecmollm_hip.so"))   # override for experiments
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 c_f32p = C.c_void_p
 
@@ -113,6 +113,13 @@ class TecmConvDx(C.Structure):
                 ("_pad", C.c_int32)]
 
 
+class TecmConvDw(C.Structure):
+    _fields_ = [("inp", C.c_void_p), ("dy", C.c_void_p), ("workspace", c_f32p), ("dw3", c_f32p), ("dw5", c_f32p),
+                ("dw7", c_f32p),
+                ("B", C.c_int32), ("Lc", C.c_int32), ("N", C.c_int32), ("Cout", C.c_int32), ("Cin", C.c_int32),
+                ("ld_in", C.c_int32), ("num_blocks", C.c_int32), ("_pad", C.c_int32)]
+
+
 class TecmConvFwd(C.Structure):
     _fields_ = [("inp", C.c_void_p), ("wpack", C.c_void_p), ("bias", c_f32p), ("y", c_f32p),
                 ("B", C.c_int32), ("Lc", C.c_int32), ("N", C.c_int32), ("Cout", C.c_int32), ("ld_in", C.c_int32),
@@ -160,6 +167,8 @@ EXPORTS = {
     "tecm_conv_fwd_bf16": (C.c_int, [C.POINTER(TecmConvFwd), C.c_void_p]),
     "tecm_conv_fwd_pack_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "tecm_conv_fwd_f32": (C.c_int, [C.POINTER(TecmConvFwd), C.c_void_p]),
+    "tecm_conv_dw_workspace": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "tecm_conv_dw_bf16": (C.c_int, [C.POINTER(TecmConvDw), C.c_void_p]),
     "tecm_conv_dx_pack_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "tecm_conv_dx_f32": (C.c_int, [C.POINTER(TecmConvDx), C.c_void_p]),
     "tecm_transpose_scale": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_float,

@@ -366,9 +366,19 @@ class ConvBlockFn(torch.autograd.Function):
         if dx_seq:
             ops.conv_dx(dy, ctx.w357[0], ctx.w357[1], ctx.w357[2], dinp, B, Lc, N, Cout, cin, ld_in)
         grads = []
+        # d weights of the three kernel sizes in ONE persistent launch that reads inp16 and dy once (csrc/conv_dw_seq.hip)
+        # instead of three split-K window GEMMs; bf16 mode only
+        dw_seq = ctx.inp16 is not None and dy.dtype == torch.bfloat16 and ops.conv_dw_seq_ok(Lc, Cout, ld_in)
+        dws = ops.conv_dw(ctx.inp16, dy, B, Lc, N, Cout, cin, ld_in) if dw_seq else None
         for j, (k, bp) in enumerate(((3, bp3), (5, bp5), (7, bp7))):
             K = k * ld_in
             db = dbconv[j * Cout:(j + 1) * Cout]
+            if dw_seq:
+                if need_dinp and not dx_seq:
+                    gemm(M, ld_in, k * Cout, dy, CT, bp, ld_in, dinp, ld_in, b_layout=B_KN, a_off=j * Cout,
+                         a_win=win(N, Lc, Lc, 1, k, Cout, (k - 1) // 2), accumulate=(j > 0), bf16=bf16)
+                grads += [dws[j], db, dgamma[j * Cout:(j + 1) * Cout], dbeta[j * Cout:(j + 1) * Cout]]
+                continue
             dpack = _empty(Cout, K, like=inp)
             b_src = ctx.inp16 if (ctx.inp16 is not None and dy.dtype == torch.bfloat16
                                   and os.environ.get("TECM_DW_B16", "1")[:1] != "0") else inp

@@ -437,6 +437,46 @@ def conv_dx(dy: torch.Tensor, w3: torch.Tensor, w5: torch.Tensor, w7: torch.Tens
 conv_dx_bf16 = conv_dx      # round-3 name (tests)
 
 
+def conv_dw_seq_ok(Lc: int, Cout: int, ld_in: int) -> bool:
+    """Shapes the sequence-tile weight-gradient kernel (csrc/conv_dw_seq.hip) serves."""
+    return (Lc % 4 == 0 and 0 < Lc <= 48 and Cout in (64, 128) and ld_in in (24, 64)
+            and os.environ.get("TECM_CONV_DW_SEQ", "1")[:1] != "0")
+
+
+_cu_count = {}
+
+
+def conv_dw(inp16: torch.Tensor, dy: torch.Tensor, B: int, Lc: int, N: int, Cout: int, cin: int, ld_in: int):
+    """(dw3, dw5, dw7), fp32 (Cout, cin, k): weight gradients of the three parallel Conv1d of a Multi_Scale_Conv_Block
+    (modules.py:43-60) from the bf16 block input (B, Lc, N, ld_in) and the bf16 dy (B, Lc, N, 3*Cout), in one persistent
+    launch that reads both once (csrc/conv_dw_seq.hip) + a fixed-order reduction of the per-block slabs."""
+    if inp16.dtype != torch.bfloat16 or dy.dtype != torch.bfloat16:
+        raise _lib.TecmError("conv_dw: inp16 and dy are bf16 tensors")
+    dev = dy.device
+    nb = _cu_count.get(dev.index)
+    if nb is None:
+        nb = _cu_count[dev.index] = int(os.environ.get("TECM_CONV_DW_BLOCKS", 0)) or \
+            torch.cuda.get_device_properties(dev).multi_processor_count
+    nws = lib().tecm_conv_dw_workspace(Cout, ld_in, nb)
+    if nws <= 0:
+        raise _lib.TecmError(f"conv_dw: no kernel for Cout={Cout}, ld_in={ld_in}")
+    ws = torch.empty(nws, device=dev, dtype=torch.float32)
+    dws = [torch.empty(Cout, cin, k, device=dev, dtype=torch.float32) for k in (3, 5, 7)]
+    d = _lib.TecmConvDw(inp=inp16.data_ptr(), dy=dy.data_ptr(), workspace=ws.data_ptr(), dw3=dws[0].data_ptr(),
+                        dw5=dws[1].data_ptr(), dw7=dws[2].data_ptr(), B=B, Lc=Lc, N=N, Cout=Cout, Cin=cin, ld_in=ld_in,
+                        num_blocks=nb)
+    if _timing is None:
+        check(lib().tecm_conv_dw_bf16(C.byref(d), stream_ptr()), "tecm_conv_dw_bf16")
+        return dws
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(lib().tecm_conv_dw_bf16(C.byref(d), stream_ptr()), "tecm_conv_dw_bf16")
+    e1.record()
+    name = "conv_dw_seq_kernel" + (f" M={15 * ld_in} N={Cout} K={B * Lc * N}" if _timing_detail else "")
+    _timing.append((name, 2.0 * B * Lc * N * ld_in * 15 * Cout, e0, e1))
+    return dws
+
+
 def conv_fwd_seq_ok(Lc: int, Cout: int, ld_in: int) -> bool:
     return (Lc % 8 == 0 and Cout % 32 == 0 and 0 < Cout <= 128 and ld_in % 8 == 0 and 0 < ld_in <= 128
             and os.environ.get("TECM_CONV_SEQ", "1")[:1] != "0" and os.environ.get("TECM_CONV_FWD_SEQ", "1")[:1] != "0")

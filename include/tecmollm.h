@@ -303,7 +303,7 @@ int tecm_conv_dx_f32(const TecmConvDx* p, void* stream);
  * real channels are written.  A persistent kernel of num_blocks thread blocks (one per CU is the intended use) keeps
  * all 15 taps' accumulators in registers and leaves one slab per block in `workspace`
  * (tecm_conv_dw_workspace(Cout, ld_in, num_blocks) floats); a second kernel adds the slabs in a fixed order.
- * (ld_in, Cout) in {24, 64} x {64, 128}; Lc % 4 == 0, Lc <= 48; 16-byte aligned tensors. */
+ * (ld_in, Cout) in {24, 64} x {64, 128}; Lc % 4 == 0; 16-byte aligned tensors. */
 typedef struct TecmConvDw {
   const void* inp;
   const void* dy;

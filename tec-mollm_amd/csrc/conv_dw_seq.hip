@@ -6,29 +6,31 @@
 // Before: three split-K window GEMMs (A = dy^T, B = the window view of inp, K = B*Lc*N up to 1.1 M rows), each staging
 // its operands through a transposing register stager and re-reading dy / the taps of inp: 0.54 + 0.60 ms per step at
 // 60-250 TFLOP/s for 2 x 0.5 GB of operands -- five times what HBM needs to deliver them once.  Here: a SEQUENCE tile.
-//   * a persistent block (one per CU, 4 waves = one per SIMD, 512 registers each) walks tiles of 4 nodes x the whole
-//     sequence (Lc <= 48 time steps) of one
-//     sample; the tile's rows of inp and dy are staged in LDS in their NATURAL layout (row = (t, node), channels
-//     contiguous), inp with 3 zero time steps in front and behind, so every tap of every kernel size is a ROW offset of
-//     the same image and the zero padding of the convolution is the halo;
+//   * a persistent block (one per CU, 8 waves) walks tiles of 4 nodes x up to 24 time steps of one sample; the tile's
+//     rows of inp and dy are staged in LDS in their NATURAL layout (row = (t, node), channels contiguous), inp with 3
+//     more time steps in front and behind (zeros outside the sequence), so every tap of every kernel size is a ROW
+//     offset of the same image and the zero padding of the convolution is the halo;
 //   * the contraction runs over rows, which is the k index of the MFMA: both operands are wanted "k-major".
 //     ds_read_b64_tr_b16 (gfx950) delivers exactly that from the natural image -- lane 4q+p of a 16-lane group supplies
 //     row q (= node q of one time step), lane i receives column i of the 4 rows -- so nothing is transposed in
 //     registers and each lane's row address is linear in the k-chunk index;
-//   * v_mfma_f32_32x32x16_bf16 with A = 32 input channels x 16 rows, B = 16 rows x 32 output channels.  A wave owns one
-//     (input-channel block, output-channel block) pair and ALL 15 taps of it: 15 accumulator tiles = 240 registers
-//     that live across the whole kernel.  Per 16-row k-chunk it issues 8 transposed reads of inp (time steps t-3..t+4:
-//     the upper half of tap o's fragment is the lower half of tap o+1's) + 6 of dy for 15 MFMAs;
+//   * v_mfma_f32_32x32x16_bf16 with A = 32 input channels x 16 rows, B = 16 rows x 32 output channels.  A PAIR of waves
+//     owns one (input-channel block, output-channel block) pair and all 15 taps of it -- kernel size 7 in one wave,
+//     5 and 3 in the other: 7-8 accumulator tiles = 128 registers that live across the whole kernel.  Per 16-row
+//     k-chunk a wave issues 8 transposed reads of inp (time steps t-3..t+4: the upper half of tap o's fragment is the
+//     lower half of tap o+1's) + 4 of dy for 7-8 MFMAs;
 //   * the 15 x Cin x Cout accumulators of Cout = 128 / ld_in = 64 are 480 KB -- the whole register file of a CU holds
 //     512 KB -- so a block owns only HALF the output channels ("flavor" = blockIdx % 2) and stages only those columns
 //     of dy; inp (1/6 of the bytes) is read by both flavors.  Cout = 64 / ld_in = 24 has only two (cib, cob) pairs:
-//     the 4 waves then also split the k-chunks two ways;
-//   * the NEXT tile travels from HBM into registers (12-21 x 16 B per lane) while the current one is multiplied;
+//     the 4 wave pairs then also split the k-chunks two ways;
+//   * the next TWO tiles travel from HBM into registers (2 x 7-8 x 16 B per lane) while the current one is multiplied;
+//     the loads are issued and awaited by hand (see issue_load);
 //   * every wave writes its 15 tiles once, at the end, to a per-block slab; conv_dw_reduce_kernel sums the slabs in a
 //     fixed order and writes the three (Cout, Cin, k) gradients.  Bit-reproducible.
 // Arithmetic = the bf16 mode's: operands are the bf16 tensors the GEMM path reads (inp16 written by the producer, dy by
 // the GroupNorm backward), fp32 accumulation; only the summation order differs.
 #include "common.h"
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -37,16 +39,18 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace tecm_convdw {
 
-constexpr int NTH = 256;     // 4 waves: one per SIMD, the 240 accumulator registers of a wave need a 512-register budget
+constexpr int NTH = 512;     // 8 waves = 4 (channel block pair | k range) x 2 tap groups; 8 accumulator tiles each
 constexpr int NB = 4;        // nodes per tile = rows of one transposed-read block
 constexpr int HALO = 3;      // zero time steps in front of / behind the inp image (k = 7)
 constexpr int NTAP = 15;     // 3 + 5 + 7
+constexpr int TCMAX = 24;    // time steps per tile (longer sequences are walked in chunks; the halo rows are re-read)
 
 struct Args {
   const void* x;             // bf16 (B, Lc, N, ld_in)
   const void* dy;            // bf16 (B, Lc, N, 3 * Cout)
   float* ws;                 // slabs [flavor][(gridDim.x / F) * KS][15][32 * NCIB][32 * CPB]
-  int B, Lc, N, ntiles, nblk;
+  int B, Lc, N, ntiles, nblk, TC, nchunk;
+  int ablate;                // diagnostics (TECM_CONV_DW_ABLATE): bit0 no HBM loads, bit1 no LDS stores, bit2 no K loop
 };
 
 template <int LD_IN, int COUT>
@@ -64,8 +68,13 @@ struct Geo {
   static constexpr int YP = YI + 64;
   static constexpr int CPRX = XB / 16, CPRY = YI / 16;       // 16-byte chunks per row
   static constexpr int CPS = CPB * 4;                        // chunks per branch segment
-  static constexpr int MAXROWS = 48 * NB;
-  static constexpr int SBX = (MAXROWS * CPRX + NTH - 1) / NTH, SBY = (MAXROWS * CPRY + NTH - 1) / NTH;
+  static constexpr int MAXROWS = TCMAX * NB;                 // dy rows of a tile
+  static constexpr int MAXXROWS = (TCMAX + 2 * HALO) * NB;   // inp rows of a tile: the halo is staged too
+  // staging map, divisions by powers of two only: LX (LY) consecutive lanes share a row of inp (dy); an inp lane moves one
+  // chunk per pass, a dy lane three (the same chunk of each branch segment)
+  static constexpr int LX = CPRX <= 4 ? 4 : 8, LY = CPS;
+  static constexpr int RPX = NTH / LX, RPY = NTH / LY;       // rows per pass
+  static constexpr int SBX = (MAXXROWS + RPX - 1) / RPX, SBY = 3 * ((MAXROWS + RPY - 1) / RPY);
   static constexpr int SLAB = NTAP * 32 * NCIB * 32 * CPB;   // floats
   static_assert(R * KS == 4 && CPB * F == NCOB, "roles must tile the 4 waves");
   static_assert(LD_IN % 8 == 0 && COUT % 32 == 0 && XB <= (NCIB == 1 ? 64 : 128), "shape");
@@ -76,73 +85,112 @@ typedef __attribute__((address_space(3))) unsigned char* lds_ptr;
 __device__ __forceinline__ bf16x4 tr_read(lds_ptr p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4bf16(reinterpret_cast<__attribute__((address_space(3))) bf16x4*>(p));
 }
+__device__ __forceinline__ int opaque0() {
+  int z;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+  return z;
+}
+// The staging loads are issued and awaited BY HAND.  With compiler-tracked loads the register sets that travel
+// round-robin through the tile loop end in `s_waitcnt vmcnt(0)` at the top of every K loop (the wait-count pass merges
+// the loop's paths pessimistically): the tile just requested was awaited before the current one was multiplied, and
+// staging and MFMA time added up (155 + 89 us at Cout = 128, measured).  vmcnt retires in order, so "at most `newer`
+// operations outstanding" is exactly "everything older has landed"; anything the compiler adds in between only makes
+// the wait stricter.  land() ties the registers to the wait so no use can move above it.
+__device__ __forceinline__ void issue_load(u32x4& dst, const void* src) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src));
+}
+template <int NEWER>
+__device__ __forceinline__ void wait_loads() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NEWER));
+}
+__device__ __forceinline__ void land(u32x4& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ bf16x8 join(const bf16x4& lo, const bf16x4& hi) {
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int LD_IN, int COUT>
+struct Tile {
+  int b, n0, t0, tc;
+};
+__device__ __forceinline__ Tile decode_tile(const Args& a, int tile) {
+  Tile t;
+  const int nbk = tile % a.nblk;
+  tile /= a.nblk;
+  const int chunk = tile % a.nchunk;
+  t.b = tile / a.nchunk;
+  t.n0 = nbk * NB;
+  t.t0 = chunk * a.TC;
+  t.tc = min(a.TC, a.Lc - t.t0);                             // multiple of 4
+  return t;
+}
+
+template <int LD_IN, int COUT, int PD>   // PD: tiles in flight from HBM (register sets)
 __global__ __launch_bounds__(NTH) void conv_dw_seq_kernel(const Args a) {
   using G = Geo<LD_IN, COUT>;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int rows = a.Lc * NB;                                // rows of the dy image; multiple of 16
-  const int xbytes = (a.Lc + 2 * HALO) * NB * G::XP, ybytes = rows * G::YP;
+  const int tid0 = threadIdx.x, lane = tid0 & 63, wave = tid0 >> 6;
+  constexpr int xbytes = (TCMAX + 2 * HALO + 1) * NB * G::XP, ybytes = TCMAX * NB * G::YP;
   unsigned char* xs = lds;
   unsigned char* ys = lds + xbytes;
-  {                                                          // halo rows (and every pad byte) are zero for the whole kernel
+  {                                                          // pad bytes are zero for the whole kernel
     const u32x4 z = {0u, 0u, 0u, 0u};
-    for (int i = tid * 16; i < xbytes + ybytes; i += NTH * 16) *reinterpret_cast<u32x4*>(lds + i) = z;
+    for (int i = tid0 * 16; i < xbytes + ybytes; i += NTH * 16) *reinterpret_cast<u32x4*>(lds + i) = z;
   }
-  const int role = wave % G::R, kq = wave / G::R;
+  const int tg = wave & 1;                                   // tap group: 0 = kernel size 7, 1 = kernel sizes 5 and 3
+  const int role = (wave >> 1) % G::R, kq = (wave >> 1) / G::R;
   const int cib = role % G::NCIB, cob = role / G::NCIB;      // cob: local to this block's flavor
   const int flavor = blockIdx.x % G::F, bif = blockIdx.x / G::F, nbf = gridDim.x / G::F;
-  f32x16 acc[NTAP];
+  f32x16 acc[8];
 #pragma unroll
-  for (int i = 0; i < NTAP; ++i)
+  for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
-  const int nx = rows * G::CPRX, ny = rows * G::CPRY;
   const char* xg = static_cast<const char*>(a.x);
   const char* yg = static_cast<const char*>(a.dy);
-  u32x4 vx[G::SBX], vy[G::SBY];
-  // chunk idx of the x (y) image: row = idx / CPR = (t, node), 16-byte chunk idx % CPR.  Loads are clamped (always in
-  // bounds), only real chunks are stored, the rows of nodes >= N are stored as zeros.
-  auto stage_load = [&](int tile) {
-    const int b = tile / a.nblk, n0 = (tile - b * a.nblk) * NB;
-    const int64_t row0 = (int64_t)b * a.Lc * a.N;
+  u32x4 vx[PD][G::SBX], vy[PD][G::SBY];
+  // inp image row r = (time t0 - 3 + (r >> 2), node r & 3), dy image row r = (time t0 + (r >> 2), node r & 3).  Loads are
+  // clamped (always in bounds), only real chunks are stored; rows of nodes >= N and of times outside [0, Lc) -- the zero
+  // padding of the convolution -- are stored as zeros.
+  const int xrow = tid0 / G::LX, xch = tid0 % G::LX, yrow = tid0 / G::LY, ych = tid0 % G::LY;
+  auto stage_load = [&](int tile, u32x4 (&wx)[G::SBX], u32x4 (&wy)[G::SBY]) {
+    const Tile t = decode_tile(a, tile);
+    const int64_t row0 = (int64_t)t.b * a.Lc * a.N;
 #pragma unroll
     for (int q = 0; q < G::SBX; ++q) {
-      const int idx = min(tid + q * NTH, nx - 1);
-      const int row = idx / G::CPRX, ch = idx - row * G::CPRX;
-      const int ng = min(n0 + (row & 3), a.N - 1);
-      vx[q] = *reinterpret_cast<const u32x4*>(xg + (row0 + (int64_t)(row >> 2) * a.N + ng) * G::XB + ch * 16);
+      const int row = xrow + q * G::RPX, ch = min(xch, G::CPRX - 1);
+      const int ts = min(max(t.t0 - HALO + (row >> 2), 0), a.Lc - 1);
+      const int ng = min(t.n0 + (row & 3), a.N - 1);
+      issue_load(wx[q], xg + (row0 + (int64_t)ts * a.N + ng) * G::XB + ch * 16);
     }
 #pragma unroll
-    for (int q = 0; q < G::SBY; ++q) {
-      const int idx = min(tid + q * NTH, ny - 1);
-      const int row = idx / G::CPRY, ch = idx - row * G::CPRY;
-      const int ng = min(n0 + (row & 3), a.N - 1);
-      const int seg = ch / G::CPS, c = ch - seg * G::CPS;    // branch, chunk inside this flavor's columns of it
-      vy[q] = *reinterpret_cast<const u32x4*>(yg + (row0 + (int64_t)(row >> 2) * a.N + ng) * G::YB + seg * (COUT * 2) +
-                                              flavor * (G::CPB * 64) + c * 16);
+    for (int q = 0; q < G::SBY / 3; ++q) {
+      const int row = yrow + q * G::RPY;
+      const int ts = min(t.t0 + (row >> 2), a.Lc - 1);
+      const int ng = min(t.n0 + (row & 3), a.N - 1);
+      const char* src = yg + (row0 + (int64_t)ts * a.N + ng) * G::YB + flavor * (G::CPB * 64) + ych * 16;
+#pragma unroll
+      for (int seg = 0; seg < 3; ++seg) issue_load(wy[3 * q + seg], src + seg * (COUT * 2));
     }
   };
-  auto stage_store = [&](int tile) {
-    const int b = tile / a.nblk, n0 = (tile - b * a.nblk) * NB;
+  auto stage_store = [&](int tile, const u32x4 (&wx)[G::SBX], const u32x4 (&wy)[G::SBY]) {
+    const Tile t = decode_tile(a, tile);
     const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int q = 0; q < G::SBX; ++q) {
-      const int idx = tid + q * NTH;
-      const int row = idx / G::CPRX, ch = idx - row * G::CPRX;
-      if (idx < nx)
-        *reinterpret_cast<u32x4*>(xs + (row + HALO * NB) * G::XP + ch * 16) = (n0 + (row & 3) < a.N) ? vx[q] : z;
+      const int row = xrow + q * G::RPX;
+      const int ts = t.t0 - HALO + (row >> 2);
+      const bool real = ts >= 0 && ts < a.Lc && t.n0 + (row & 3) < a.N;
+      if (row < (t.tc + 2 * HALO) * NB && xch < G::CPRX) *reinterpret_cast<u32x4*>(xs + row * G::XP + xch * 16) = real ? wx[q] : z;
     }
 #pragma unroll
-    for (int q = 0; q < G::SBY; ++q) {
-      const int idx = tid + q * NTH;
-      const int row = idx / G::CPRY, ch = idx - row * G::CPRY;
-      if (idx < ny) *reinterpret_cast<u32x4*>(ys + row * G::YP + ch * 16) = (n0 + (row & 3) < a.N) ? vy[q] : z;
+    for (int q = 0; q < G::SBY / 3; ++q) {
+      const int row = yrow + q * G::RPY;
+      if (row < t.tc * NB) {
+        const bool real = t.n0 + (row & 3) < a.N;
+#pragma unroll
+        for (int seg = 0; seg < 3; ++seg)
+          *reinterpret_cast<u32x4*>(ys + row * G::YP + seg * (G::CPB * 64) + ych * 16) = real ? wy[3 * q + seg] : z;
+      }
     }
   };
 
@@ -150,46 +198,75 @@ __global__ __launch_bounds__(NTH) void conv_dw_seq_kernel(const Args a) {
   // second read of a fragment), columns 16*g1 + 4p .. +3 of the wave's channel block
   const int q = (lane & 15) >> 2, p = lane & 3, g1 = (lane >> 4) & 1, h = lane >> 5;
   const lds_ptr base3 = (lds_ptr)lds;
-  const int x0 = (2 * h * NB + q) * G::XP + (cib * 32 + 16 * g1 + 4 * p) * 2;            // tap offset -3 = image row t
+  // tap group 1 starts one time step later (its widest kernel is 5) and takes dy's second branch as its main operand
+  const int x0 = ((2 * h + tg) * NB + q) * G::XP + (cib * 32 + 16 * g1 + 4 * p) * 2;     // tap offset -3 = image row t
   const int y0 = xbytes + (2 * h * NB + q) * G::YP + (cob * 32 + 16 * g1 + 4 * p) * 2;
-  const int nchunks = rows / 16;
+  const int ya = (tg ? 1 : 2) * (G::CPB * 64);
 
-  int tile = bif;
-  if (tile < a.ntiles) stage_load(tile);
-  __syncthreads();                                           // the zero fill is complete
-  for (; tile < a.ntiles; tile += nbf) {
-    stage_store(tile);
-    __syncthreads();
-    if (tile + nbf < a.ntiles) stage_load(tile + nbf);
+  // one tile's product, both tap groups through the same code.  xr[i] = time step t + i - 3 + tg (t = 4*kc + 2h),
+  // fragment i = (xr[i], xr[i+1]) = time offset i - 3 + tg.
+  //   tg 0 (kernel size 7): slots 0..6 = fragments 0..6 against dy's third branch.
+  //   tg 1: slots 0..4 = kernel size 5 (fragments 0..4, offsets -2..2, second branch), slots 5..7 = kernel size 3
+  //         (fragments 1..3, offsets -1..1, first branch).
+  auto compute = [&](int nchunks) {
     for (int kc = kq; kc < nchunks; kc += G::KS) {
       const lds_ptr xp = base3 + x0 + kc * 16 * G::XP;
       const lds_ptr yp = base3 + y0 + kc * 16 * G::YP;
-      bf16x4 xr[8];                                          // time steps t-3 .. t+4 (t = 4*kc + 2h)
+      bf16x4 xr[8];
 #pragma unroll
       for (int o = 0; o < 8; ++o) xr[o] = tr_read(xp + o * NB * G::XP);
-      bf16x8 yf[3];
+      const bf16x8 yA = join(tr_read(yp + ya), tr_read(yp + ya + NB * G::YP));
+      const bf16x8 yB = join(tr_read(yp), tr_read(yp + NB * G::YP));
 #pragma unroll
-      for (int j = 0; j < 3; ++j) yf[j] = join(tr_read(yp + j * (G::CPB * 64)), tr_read(yp + NB * G::YP + j * (G::CPB * 64)));
-      // tap o (time offset o - 3): kernel size 7 uses o = 0..6, 5 uses 1..5, 3 uses 2..4
+      for (int s5 = 0; s5 < 5; ++s5)
+        acc[s5] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join(xr[s5], xr[s5 + 1]), yA, acc[s5], 0, 0, 0);
 #pragma unroll
-      for (int o = 0; o < 7; ++o) {
-        const bf16x8 xf = join(xr[o], xr[o + 1]);
-        acc[8 + o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, yf[2], acc[8 + o], 0, 0, 0);
-        if (o >= 1 && o <= 5) acc[3 + o - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, yf[1], acc[3 + o - 1], 0, 0, 0);
-        if (o >= 2 && o <= 4) acc[o - 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, yf[0], acc[o - 2], 0, 0, 0);
+      for (int s5 = 5; s5 < 7; ++s5) {
+        const bf16x8 xf = tg ? join(xr[s5 - 4], xr[s5 - 3]) : join(xr[s5], xr[s5 + 1]);
+        acc[s5] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, tg ? yB : yA, acc[s5], 0, 0, 0);
       }
+      if (tg) acc[7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join(xr[3], xr[4]), yB, acc[7], 0, 0, 0);
     }
-    __syncthreads();                                         // every wave is done with the image
+  };
+
+  // PD register sets travel round-robin: while tile i is multiplied, tiles i+1 .. i+PD are on their way from HBM
+#pragma unroll
+  for (int s = 0; s < PD; ++s)
+    if (bif + s * nbf < a.ntiles) stage_load(bif + s * nbf, vx[s], vy[s]);
+  __syncthreads();                                           // the zero fill is complete
+  for (int tile = bif; tile < a.ntiles;) {
+#pragma unroll
+    for (int s = 0; s < PD; ++s) {
+      if (tile < a.ntiles) {                                 // block-uniform
+        // outstanding, oldest first: this tile's loads, then those of the PD - 1 tiles requested after it (if they exist)
+        if (PD == 2 && tile + nbf < a.ntiles && !(a.ablate & 1)) wait_loads<G::SBX + G::SBY>();
+        else wait_loads<0>();
+#pragma unroll
+        for (int q = 0; q < G::SBX; ++q) land(vx[s][q]);
+#pragma unroll
+        for (int q = 0; q < G::SBY; ++q) land(vy[s][q]);
+        if (!(a.ablate & 2)) stage_store(tile, vx[s], vy[s]);
+        __syncthreads();
+        if (tile + PD * nbf < a.ntiles && !(a.ablate & 1)) stage_load(tile + PD * nbf, vx[s], vy[s]);
+        if (!(a.ablate & 4)) compute(min(a.TC, a.Lc - ((tile / a.nblk) % a.nchunk) * a.TC) / 4);
+        __syncthreads();                                     // every wave is done with the image
+      }
+      tile += nbf;
+    }
   }
   // slab [flavor][(block in flavor, kq)][tap][ci][local co]: lane holds co = lane & 31 of rows ci = 8*(i>>2) + 4*(lane>>5) + (i&3)
+  // slab taps 0..2: kernel size 3, 3..7: 5, 8..14: 7
   float* slab = a.ws + (((int64_t)flavor * nbf + bif) * G::KS + kq) * G::SLAB;
 #pragma unroll
-  for (int tp = 0; tp < NTAP; ++tp)
+  for (int t8 = 0; t8 < 8; ++t8) {
+    const int tp = tg == 0 ? 8 + t8 : (t8 < 5 ? 3 + t8 : t8 - 5);
+    if (tg == 0 && t8 == 7) continue;                        // kernel size 7 has seven taps
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int ci = cib * 32 + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3);
-      slab[(tp * 32 * G::NCIB + ci) * (32 * G::CPB) + cob * 32 + (lane & 31)] = acc[tp][i];
+      slab[(tp * 32 * G::NCIB + ci) * (32 * G::CPB) + cob * 32 + (lane & 31)] = acc[t8][i];
     }
+  }
 }
 
 // dw_j[co][ci][tau] = sum over the slabs of co's flavor, fixed order.  Block = 64 consecutive co of one (tap, ci); the
@@ -231,28 +308,33 @@ __global__ __launch_bounds__(256) void conv_dw_reduce_kernel(const float* __rest
   }
 }
 
-template <int LD_IN, int COUT>
+template <int LD_IN, int COUT, int PD>
 int launch(const TecmConvDw* p, hipStream_t st) {
   using G = Geo<LD_IN, COUT>;
   Args a;
   a.x = p->inp; a.dy = p->dy; a.ws = p->workspace;
   a.B = p->B; a.Lc = p->Lc; a.N = p->N;
+  {
+    static const int ablate = getenv("TECM_CONV_DW_ABLATE") ? atoi(getenv("TECM_CONV_DW_ABLATE")) : 0;
+    a.ablate = ablate;
+  }
   a.nblk = (p->N + NB - 1) / NB;
-  const int64_t tiles = (int64_t)p->B * a.nblk;
+  a.TC = p->Lc < TCMAX ? p->Lc : TCMAX;
+  a.nchunk = (p->Lc + a.TC - 1) / a.TC;
+  const int64_t tiles = (int64_t)p->B * a.nchunk * a.nblk;
   TECM_REQUIRE(tiles < ((int64_t)1 << 31), TECM_E_ARG, "tecm_conv_dw_bf16: too many tiles");
   a.ntiles = (int)tiles;
-  const size_t lds = (size_t)(p->Lc + 2 * HALO) * NB * G::XP + (size_t)p->Lc * NB * G::YP;
-  TECM_REQUIRE(lds <= 160 * 1024, TECM_E_LDS, "tecm_conv_dw_bf16: %zu B of LDS per tile", lds);
+  const size_t lds = (size_t)(TCMAX + 2 * HALO + 1) * NB * G::XP + (size_t)TCMAX * NB * G::YP;   // as the kernel lays it out
   int nbf = p->num_blocks / G::F;                           // blocks per flavor
   if (nbf > tiles) nbf = (int)tiles;
   TECM_REQUIRE(nbf >= 1, TECM_E_ARG, "tecm_conv_dw_bf16: num_blocks must be at least %d", G::F);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dw_seq_kernel<LD_IN, COUT>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dw_seq_kernel<LD_IN, COUT, PD>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_dw_seq_kernel<LD_IN, COUT>), dim3(nbf * G::F), dim3(NTH), lds, st, a);
+  hipLaunchKernelGGL((conv_dw_seq_kernel<LD_IN, COUT, PD>), dim3(nbf * G::F), dim3(NTH), lds, st, a);
   TECM_CHECK_LAUNCH("tecm_conv_dw_bf16/seq");
   hipLaunchKernelGGL(conv_dw_reduce_kernel, dim3((unsigned)(NTAP * p->Cin * (COUT / 64))), dim3(256), 0, st, p->workspace,
                      nbf * G::KS, 32 * G::NCIB, 32 * G::CPB, COUT, p->Cin, p->dw3, p->dw5, p->dw7);
@@ -272,15 +354,20 @@ extern "C" int64_t tecm_conv_dw_workspace(int32_t Cout, int32_t ld_in, int32_t n
 
 extern "C" int tecm_conv_dw_bf16(const TecmConvDw* p, void* stream) {
   TECM_REQUIRE(p && p->inp && p->dy && p->workspace && p->dw3 && p->dw5 && p->dw7, TECM_E_ARG, "tecm_conv_dw_bf16: null pointer");
-  TECM_REQUIRE(p->B > 0 && p->N > 0 && p->Lc > 0 && p->Lc % 4 == 0 && p->Lc <= 48, TECM_E_ARG,
-               "tecm_conv_dw_bf16: the sequence length must be a multiple of 4 up to 48 (got %d)", p->Lc);
+  TECM_REQUIRE(p->B > 0 && p->N > 0 && p->Lc > 0 && p->Lc % 4 == 0, TECM_E_ARG,
+               "tecm_conv_dw_bf16: the sequence length must be a multiple of 4 (got %d)", p->Lc);
   TECM_REQUIRE(p->Cin > 0 && p->Cin <= p->ld_in && p->num_blocks > 0, TECM_E_ARG, "tecm_conv_dw_bf16: bad Cin / num_blocks");
   TECM_REQUIRE(tecm_aligned(p->inp, 16) && tecm_aligned(p->dy, 16), TECM_E_ALIGN, "tecm_conv_dw_bf16: 16-byte aligned tensors");
   hipStream_t st = (hipStream_t)stream;
-  if (p->ld_in == 64 && p->Cout == 128) return tecm_convdw::launch<64, 128>(p, st);
-  if (p->ld_in == 24 && p->Cout == 64) return tecm_convdw::launch<24, 64>(p, st);
-  if (p->ld_in == 64 && p->Cout == 64) return tecm_convdw::launch<64, 64>(p, st);
-  if (p->ld_in == 24 && p->Cout == 128) return tecm_convdw::launch<24, 128>(p, st);
+  // two register sets where they fit WITHOUT spilling (a spilled register with a hand-issued load pending would be
+  // stored before the data has landed; __graft_entry__.build() checks ScratchSize of every instantiation)
+#define TECM_DW_CASE(LD, CO, PD) \
+  if (p->ld_in == LD && p->Cout == CO) return tecm_convdw::launch<LD, CO, PD>(p, st)
+  TECM_DW_CASE(64, 128, 2);
+  TECM_DW_CASE(24, 64, 2);
+  TECM_DW_CASE(64, 64, 2);
+  TECM_DW_CASE(24, 128, 1);                                  // (not a shape of the reference model) one set: two would spill
+#undef TECM_DW_CASE
   TECM_REQUIRE(false, TECM_E_ARG, "tecm_conv_dw_bf16: built for ld_in in {24, 64} x Cout in {64, 128} (got %d, %d)", p->ld_in,
                p->Cout);
   return TECM_E_ARG;

@@ -439,7 +439,7 @@ conv_dx_bf16 = conv_dx      # round-3 name (tests)
 
 def conv_dw_seq_ok(Lc: int, Cout: int, ld_in: int) -> bool:
     """Shapes the sequence-tile weight-gradient kernel (csrc/conv_dw_seq.hip) serves."""
-    return (Lc % 4 == 0 and 0 < Lc <= 48 and Cout in (64, 128) and ld_in in (24, 64)
+    return (Lc % 4 == 0 and Lc > 0 and Cout in (64, 128) and ld_in in (24, 64)
             and os.environ.get("TECM_CONV_DW_SEQ", "1")[:1] != "0")
 
 

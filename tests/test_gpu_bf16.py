@@ -345,13 +345,14 @@ def test_conv_dx_sequence_tile_kernel(dev, Bn, Lc, N, cin, ld_in, Cout, f32):
 
 @pytest.mark.parametrize("Bn,Lc,N,cin,ld_in,Cout", [(2, 48, 5, 22, 24, 64), (1, 24, 9, 64, 64, 128), (2, 8, 4, 22, 24, 64),
                                                   (1, 12, 7, 64, 64, 128), (1, 16, 2911, 22, 24, 64), (3, 4, 3, 64, 64, 64),
-                                                  (1, 24, 1203, 64, 64, 128)])
+                                                  (1, 24, 1203, 64, 64, 128), (2, 40, 6, 64, 64, 128), (1, 96, 3, 22, 24, 128)])
 def test_conv_dw_sequence_tile_kernel(dev, Bn, Lc, N, cin, ld_in, Cout, monkeypatch):
     """csrc/conv_dw_seq.hip: the weight gradients of the three parallel Conv1d (modules.py:43-60) from the bf16 block
     input and the bf16 dy in one persistent launch (+ the fixed-order slab reduction), against an fp64 conv-backward of
-    the same bf16 operands (2e-4).  Ragged node blocks, sequences that are not a multiple of 8, both channel widths,
-    more tiles than blocks (persistent loop, register prefetch) and fewer; the padding columns of the input carry
-    garbage and must not matter; two runs agree bit for bit."""
+    the same bf16 operands (2e-4).  Ragged node blocks, sequences that are not a multiple of 8 or longer than one tile
+    (time chunks of 24 with re-read halos, a ragged last chunk), every channel-width pair, more tiles than blocks
+    (persistent loop, two register sets in flight) and fewer; the padding columns of the input carry garbage and must
+    not matter; two runs agree bit for bit."""
     from tecmollm import ops
     g = torch.Generator().manual_seed(Lc * 1000 + N)
     CT = 3 * Cout

@@ -33,7 +33,7 @@ extern "C" {
 #define TECM_E_LAUNCH (-3)     /* hipGetLastError() != hipSuccess after the launch       */
 #define TECM_E_LDS (-4)        /* problem does not fit the 160 KiB LDS budget            */
 
-#define TECM_ABI_VERSION 12
+#define TECM_ABI_VERSION 13
 int tecm_abi_version(void);
 /* Human-readable text for the last error on this thread (host pointer, never NULL). */
 const char* tecm_last_error(void);
@@ -315,6 +315,8 @@ typedef struct TecmConvDw {
 } TecmConvDw;
 int64_t tecm_conv_dw_workspace(int32_t Cout, int32_t ld_in, int32_t num_blocks);
 int tecm_conv_dw_bf16(const TecmConvDw* p, void* stream);
+/* The same in exact fp32 (BASELINE configs[1]): inp and dy fp32, v_mfma_f32_32x32x2_f32. */
+int tecm_conv_dw_f32(const TecmConvDw* p, void* stream);
 
 /* dst (bf16) [r][c] = round-to-nearest-even(src [r][c]) for a (rows, cols) block; cols % 4 == 0.  The cast torch.autocast
  * inserts in front of a Linear / Conv1D input (reference train.py:68), done once for a tensor a bf16 GEMM will read (here:

@@ -1,4 +1,4 @@
-// Multi_Scale_Conv_Block (reference modules.py:43-60), bf16 mode: the WEIGHT gradient of the three parallel Conv1d
+// Multi_Scale_Conv_Block (reference modules.py:43-60): the WEIGHT gradient of the three parallel Conv1d
 // (k = 3, 5, 7) as ONE kernel that reads the block input and dy once.
 //
 //     dw_j[co, ci, tau] = sum_{b, t, n}  dy[b, t, n, j*Cout + co] * inp[b, t + tau - p_j, n, ci],     p_j = (k_j - 1) / 2
@@ -29,6 +29,9 @@
 //     fixed order and writes the three (Cout, Cin, k) gradients.  Bit-reproducible.
 // Arithmetic = the bf16 mode's: operands are the bf16 tensors the GEMM path reads (inp16 written by the producer, dy by
 // the GroupNorm backward), fp32 accumulation; only the summation order differs.
+// The SAME kernel in exact fp32 (template F32, BASELINE configs[1]): fp32 inp and dy, v_mfma_f32_32x32x2_f32 fed by one
+// ds_read_b32 per operand from the natural image (no transposition needed: a lane holds one element).  There the kernel
+// is bound by the matrix cores, and what it saves over the split-K window GEMMs is their re-staging of both operands.
 #include "common.h"
 #include <cstdlib>
 
@@ -53,42 +56,42 @@ struct Args {
   int ablate;                // diagnostics (TECM_CONV_DW_ABLATE): bit0 no HBM loads, bit1 no LDS stores, bit2 no K loop
 };
 
-template <int LD_IN, int COUT>
+template <int LD_IN, int COUT, bool F32>
 struct Geo {
+  static constexpr int ES = F32 ? 4 : 2;                     // element size
   static constexpr int NCIB = (LD_IN + 31) / 32;             // input-channel blocks of 32
   static constexpr int NCOB = COUT / 32;
   static constexpr int CPB = NCOB < 4 / NCIB ? NCOB : 4 / NCIB;   // output-channel blocks per thread block
   static constexpr int F = NCOB / CPB;                       // flavors: thread blocks that share a tile's inp, split dy's columns
   static constexpr int R = NCIB * CPB;                       // (cib, cob) pairs = wave roles
-  static constexpr int KS = 4 / R;                           // waves per role: they split the k-chunks
-  static constexpr int XB = LD_IN * 2, YB = 3 * COUT * 2;    // bytes of one row in HBM
-  static constexpr int YI = 3 * CPB * 64;                    // bytes of one dy row in the image: 3 branches x CPB*32 columns
-  // pitches are odd multiples of 64 B: the 4 rows x 64 B of a transposed read (one 32-lane half) tile all 64 banks
-  static constexpr int XP = NCIB == 1 ? 64 : 192;
-  static constexpr int YP = YI + 64;
-  static constexpr int CPRX = XB / 16, CPRY = YI / 16;       // 16-byte chunks per row
-  static constexpr int CPS = CPB * 4;                        // chunks per branch segment
+  static constexpr int KS = 4 / R;                           // wave pairs per role: they split the k range
+  static constexpr int XB = LD_IN * ES, YB = 3 * COUT * ES;  // bytes of one row in HBM
+  static constexpr int SEGB = CPB * 32 * ES;                 // bytes of one branch's columns of this flavor
+  static constexpr int YI = 3 * SEGB;                        // bytes of one dy row in the image
+  // bf16: pitches are odd multiples of 64 B -- the 4 rows x 64 B of a transposed read (one 32-lane half) tile all 64
+  // banks.  fp32: a half-wave reads 32 consecutive floats of one row, any pitch is conflict-free.
+  static constexpr int XP = F32 ? XB : (NCIB == 1 ? 64 : 192);
+  static constexpr int YP = F32 ? YI : YI + 64;
+  static constexpr int CPRX = XB / 16;                       // 16-byte chunks per inp row
+  static constexpr int CPS = SEGB / 16;                      // chunks per branch segment
   static constexpr int MAXROWS = TCMAX * NB;                 // dy rows of a tile
   static constexpr int MAXXROWS = (TCMAX + 2 * HALO) * NB;   // inp rows of a tile: the halo is staged too
+  static constexpr int XBYTES = (TCMAX + 2 * HALO + 1) * NB * XP + 64, YBYTES = TCMAX * NB * YP;   // + slack: see compute
   // staging map, divisions by powers of two only: LX (LY) consecutive lanes share a row of inp (dy); an inp lane moves one
   // chunk per pass, a dy lane three (the same chunk of each branch segment)
-  static constexpr int LX = CPRX <= 4 ? 4 : 8, LY = CPS;
+  static constexpr int LX = CPRX <= 4 ? 4 : (CPRX <= 8 ? 8 : 16), LY = CPS;
   static constexpr int RPX = NTH / LX, RPY = NTH / LY;       // rows per pass
   static constexpr int SBX = (MAXXROWS + RPX - 1) / RPX, SBY = 3 * ((MAXROWS + RPY - 1) / RPY);
   static constexpr int SLAB = NTAP * 32 * NCIB * 32 * CPB;   // floats
-  static_assert(R * KS == 4 && CPB * F == NCOB, "roles must tile the 4 waves");
-  static_assert(LD_IN % 8 == 0 && COUT % 32 == 0 && XB <= (NCIB == 1 ? 64 : 128), "shape");
-  static_assert((YP / 64) % 2 == 1, "dy pitch must be an odd multiple of 64 B");
+  static_assert(R * KS == 4 && CPB * F == NCOB, "roles must tile the 4 wave pairs");
+  static_assert(LD_IN % 8 == 0 && COUT % 32 == 0 && CPRX <= LX && (LY == 8 || LY == 16 || LY == 32), "shape");
+  static_assert(F32 || (YP / 64) % 2 == 1, "bf16 dy pitch must be an odd multiple of 64 B");
+  static_assert(XBYTES % 16 == 0 && XP % 16 == 0 && YP % 16 == 0, "16-byte rows");
 };
 
 typedef __attribute__((address_space(3))) unsigned char* lds_ptr;
 __device__ __forceinline__ bf16x4 tr_read(lds_ptr p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4bf16(reinterpret_cast<__attribute__((address_space(3))) bf16x4*>(p));
-}
-__device__ __forceinline__ int opaque0() {
-  int z;
-  asm volatile("v_mov_b32 %0, 0" : "=v"(z));
-  return z;
 }
 // The staging loads are issued and awaited BY HAND.  With compiler-tracked loads the register sets that travel
 // round-robin through the tile loop end in `s_waitcnt vmcnt(0)` at the top of every K loop (the wait-count pass merges
@@ -123,19 +126,22 @@ __device__ __forceinline__ Tile decode_tile(const Args& a, int tile) {
   return t;
 }
 
-template <int LD_IN, int COUT, int PD>   // PD: tiles in flight from HBM (register sets)
+template <int LD_IN, int COUT, int PD, bool F32>   // PD: tiles in flight from HBM (register sets)
 __global__ __launch_bounds__(NTH) void conv_dw_seq_kernel(const Args a) {
-  using G = Geo<LD_IN, COUT>;
+  using G = Geo<LD_IN, COUT, F32>;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int tid0 = threadIdx.x, lane = tid0 & 63, wave = tid0 >> 6;
-  constexpr int xbytes = (TCMAX + 2 * HALO + 1) * NB * G::XP, ybytes = TCMAX * NB * G::YP;
+  const int tid0 = threadIdx.x, lane = tid0 & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);   // scalar: everything derived from it branches, not masks
+  constexpr int xbytes = G::XBYTES, ybytes = G::YBYTES;
   unsigned char* xs = lds;
   unsigned char* ys = lds + xbytes;
   {                                                          // pad bytes are zero for the whole kernel
     const u32x4 z = {0u, 0u, 0u, 0u};
     for (int i = tid0 * 16; i < xbytes + ybytes; i += NTH * 16) *reinterpret_cast<u32x4*>(lds + i) = z;
   }
-  const int tg = wave & 1;                                   // tap group: 0 = kernel size 7, 1 = kernel sizes 5 and 3
+  // tap group: 0 = kernel size 7 (7 MFMAs per step), 1 = kernel sizes 5 and 3 (8).  Waves w and w + 4 share a SIMD: the
+  // XOR gives every SIMD one wave of each group (15 MFMAs per step everywhere instead of 14 / 16)
+  const int tg = (wave ^ (wave >> 2)) & 1;
   const int role = (wave >> 1) % G::R, kq = (wave >> 1) / G::R;
   const int cib = role % G::NCIB, cob = role / G::NCIB;      // cob: local to this block's flavor
   const int flavor = blockIdx.x % G::F, bif = blockIdx.x / G::F, nbf = gridDim.x / G::F;
@@ -167,9 +173,9 @@ __global__ __launch_bounds__(NTH) void conv_dw_seq_kernel(const Args a) {
       const int row = yrow + q * G::RPY;
       const int ts = min(t.t0 + (row >> 2), a.Lc - 1);
       const int ng = min(t.n0 + (row & 3), a.N - 1);
-      const char* src = yg + (row0 + (int64_t)ts * a.N + ng) * G::YB + flavor * (G::CPB * 64) + ych * 16;
+      const char* src = yg + (row0 + (int64_t)ts * a.N + ng) * G::YB + flavor * G::SEGB + ych * 16;
 #pragma unroll
-      for (int seg = 0; seg < 3; ++seg) issue_load(wy[3 * q + seg], src + seg * (COUT * 2));
+      for (int seg = 0; seg < 3; ++seg) issue_load(wy[3 * q + seg], src + seg * (COUT * G::ES));
     }
   };
   auto stage_store = [&](int tile, const u32x4 (&wx)[G::SBX], const u32x4 (&wy)[G::SBY]) {
@@ -189,43 +195,90 @@ __global__ __launch_bounds__(NTH) void conv_dw_seq_kernel(const Args a) {
         const bool real = t.n0 + (row & 3) < a.N;
 #pragma unroll
         for (int seg = 0; seg < 3; ++seg)
-          *reinterpret_cast<u32x4*>(ys + row * G::YP + seg * (G::CPB * 64) + ych * 16) = real ? wy[3 * q + seg] : z;
+          *reinterpret_cast<u32x4*>(ys + row * G::YP + seg * G::SEGB + ych * 16) = real ? wy[3 * q + seg] : z;
       }
     }
   };
 
-  // this lane's addresses for the transposed reads of k-chunk 0: it supplies row q (node q) of time step 2h (+1 for the
-  // second read of a fragment), columns 16*g1 + 4p .. +3 of the wave's channel block
-  const int q = (lane & 15) >> 2, p = lane & 3, g1 = (lane >> 4) & 1, h = lane >> 5;
   const lds_ptr base3 = (lds_ptr)lds;
-  // tap group 1 starts one time step later (its widest kernel is 5) and takes dy's second branch as its main operand
-  const int x0 = ((2 * h + tg) * NB + q) * G::XP + (cib * 32 + 16 * g1 + 4 * p) * 2;     // tap offset -3 = image row t
-  const int y0 = xbytes + (2 * h * NB + q) * G::YP + (cob * 32 + 16 * g1 + 4 * p) * 2;
-  const int ya = (tg ? 1 : 2) * (G::CPB * 64);
-
-  // one tile's product, both tap groups through the same code.  xr[i] = time step t + i - 3 + tg (t = 4*kc + 2h),
-  // fragment i = (xr[i], xr[i+1]) = time offset i - 3 + tg.
-  //   tg 0 (kernel size 7): slots 0..6 = fragments 0..6 against dy's third branch.
-  //   tg 1: slots 0..4 = kernel size 5 (fragments 0..4, offsets -2..2, second branch), slots 5..7 = kernel size 3
-  //         (fragments 1..3, offsets -1..1, first branch).
-  auto compute = [&](int nchunks) {
-    for (int kc = kq; kc < nchunks; kc += G::KS) {
-      const lds_ptr xp = base3 + x0 + kc * 16 * G::XP;
-      const lds_ptr yp = base3 + y0 + kc * 16 * G::YP;
-      bf16x4 xr[8];
+  const int ya = (tg ? 1 : 2) * G::SEGB;                     // the main dy operand: third branch (k = 7) / second (k = 5)
+  // One tile's product, both tap groups through the same code.  Operand i of inp = time offset i - 3 + tg (tap group 1
+  // starts one time step later: its widest kernel is 5).
+  //   tg 0 (kernel size 7): slots 0..6 = operands 0..6 against dy's third branch.
+  //   tg 1: slots 0..4 = kernel size 5 (operands 0..4, offsets -2..2, second branch), slots 5..7 = kernel size 3
+  //         (operands 1..3, offsets -1..1, first branch).
+  auto compute = [&](int tc) {
+    if constexpr (!F32) {
+      // transposed reads: this lane supplies row q (node q) of time step 2h (+1 for the second read of a fragment),
+      // columns 16*g1 + 4p .. +3 of the wave's channel block.  xr[i] = time step t + i - 3 + tg (t = 4*kc + 2h), operand
+      // i = (xr[i], xr[i+1]): the upper half of one tap's fragment is the lower half of the next one's.
+      const int q = (lane & 15) >> 2, p = lane & 3, g1 = (lane >> 4) & 1, h = lane >> 5;
+      const int x0 = ((2 * h + tg) * NB + q) * G::XP + (cib * 32 + 16 * g1 + 4 * p) * 2;   // tap offset -3 = image row t
+      const int y0 = xbytes + (2 * h * NB + q) * G::YP + (cob * 32 + 16 * g1 + 4 * p) * 2;
+      const int nchunks = tc / 4;                            // 16 rows = 4 time steps per step
+      bf16x4 xr[8], yr[4];
+      auto fetch = [&](int kc, bf16x4 (&x)[8], bf16x4 (&y)[4]) {
+        const lds_ptr xp = base3 + x0 + kc * 16 * G::XP;
+        const lds_ptr yp = base3 + y0 + kc * 16 * G::YP;
 #pragma unroll
-      for (int o = 0; o < 8; ++o) xr[o] = tr_read(xp + o * NB * G::XP);
-      const bf16x8 yA = join(tr_read(yp + ya), tr_read(yp + ya + NB * G::YP));
-      const bf16x8 yB = join(tr_read(yp), tr_read(yp + NB * G::YP));
+        for (int o = 0; o < 8; ++o) x[o] = tr_read(xp + o * NB * G::XP);
+        y[0] = tr_read(yp + ya);
+        y[1] = tr_read(yp + ya + NB * G::YP);
+        y[2] = tr_read(yp);
+        y[3] = tr_read(yp + NB * G::YP);
+      };
+      if (kq < nchunks) fetch(kq, xr, yr);
+      for (int kc = kq; kc < nchunks; kc += G::KS) {
+        bf16x4 xn[8], yn[4];                                 // the next step's operands are read while this one multiplies
+        fetch(min(kc + G::KS, nchunks - 1), xn, yn);
+        const bf16x8 yA = join(yr[0], yr[1]), yB = join(yr[2], yr[3]);
 #pragma unroll
-      for (int s5 = 0; s5 < 5; ++s5)
-        acc[s5] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join(xr[s5], xr[s5 + 1]), yA, acc[s5], 0, 0, 0);
+        for (int s5 = 0; s5 < 5; ++s5)
+          acc[s5] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join(xr[s5], xr[s5 + 1]), yA, acc[s5], 0, 0, 0);
 #pragma unroll
-      for (int s5 = 5; s5 < 7; ++s5) {
-        const bf16x8 xf = tg ? join(xr[s5 - 4], xr[s5 - 3]) : join(xr[s5], xr[s5 + 1]);
-        acc[s5] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, tg ? yB : yA, acc[s5], 0, 0, 0);
+        for (int s5 = 5; s5 < 7; ++s5) {
+          const bf16x8 xf = tg ? join(xr[s5 - 4], xr[s5 - 3]) : join(xr[s5], xr[s5 + 1]);
+          acc[s5] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, tg ? yB : yA, acc[s5], 0, 0, 0);
+        }
+        if (tg) acc[7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join(xr[3], xr[4]), yB, acc[7], 0, 0, 0);
+#pragma unroll
+        for (int o = 0; o < 8; ++o) xr[o] = xn[o];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) yr[o] = yn[o];
       }
-      if (tg) acc[7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join(xr[3], xr[4]), yB, acc[7], 0, 0, 0);
+    } else {
+      // v_mfma_f32_32x32x2_f32: lane = (channel m, row h of the pair) reads ONE float per operand, straight from the natural
+      // image (32 consecutive floats of a row per half-wave).  ld_in = 24: lanes m >= 24 read into the next row -- finite
+      // or not, that only reaches accumulator rows the reduction never reads (the image has 64 B of slack at its end).
+      const int m = lane & 31, h = lane >> 5;
+      const int x0 = (h + tg * NB) * G::XP + (cib * 32 + m) * 4;
+      const int y0 = xbytes + h * G::YP + (cob * 32 + m) * 4;
+      typedef __attribute__((address_space(3))) const float* lds_f;
+      const int npairs = tc * 2;                             // 2 rows per step
+      float xr[7], yA, yB;
+      auto fetch = [&](int kp, float (&x)[7], float& ya_, float& yb_) {
+        const lds_ptr xp = base3 + x0 + kp * 2 * G::XP;
+        const lds_ptr yp = base3 + y0 + kp * 2 * G::YP;
+#pragma unroll
+        for (int o = 0; o < 7; ++o) x[o] = *reinterpret_cast<lds_f>(xp + o * NB * G::XP);
+        ya_ = *reinterpret_cast<lds_f>(yp + ya);
+        yb_ = *reinterpret_cast<lds_f>(yp);
+      };
+      if (kq < npairs) fetch(kq, xr, yA, yB);
+      for (int kp = kq; kp < npairs; kp += G::KS) {
+        float xn[7], yAn, yBn;                               // the next step's operands are read while this one multiplies
+        fetch(min(kp + G::KS, npairs - 1), xn, yAn, yBn);
+#pragma unroll
+        for (int s5 = 0; s5 < 5; ++s5) acc[s5] = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[s5], yA, acc[s5], 0, 0, 0);
+#pragma unroll
+        for (int s5 = 5; s5 < 7; ++s5)
+          acc[s5] = __builtin_amdgcn_mfma_f32_32x32x2f32(tg ? xr[s5 - 4] : xr[s5], tg ? yB : yA, acc[s5], 0, 0, 0);
+        if (tg) acc[7] = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[3], yB, acc[7], 0, 0, 0);
+#pragma unroll
+        for (int o = 0; o < 7; ++o) xr[o] = xn[o];
+        yA = yAn;
+        yB = yBn;
+      }
     }
   };
 
@@ -248,7 +301,7 @@ __global__ __launch_bounds__(NTH) void conv_dw_seq_kernel(const Args a) {
         if (!(a.ablate & 2)) stage_store(tile, vx[s], vy[s]);
         __syncthreads();
         if (tile + PD * nbf < a.ntiles && !(a.ablate & 1)) stage_load(tile + PD * nbf, vx[s], vy[s]);
-        if (!(a.ablate & 4)) compute(min(a.TC, a.Lc - ((tile / a.nblk) % a.nchunk) * a.TC) / 4);
+        if (!(a.ablate & 4)) compute(min(a.TC, a.Lc - ((tile / a.nblk) % a.nchunk) * a.TC));
         __syncthreads();                                     // every wave is done with the image
       }
       tile += nbf;
@@ -308,9 +361,9 @@ __global__ __launch_bounds__(256) void conv_dw_reduce_kernel(const float* __rest
   }
 }
 
-template <int LD_IN, int COUT, int PD>
+template <int LD_IN, int COUT, int PD, bool F32>
 int launch(const TecmConvDw* p, hipStream_t st) {
-  using G = Geo<LD_IN, COUT>;
+  using G = Geo<LD_IN, COUT, F32>;
   Args a;
   a.x = p->inp; a.dy = p->dy; a.ws = p->workspace;
   a.B = p->B; a.Lc = p->Lc; a.N = p->N;
@@ -324,21 +377,22 @@ int launch(const TecmConvDw* p, hipStream_t st) {
   const int64_t tiles = (int64_t)p->B * a.nchunk * a.nblk;
   TECM_REQUIRE(tiles < ((int64_t)1 << 31), TECM_E_ARG, "tecm_conv_dw_bf16: too many tiles");
   a.ntiles = (int)tiles;
-  const size_t lds = (size_t)(TCMAX + 2 * HALO + 1) * NB * G::XP + (size_t)TCMAX * NB * G::YP;   // as the kernel lays it out
+  const size_t lds = (size_t)G::XBYTES + G::YBYTES;
+  static_assert(G::XBYTES + G::YBYTES <= 160 * 1024, "one tile must fit the LDS");
   int nbf = p->num_blocks / G::F;                           // blocks per flavor
   if (nbf > tiles) nbf = (int)tiles;
   TECM_REQUIRE(nbf >= 1, TECM_E_ARG, "tecm_conv_dw_bf16: num_blocks must be at least %d", G::F);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dw_seq_kernel<LD_IN, COUT, PD>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dw_seq_kernel<LD_IN, COUT, PD, F32>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_dw_seq_kernel<LD_IN, COUT, PD>), dim3(nbf * G::F), dim3(NTH), lds, st, a);
-  TECM_CHECK_LAUNCH("tecm_conv_dw_bf16/seq");
+  hipLaunchKernelGGL((conv_dw_seq_kernel<LD_IN, COUT, PD, F32>), dim3(nbf * G::F), dim3(NTH), lds, st, a);
+  TECM_CHECK_LAUNCH("tecm_conv_dw/seq");
   hipLaunchKernelGGL(conv_dw_reduce_kernel, dim3((unsigned)(NTAP * p->Cin * (COUT / 64))), dim3(256), 0, st, p->workspace,
                      nbf * G::KS, 32 * G::NCIB, 32 * G::CPB, COUT, p->Cin, p->dw3, p->dw5, p->dw7);
-  TECM_CHECK_LAUNCH("tecm_conv_dw_bf16/reduce");
+  TECM_CHECK_LAUNCH("tecm_conv_dw/reduce");
   return TECM_OK;
 }
 
@@ -352,23 +406,26 @@ extern "C" int64_t tecm_conv_dw_workspace(int32_t Cout, int32_t ld_in, int32_t n
   return (int64_t)f * (num_blocks / f > 0 ? num_blocks / f : 1) * ks * tecm_convdw::NTAP * 32 * ncib * 32 * cpb;
 }
 
-extern "C" int tecm_conv_dw_bf16(const TecmConvDw* p, void* stream) {
-  TECM_REQUIRE(p && p->inp && p->dy && p->workspace && p->dw3 && p->dw5 && p->dw7, TECM_E_ARG, "tecm_conv_dw_bf16: null pointer");
+static int conv_dw_launch(const TecmConvDw* p, void* stream, bool f32, const char* who) {
+  TECM_REQUIRE(p && p->inp && p->dy && p->workspace && p->dw3 && p->dw5 && p->dw7, TECM_E_ARG, "%s: null pointer", who);
   TECM_REQUIRE(p->B > 0 && p->N > 0 && p->Lc > 0 && p->Lc % 4 == 0, TECM_E_ARG,
-               "tecm_conv_dw_bf16: the sequence length must be a multiple of 4 (got %d)", p->Lc);
-  TECM_REQUIRE(p->Cin > 0 && p->Cin <= p->ld_in && p->num_blocks > 0, TECM_E_ARG, "tecm_conv_dw_bf16: bad Cin / num_blocks");
-  TECM_REQUIRE(tecm_aligned(p->inp, 16) && tecm_aligned(p->dy, 16), TECM_E_ALIGN, "tecm_conv_dw_bf16: 16-byte aligned tensors");
+               "%s: the sequence length must be a multiple of 4 (got %d)", who, p->Lc);
+  TECM_REQUIRE(p->Cin > 0 && p->Cin <= p->ld_in && p->num_blocks > 0, TECM_E_ARG, "%s: bad Cin / num_blocks", who);
+  TECM_REQUIRE(tecm_aligned(p->inp, 16) && tecm_aligned(p->dy, 16), TECM_E_ALIGN, "%s: 16-byte aligned tensors", who);
   hipStream_t st = (hipStream_t)stream;
-  // two register sets where they fit WITHOUT spilling (a spilled register with a hand-issued load pending would be
-  // stored before the data has landed; __graft_entry__.build() checks ScratchSize of every instantiation)
-#define TECM_DW_CASE(LD, CO, PD) \
-  if (p->ld_in == LD && p->Cout == CO) return tecm_convdw::launch<LD, CO, PD>(p, st)
+  // PD = register sets in flight: two where they fit WITHOUT spilling (a spilled register with a hand-issued load pending
+  // would be stored before the data has landed; __graft_entry__.build() checks ScratchSize of every instantiation).  The
+  // fp32 kernel is bound by the matrix cores (11 us of MFMA per tile): one set is plenty.
+#define TECM_DW_CASE(LD, CO, PD)                                                              \
+  if (p->ld_in == LD && p->Cout == CO)                                                        \
+    return f32 ? tecm_convdw::launch<LD, CO, 1, true>(p, st) : tecm_convdw::launch<LD, CO, PD, false>(p, st)
   TECM_DW_CASE(64, 128, 2);
   TECM_DW_CASE(24, 64, 2);
   TECM_DW_CASE(64, 64, 2);
-  TECM_DW_CASE(24, 128, 1);                                  // (not a shape of the reference model) one set: two would spill
+  TECM_DW_CASE(24, 128, 1);                                  // (not a shape of the reference model)
 #undef TECM_DW_CASE
-  TECM_REQUIRE(false, TECM_E_ARG, "tecm_conv_dw_bf16: built for ld_in in {24, 64} x Cout in {64, 128} (got %d, %d)", p->ld_in,
-               p->Cout);
+  TECM_REQUIRE(false, TECM_E_ARG, "%s: built for ld_in in {24, 64} x Cout in {64, 128} (got %d, %d)", who, p->ld_in, p->Cout);
   return TECM_E_ARG;
 }
+extern "C" int tecm_conv_dw_bf16(const TecmConvDw* p, void* stream) { return conv_dw_launch(p, stream, false, "tecm_conv_dw_bf16"); }
+extern "C" int tecm_conv_dw_f32(const TecmConvDw* p, void* stream) { return conv_dw_launch(p, stream, true, "tecm_conv_dw_f32"); }

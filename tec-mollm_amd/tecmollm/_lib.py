@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TECM_LIB", os.path.join(_HERE, "libtecmollm_hip.so"))   # override for experiments
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 c_f32p = C.c_void_p
 
@@ -169,6 +169,7 @@ EXPORTS = {
     "tecm_conv_fwd_f32": (C.c_int, [C.POINTER(TecmConvFwd), C.c_void_p]),
     "tecm_conv_dw_workspace": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "tecm_conv_dw_bf16": (C.c_int, [C.POINTER(TecmConvDw), C.c_void_p]),
+    "tecm_conv_dw_f32": (C.c_int, [C.POINTER(TecmConvDw), C.c_void_p]),
     "tecm_conv_dx_pack_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "tecm_conv_dx_f32": (C.c_int, [C.POINTER(TecmConvDx), C.c_void_p]),
     "tecm_transpose_scale": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_float,

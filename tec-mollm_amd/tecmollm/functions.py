@@ -367,9 +367,11 @@ class ConvBlockFn(torch.autograd.Function):
             ops.conv_dx(dy, ctx.w357[0], ctx.w357[1], ctx.w357[2], dinp, B, Lc, N, Cout, cin, ld_in)
         grads = []
         # d weights of the three kernel sizes in ONE persistent launch that reads inp16 and dy once (csrc/conv_dw_seq.hip)
-        # instead of three split-K window GEMMs; bf16 mode only
-        dw_seq = ctx.inp16 is not None and dy.dtype == torch.bfloat16 and ops.conv_dw_seq_ok(Lc, Cout, ld_in)
-        dws = ops.conv_dw(ctx.inp16, dy, B, Lc, N, Cout, cin, ld_in) if dw_seq else None
+        # instead of three split-K window GEMMs: exact fp32 from the fp32 tensors, the bf16 mode's arithmetic from the bf16
+        # ones (the bf16x3 / bf16x6 modes keep the GEMM path)
+        dw_in = ctx.inp16 if dy.dtype == torch.bfloat16 else (inp if int(bf16) == ops.PREC_FP32 else None)
+        dw_seq = dw_in is not None and ops.conv_dw_seq_ok(Lc, Cout, ld_in)
+        dws = ops.conv_dw(dw_in, dy, B, Lc, N, Cout, cin, ld_in) if dw_seq else None
         for j, (k, bp) in enumerate(((3, bp3), (5, bp5), (7, bp7))):
             K = k * ld_in
             db = dbconv[j * Cout:(j + 1) * Cout]

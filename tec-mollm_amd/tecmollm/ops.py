@@ -446,12 +446,15 @@ def conv_dw_seq_ok(Lc: int, Cout: int, ld_in: int) -> bool:
 _cu_count = {}
 
 
-def conv_dw(inp16: torch.Tensor, dy: torch.Tensor, B: int, Lc: int, N: int, Cout: int, cin: int, ld_in: int):
+def conv_dw(inp: torch.Tensor, dy: torch.Tensor, B: int, Lc: int, N: int, Cout: int, cin: int, ld_in: int):
     """(dw3, dw5, dw7), fp32 (Cout, cin, k): weight gradients of the three parallel Conv1d of a Multi_Scale_Conv_Block
-    (modules.py:43-60) from the bf16 block input (B, Lc, N, ld_in) and the bf16 dy (B, Lc, N, 3*Cout), in one persistent
-    launch that reads both once (csrc/conv_dw_seq.hip) + a fixed-order reduction of the per-block slabs."""
-    if inp16.dtype != torch.bfloat16 or dy.dtype != torch.bfloat16:
-        raise _lib.TecmError("conv_dw: inp16 and dy are bf16 tensors")
+    (modules.py:43-60) from the block input (B, Lc, N, ld_in) and dy (B, Lc, N, 3*Cout), in one persistent launch that
+    reads both once (csrc/conv_dw_seq.hip) + a fixed-order reduction of the per-block slabs.  Both bf16: the bf16 mode's
+    arithmetic; both fp32: exact fp32."""
+    if inp.dtype != dy.dtype or dy.dtype not in (torch.bfloat16, torch.float32):
+        raise _lib.TecmError("conv_dw: inp and dy are both bf16 or both fp32 tensors")
+    f32 = dy.dtype == torch.float32
+    run, what = (lib().tecm_conv_dw_f32, "tecm_conv_dw_f32") if f32 else (lib().tecm_conv_dw_bf16, "tecm_conv_dw_bf16")
     dev = dy.device
     nb = _cu_count.get(dev.index)
     if nb is None:
@@ -462,17 +465,17 @@ def conv_dw(inp16: torch.Tensor, dy: torch.Tensor, B: int, Lc: int, N: int, Cout
         raise _lib.TecmError(f"conv_dw: no kernel for Cout={Cout}, ld_in={ld_in}")
     ws = torch.empty(nws, device=dev, dtype=torch.float32)
     dws = [torch.empty(Cout, cin, k, device=dev, dtype=torch.float32) for k in (3, 5, 7)]
-    d = _lib.TecmConvDw(inp=inp16.data_ptr(), dy=dy.data_ptr(), workspace=ws.data_ptr(), dw3=dws[0].data_ptr(),
+    d = _lib.TecmConvDw(inp=inp.data_ptr(), dy=dy.data_ptr(), workspace=ws.data_ptr(), dw3=dws[0].data_ptr(),
                         dw5=dws[1].data_ptr(), dw7=dws[2].data_ptr(), B=B, Lc=Lc, N=N, Cout=Cout, Cin=cin, ld_in=ld_in,
                         num_blocks=nb)
     if _timing is None:
-        check(lib().tecm_conv_dw_bf16(C.byref(d), stream_ptr()), "tecm_conv_dw_bf16")
+        check(run(C.byref(d), stream_ptr()), what)
         return dws
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    check(lib().tecm_conv_dw_bf16(C.byref(d), stream_ptr()), "tecm_conv_dw_bf16")
+    check(run(C.byref(d), stream_ptr()), what)
     e1.record()
-    name = "conv_dw_seq_kernel" + (f" M={15 * ld_in} N={Cout} K={B * Lc * N}" if _timing_detail else "")
+    name = ("conv_dw_seq_f32_kernel" if f32 else "conv_dw_seq_kernel") + (f" M={15 * ld_in} N={Cout} K={B * Lc * N}" if _timing_detail else "")
     _timing.append((name, 2.0 * B * Lc * N * ld_in * 15 * Cout, e0, e1))
     return dws
 

@@ -346,18 +346,21 @@ def test_conv_dx_sequence_tile_kernel(dev, Bn, Lc, N, cin, ld_in, Cout, f32):
 @pytest.mark.parametrize("Bn,Lc,N,cin,ld_in,Cout", [(2, 48, 5, 22, 24, 64), (1, 24, 9, 64, 64, 128), (2, 8, 4, 22, 24, 64),
                                                   (1, 12, 7, 64, 64, 128), (1, 16, 2911, 22, 24, 64), (3, 4, 3, 64, 64, 64),
                                                   (1, 24, 1203, 64, 64, 128), (2, 40, 6, 64, 64, 128), (1, 96, 3, 22, 24, 128)])
-def test_conv_dw_sequence_tile_kernel(dev, Bn, Lc, N, cin, ld_in, Cout, monkeypatch):
-    """csrc/conv_dw_seq.hip: the weight gradients of the three parallel Conv1d (modules.py:43-60) from the bf16 block
-    input and the bf16 dy in one persistent launch (+ the fixed-order slab reduction), against an fp64 conv-backward of
-    the same bf16 operands (2e-4).  Ragged node blocks, sequences that are not a multiple of 8 or longer than one tile
+@pytest.mark.parametrize("f32", [False, True], ids=["bf16", "fp32"])
+def test_conv_dw_sequence_tile_kernel(dev, Bn, Lc, N, cin, ld_in, Cout, f32, monkeypatch):
+    """csrc/conv_dw_seq.hip: the weight gradients of the three parallel Conv1d (modules.py:43-60) from the block input
+    and dy -- both bf16 (bf16 mode) or both fp32 (exact f32 MFMA) -- in one persistent launch (+ the fixed-order slab
+    reduction), against an fp64 conv-backward of the same operands (2e-4 / 2e-5).  Ragged node blocks, sequences that are not a multiple of 8 or longer than one tile
     (time chunks of 24 with re-read halos, a ragged last chunk), every channel-width pair, more tiles than blocks
     (persistent loop, two register sets in flight) and fewer; the padding columns of the input carry garbage and must
     not matter; two runs agree bit for bit."""
     from tecmollm import ops
     g = torch.Generator().manual_seed(Lc * 1000 + N)
     CT = 3 * Cout
-    dy = (torch.randn(Bn, Lc, N, CT, generator=g) * 0.5).bfloat16()
-    x = torch.randn(Bn, Lc, N, ld_in, generator=g).bfloat16()
+    dt = torch.float32 if f32 else torch.bfloat16
+    dy = (torch.randn(Bn, Lc, N, CT, generator=g) * 0.5).to(dt)
+    x = torch.randn(Bn, Lc, N, ld_in, generator=g).to(dt)
+    tol = 2e-5 if f32 else TOL
     S = Bn * N
     xs = x[..., :cin].double().permute(0, 2, 3, 1).reshape(S, cin, Lc)
     dys = dy.double().permute(0, 2, 3, 1).reshape(S, CT, Lc)
@@ -369,7 +372,7 @@ def test_conv_dw_sequence_tile_kernel(dev, Bn, Lc, N, cin, ld_in, Cout, monkeypa
     torch.cuda.synchronize()
     for w, r in zip(got, refs):
         assert w.shape == r.shape and torch.isfinite(w).all()
-        assert _rel(w, r) < TOL
+        assert _rel(w, r) < tol
     again = ops.conv_dw(xd, dyd, Bn, Lc, N, Cout, cin, ld_in)
     for w, v in zip(got, again):
         assert torch.equal(w, v)
@@ -379,7 +382,7 @@ def test_conv_dw_sequence_tile_kernel(dev, Bn, Lc, N, cin, ld_in, Cout, monkeypa
     few = ops.conv_dw(xd, dyd, Bn, Lc, N, Cout, cin, ld_in)
     ops._cu_count.clear()
     for w, r in zip(few, refs):
-        assert _rel(w, r) < TOL
+        assert _rel(w, r) < tol
 
 
 @pytest.mark.parametrize("f32", [False, True], ids=["bf16", "fp32"])

@@ -8,9 +8,10 @@ from tecmollm import ops
 
 dev = torch.device("cuda")
 B, N = 8, 2911
+dt = torch.float32 if os.environ.get("PRECISION", "bf16") == "fp32" else torch.bfloat16
 for Lc, cin, ld_in, Cout in ((48, 22, 24, 64), (24, 64, 64, 128)):
-    x = torch.randn(B, Lc, N, ld_in, device=dev).bfloat16()
-    dy = torch.randn(B, Lc, N, 3 * Cout, device=dev).bfloat16()
+    x = torch.randn(B, Lc, N, ld_in, device=dev).to(dt)
+    dy = torch.randn(B, Lc, N, 3 * Cout, device=dev).to(dt)
     for _ in range(3):
         ops.conv_dw(x, dy, B, Lc, N, Cout, cin, ld_in)
     torch.cuda.synchronize()
@@ -22,6 +23,7 @@ for Lc, cin, ld_in, Cout in ((48, 22, 24, 64), (24, 64, 64, 128)):
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / n
-    mb = (x.numel() + dy.numel()) * 2 / 1e6
+    mb = (x.numel() + dy.numel()) * x.element_size() / 1e6
+    tf = 2.0 * B * Lc * N * 15 * cin * Cout / us * 1e-6
     print(f"ld_in={ld_in} Cout={Cout} Lc={Lc}: {us:7.1f} us per call (kernel + reduce), operands {mb:.0f} MB -> {mb / us * 1e-3 * 1e3:.2f} GB/ms"
-          f" = {mb / us:.2f} TB/s   ablate={os.environ.get('TECM_CONV_DW_ABLATE', '0')}")
+          f" = {mb / us:.2f} TB/s, {tf:.1f} TFLOP/s (real channels)   ablate={os.environ.get('TECM_CONV_DW_ABLATE', '0')}")

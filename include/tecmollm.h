@@ -33,7 +33,7 @@ extern "C" {
 #define TECM_E_LAUNCH (-3)     /* hipGetLastError() != hipSuccess after the launch       */
 #define TECM_E_LDS (-4)        /* problem does not fit the 160 KiB LDS budget            */
 
-#define TECM_ABI_VERSION 13
+#define TECM_ABI_VERSION 14
 int tecm_abi_version(void);
 /* Human-readable text for the last error on this thread (host pointer, never NULL). */
 const char* tecm_last_error(void);
@@ -226,11 +226,16 @@ int tecm_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ld
 /* Causal multi-head self-attention over T tokens per sequence (GPT2Attention, modeling_gpt2.py:54-73,
  * :144-226; all-ones attention_mask tec_mollm.py:111 => pure causal).  qkv: (B,T,N,3*D) time-major
  * rows, ctx: (B,T,N,D).  head_dim = D/heads must be 64.  Dropout on the probabilities. */
-/* ctx_bf16 != 0: ctx is a bf16 (B,T,N,D) tensor (its only reader, attn.c_proj, is a bf16 GEMM). */
-int tecm_attention_fwd(const float* qkv, void* ctx, int32_t ctx_bf16, int32_t B, int32_t T, int32_t N, int32_t heads,
+/* io_bf16: TECM_ATT_OUT_BF16 -- ctx is a bf16 (B,T,N,D) tensor (its only reader, attn.c_proj, is a bf16 GEMM);
+ * TECM_ATT_QKV_BF16 -- qkv is a bf16 (B,T,N,3*D) tensor (bf16 mode: the c_attn GEMM stores its output as bf16, which is
+ * what a Linear's output is under torch.autocast, train.py:68; scores, softmax and the weighted sum stay fp32). */
+#define TECM_ATT_OUT_BF16 1
+#define TECM_ATT_QKV_BF16 2
+int tecm_attention_fwd(const float* qkv, void* ctx, int32_t io_bf16, int32_t B, int32_t T, int32_t N, int32_t heads,
                        int32_t D, const TecmDrop* prob_drop, void* stream);
-/* dqkv_bf16 != 0: dqkv is a bf16 (B,T,N,3*D) tensor (its readers, the c_attn dX and the LoRA-B dW GEMMs, are bf16 GEMMs). */
-int tecm_attention_bwd(const float* qkv, const float* dctx, void* dqkv, int32_t dqkv_bf16, int32_t B, int32_t T, int32_t N,
+/* io_bf16: TECM_ATT_OUT_BF16 -- dqkv is a bf16 (B,T,N,3*D) tensor (its readers, the c_attn dX and the LoRA-B dW GEMMs, are
+ * bf16 GEMMs); TECM_ATT_QKV_BF16 -- qkv is the bf16 tensor the forward read.  dctx is fp32. */
+int tecm_attention_bwd(const float* qkv, const float* dctx, void* dqkv, int32_t io_bf16, int32_t B, int32_t T, int32_t N,
                        int32_t heads, int32_t D, const TecmDrop* prob_drop, void* stream);
 
 /* ------------------------------------------------------------------ reductions / small ops

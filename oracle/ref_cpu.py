@@ -150,7 +150,8 @@ class Rounding:
     """Operand rounding of the dense contractions as a PAIR: `fwd` is applied to both operands of a forward
     contraction, `bwd` to both operands of the two contractions its backward consists of (dX = dY.W^T and
     dW = X^T.dY).  Accumulation, bias, activation, dropout, norms, softmax and the GATv2 stage are fp32 in every mode;
-    the one activation INPUT that is rounded is the GPT-2 c_fc output (`stored`, below).
+    the tensors that are rounded where they are STORED (`stored`, below) are the GPT-2 c_fc output GELU is evaluated at
+    and the c_attn output qkv the attention reads -- bf16 Linear outputs under autocast.
     FP32 = the reference's CPU arithmetic.  BF16 = what `torch.autocast('cuda', bfloat16)` (train.py:68) does to the
     operands of Linear / Conv1d / matmul, forward AND backward, as the MI355X bf16 mode implements it: fp32 outputs,
     bf16 operands.  A tensor the HIP path stores in HBM as bf16 (LN outputs, attention context, gelu(c_fc), conv
@@ -314,7 +315,7 @@ def gpt2_lora(h: torch.Tensor, p: Params, n_layers: int, q: Rounding = FP32, mas
         Bm = p[pre + "attn.c_attn.lora_B.default.weight"]    # (2304, r)
         z = mm(_mul(u, masks, f"lora{i}"), A.t(), q, f=False)
         wcat = torch.cat([p[pre + "attn.c_attn.base_layer.weight"], LORA_SCALE * Bm.t()], 0)     # (768 + r, 2304)
-        qkv = mm(torch.cat([u, z], -1), wcat, q) + p[pre + "attn.c_attn.base_layer.bias"]
+        qkv = stored(mm(torch.cat([u, z], -1), wcat, q) + p[pre + "attn.c_attn.base_layer.bias"], q)   # a bf16 tensor under autocast
         qq, k, v = qkv.split(D, dim=-1)
         qq = qq.view(S, T, GPT2_HEADS, hd).transpose(1, 2)
         k = k.view(S, T, GPT2_HEADS, hd).transpose(1, 2)

@@ -24,6 +24,18 @@ __device__ __forceinline__ void fma4(float4& acc, float s, const float4& v) {
   acc.x += s * v.x; acc.y += s * v.y; acc.z += s * v.z; acc.w += s * v.w;
 }
 
+// qkv is fp32, or bf16 (template Q16) when the c_attn GEMM stored it that way (bf16 mode: the Linear's output is a bf16
+// tensor under autocast): four consecutive elements at element offset `off` as floats
+template <bool Q16>
+__device__ __forceinline__ float4 ldq(const float* __restrict__ qkv, int64_t off) {
+  if constexpr (Q16) {
+    const tecm_bf16x4 h = *reinterpret_cast<const tecm_bf16x4*>(reinterpret_cast<const __bf16*>(qkv) + off);
+    return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+  } else {
+    return *reinterpret_cast<const float4*>(qkv + off);
+  }
+}
+
 // ctx is fp32, or bf16 when its only reader is a bf16 matrix-core GEMM (rounded once here instead of in that loader)
 __device__ __forceinline__ void store_ctx(float* ctx, int ctx_bf16, int64_t off, const float4& o) {
   if (ctx_bf16)
@@ -33,7 +45,7 @@ __device__ __forceinline__ void store_ctx(float* ctx, int ctx_bf16, int64_t off,
 }
 
 // TT > 0: compile-time T with q/k/v held in registers; TT == 0: runtime T <= 32, k/v re-read (L1/L2).
-template <int TT>
+template <int TT, bool Q16>
 __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ ctx,
                                                             int ctx_bf16, int B, int Trt, int N, int H, int D, DropA dr) {
   const int T = TT > 0 ? TT : Trt;
@@ -53,10 +65,10 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restr
     float4 q[TT], k[TT], v[TT];
 #pragma unroll
     for (int p = 0; p < TT; ++p) {
-      const float* r = qkv + (row0 + (int64_t)p * N) * ld + col;
-      q[p] = *reinterpret_cast<const float4*>(r);
-      k[p] = *reinterpret_cast<const float4*>(r + D);
-      v[p] = *reinterpret_cast<const float4*>(r + 2 * D);
+      const int64_t r = (row0 + (int64_t)p * N) * ld + col;
+      q[p] = ldq<Q16>(qkv, r);
+      k[p] = ldq<Q16>(qkv, r + D);
+      v[p] = ldq<Q16>(qkv, r + 2 * D);
     }
 #pragma unroll
     for (int i = 0; i < TT; ++i) {
@@ -85,11 +97,11 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restr
     }
   } else {
     for (int i = 0; i < T; ++i) {
-      const float4 qi = *reinterpret_cast<const float4*>(qkv + (row0 + (int64_t)i * N) * ld + col);
+      const float4 qi = ldq<Q16>(qkv, (row0 + (int64_t)i * N) * ld + col);
       float s[32];
       float mx = -INFINITY;
       for (int j = 0; j <= i; ++j) {
-        const float4 kj = *reinterpret_cast<const float4*>(qkv + (row0 + (int64_t)j * N) * ld + D + col);
+        const float4 kj = ldq<Q16>(qkv, (row0 + (int64_t)j * N) * ld + D + col);
         s[j] = group16_sum(dot4(qi, kj)) * scale;
         mx = fmaxf(mx, s[j]);
       }
@@ -101,7 +113,7 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restr
       const float inv = 1.0f / den;
       float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int j = 0; j <= i; ++j) {
-        const float4 vj = *reinterpret_cast<const float4*>(qkv + (row0 + (int64_t)j * N) * ld + 2 * D + col);
+        const float4 vj = ldq<Q16>(qkv, (row0 + (int64_t)j * N) * ld + 2 * D + col);
         float p = s[j] * inv;
         if (dr.thresh) p *= tecm_drop_mult(dr.seed, (uint64_t)(((item * T + i) * T) + j), dr.thresh, dr.inv);
         fma4(o, p, vj);
@@ -114,7 +126,7 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restr
 // Forward for 12 < T <= TM: k and v register-resident (2 x 24 float4), q_i loaded per query row; loops unrolled to TM
 // behind wave-uniform `i < T` guards (see attention_bwd_kernel_qstream).  The runtime-T path above re-reads k_j / v_j
 // from L1/L2 for every (i, j).
-template <int TM>
+template <int TM, bool Q16>
 __global__ __launch_bounds__(256) void attention_fwd_kernel_kv(const float* __restrict__ qkv, float* __restrict__ ctx,
                                                                int ctx_bf16, int B, int T, int N, int H, int D, DropA dr) {
   const int sub = threadIdx.x & 15;
@@ -133,15 +145,15 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel_kv(const float* __re
   for (int p = 0; p < TM; ++p) {
     k[p] = v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p < T) {
-      const float* r = qkv + (row0 + (int64_t)p * N) * ld + col;
-      k[p] = *reinterpret_cast<const float4*>(r + D);
-      v[p] = *reinterpret_cast<const float4*>(r + 2 * D);
+      const int64_t r = (row0 + (int64_t)p * N) * ld + col;
+      k[p] = ldq<Q16>(qkv, r + D);
+      v[p] = ldq<Q16>(qkv, r + 2 * D);
     }
   }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     if (i < T) {
-      const float4 qi = *reinterpret_cast<const float4*>(qkv + (row0 + (int64_t)i * N) * ld + col);
+      const float4 qi = ldq<Q16>(qkv, (row0 + (int64_t)i * N) * ld + col);
       float s[TM];
       float mx = -INFINITY;
 #pragma unroll
@@ -171,7 +183,7 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel_kv(const float* __re
 // Backward: recompute the probabilities, then
 //   dP~_ij = <dctx_i, v_j>;  dV_j += P~_ij dctx_i;  dP_ij = dP~_ij * keep/(1-p);
 //   dS_ij = P_ij (dP_ij - sum_k P_ik dP_ik);  dQ_i += dS_ij K_j / 8;  dK_j += dS_ij Q_i / 8.
-template <int TT>
+template <int TT, bool Q16>
 __device__ __forceinline__ void attention_bwd_body(const float* __restrict__ qkv, const float* __restrict__ dctx,
                                                    float* __restrict__ dqkv, int dqkv_bf16, int B, int Trt, int N, int H,
                                                    int D, DropA dr) {
@@ -192,10 +204,10 @@ __device__ __forceinline__ void attention_bwd_body(const float* __restrict__ qkv
   float4 q[TM], k[TM], v[TM], dq[TM], dk[TM], dv[TM];
 #pragma unroll
   for (int p = 0; p < T; ++p) {
-    const float* r = qkv + (row0 + (int64_t)p * N) * ld + col;
-    q[p] = *reinterpret_cast<const float4*>(r);
-    k[p] = *reinterpret_cast<const float4*>(r + D);
-    v[p] = *reinterpret_cast<const float4*>(r + 2 * D);
+    const int64_t r = (row0 + (int64_t)p * N) * ld + col;
+    q[p] = ldq<Q16>(qkv, r);
+    k[p] = ldq<Q16>(qkv, r + D);
+    v[p] = ldq<Q16>(qkv, r + 2 * D);
     dq[p] = make_float4(0.f, 0.f, 0.f, 0.f);
     dk[p] = dq[p];
     dv[p] = dq[p];
@@ -250,7 +262,7 @@ __device__ __forceinline__ void attention_bwd_body(const float* __restrict__ qkv
 // arrays with runtime bounds, i.e. scratch: 6.0 ms per launch at B = 2, L_in = 336 against 1.2 ms for the forward), and
 // the guards keep the scheduler from interleaving query rows (a guard-free T = 21 instance hoisted the loads of all
 // rows and spilled 856 VGPRs).
-template <int TM>
+template <int TM, bool Q16>
 __global__ __launch_bounds__(256, 1) void attention_bwd_kernel_qstream(const float* __restrict__ qkv,
                                                                        const float* __restrict__ dctx,
                                                                        float* __restrict__ dqkv, int dqkv_bf16, int B, int T,
@@ -272,16 +284,16 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel_qstream(const flo
   for (int p = 0; p < TM; ++p) {
     k[p] = v[p] = dk[p] = dv[p] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p < T) {
-      const float* r = qkv + (row0 + (int64_t)p * N) * ld + col;
-      k[p] = *reinterpret_cast<const float4*>(r + D);
-      v[p] = *reinterpret_cast<const float4*>(r + 2 * D);
+      const int64_t r = (row0 + (int64_t)p * N) * ld + col;
+      k[p] = ldq<Q16>(qkv, r + D);
+      v[p] = ldq<Q16>(qkv, r + 2 * D);
     }
   }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     if (i < T) {
       const int64_t roff = row0 + (int64_t)i * N;
-      const float4 qi = *reinterpret_cast<const float4*>(qkv + roff * ld + col);
+      const float4 qi = ldq<Q16>(qkv, roff * ld + col);
       const float4 go = *reinterpret_cast<const float4*>(dctx + roff * D + col);
       float4 dqi = make_float4(0.f, 0.f, 0.f, 0.f);
       float pr[TM], dp[TM];
@@ -328,19 +340,19 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel_qstream(const flo
   }
 }
 
-template <int TT>
+template <int TT, bool Q16>
 __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restrict__ qkv,
                                                             const float* __restrict__ dctx, float* __restrict__ dqkv,
                                                             int dqkv_bf16, int B, int Trt, int N, int H, int D, DropA dr) {
-  attention_bwd_body<TT>(qkv, dctx, dqkv, dqkv_bf16, B, Trt, N, H, D, dr);
+  attention_bwd_body<TT, Q16>(qkv, dctx, dqkv, dqkv_bf16, B, Trt, N, H, D, dr);
 }
 // T = 8, 12: six float4[T] register arrays need more than 256 VGPRs -- one wave per SIMD, the whole 512-entry file
-template <int TT>
+template <int TT, bool Q16>
 __global__ __launch_bounds__(256, 1) void attention_bwd_kernel_wide(const float* __restrict__ qkv,
                                                                     const float* __restrict__ dctx,
                                                                     float* __restrict__ dqkv, int dqkv_bf16, int B, int Trt,
                                                                     int N, int H, int D, DropA dr) {
-  attention_bwd_body<TT>(qkv, dctx, dqkv, dqkv_bf16, B, Trt, N, H, D, dr);
+  attention_bwd_body<TT, Q16>(qkv, dctx, dqkv, dqkv_bf16, B, Trt, N, H, D, dr);
 }
 
 int check(const char* who, const void* a, const void* b, const void* c, int B, int T, int N, int heads, int D) {
@@ -362,17 +374,23 @@ DropA make_dropa(const TecmDrop* d) {
 
 }  // namespace
 
-extern "C" int tecm_attention_fwd(const float* qkv, void* ctxv, int32_t ctx_bf16, int32_t B, int32_t T, int32_t N,
+extern "C" int tecm_attention_fwd(const float* qkv, void* ctxv, int32_t io_bf16, int32_t B, int32_t T, int32_t N,
                                   int32_t heads, int32_t D, const TecmDrop* prob_drop, void* stream) {
   float* ctx = static_cast<float*>(ctxv);
   const int rc = check("tecm_attention_fwd", qkv, ctx, ctx, B, T, N, heads, D);
   if (rc) return rc;
+  TECM_REQUIRE((io_bf16 & ~3) == 0, TECM_E_ARG, "tecm_attention_fwd: io_bf16 is a mask of TECM_ATT_OUT_BF16 | TECM_ATT_QKV_BF16");
+  const int ctx_bf16 = io_bf16 & TECM_ATT_OUT_BF16;
+  const bool q16 = (io_bf16 & TECM_ATT_QKV_BF16) != 0;
   const int64_t items = (int64_t)B * N * heads;
   const dim3 grid((unsigned)((items + 15) / 16));
   const DropA dr = make_dropa(prob_drop);
   hipStream_t st = (hipStream_t)stream;
-#define ATT_FWD(TT) \
-  hipLaunchKernelGGL((attention_fwd_kernel<TT>), grid, dim3(256), 0, st, qkv, ctx, (int)ctx_bf16, B, T, N, heads, D, dr)
+#define ATT_FWD(TT)                                                                                                        \
+  do {                                                                                                                     \
+    if (q16) hipLaunchKernelGGL((attention_fwd_kernel<TT, true>), grid, dim3(256), 0, st, qkv, ctx, ctx_bf16, B, T, N, heads, D, dr); \
+    else hipLaunchKernelGGL((attention_fwd_kernel<TT, false>), grid, dim3(256), 0, st, qkv, ctx, ctx_bf16, B, T, N, heads, D, dr);    \
+  } while (0)
   switch (T) {
     case 1: ATT_FWD(1); break;
     case 2: ATT_FWD(2); break;
@@ -382,11 +400,12 @@ extern "C" int tecm_attention_fwd(const float* qkv, void* ctxv, int32_t ctx_bf16
     case 8: ATT_FWD(8); break;
     case 12: ATT_FWD(12); break;       // L_in = 192 with patch_len 4
     default:
-      if (T > 12 && T <= 24)             // L_in = 336 -> 21 tokens (the reference's default)
-        hipLaunchKernelGGL((attention_fwd_kernel_kv<24>), grid, dim3(256), 0, st, qkv, ctx, (int)ctx_bf16, B,
-                           T, N, heads, D, dr);
-      else
+      if (T > 12 && T <= 24) {           // L_in = 336 -> 21 tokens (the reference's default)
+        if (q16) hipLaunchKernelGGL((attention_fwd_kernel_kv<24, true>), grid, dim3(256), 0, st, qkv, ctx, ctx_bf16, B, T, N, heads, D, dr);
+        else hipLaunchKernelGGL((attention_fwd_kernel_kv<24, false>), grid, dim3(256), 0, st, qkv, ctx, ctx_bf16, B, T, N, heads, D, dr);
+      } else {
         ATT_FWD(0);                      // runtime T <= 32: k / v re-read from L1/L2
+      }
       break;
   }
 #undef ATT_FWD
@@ -394,40 +413,37 @@ extern "C" int tecm_attention_fwd(const float* qkv, void* ctxv, int32_t ctx_bf16
   return TECM_OK;
 }
 
-extern "C" int tecm_attention_bwd(const float* qkv, const float* dctx, void* dqkv_, int32_t dqkv_bf16, int32_t B, int32_t T,
+extern "C" int tecm_attention_bwd(const float* qkv, const float* dctx, void* dqkv_, int32_t io_bf16, int32_t B, int32_t T,
                                   int32_t N, int32_t heads, int32_t D, const TecmDrop* prob_drop, void* stream) {
   float* dqkv = reinterpret_cast<float*>(dqkv_);
   const int rc = check("tecm_attention_bwd", qkv, dctx, dqkv, B, T, N, heads, D);
   if (rc) return rc;
+  TECM_REQUIRE((io_bf16 & ~3) == 0, TECM_E_ARG, "tecm_attention_bwd: io_bf16 is a mask of TECM_ATT_OUT_BF16 | TECM_ATT_QKV_BF16");
+  const int dqkv_bf16 = io_bf16 & TECM_ATT_OUT_BF16;
+  const bool q16 = (io_bf16 & TECM_ATT_QKV_BF16) != 0;
   const int64_t items = (int64_t)B * N * heads;
   const dim3 grid((unsigned)((items + 15) / 16));
   const DropA dr = make_dropa(prob_drop);
   hipStream_t st = (hipStream_t)stream;
-#define ATT_BWD(TT) \
-  hipLaunchKernelGGL((attention_bwd_kernel<TT>), grid, dim3(256), 0, st, qkv, dctx, dqkv, dqkv_bf16, B, T, N, heads, D, dr)
+#define ATT_LAUNCH(KERNEL, TT)                                                                                             \
+  do {                                                                                                                     \
+    if (q16) hipLaunchKernelGGL((KERNEL<TT, true>), grid, dim3(256), 0, st, qkv, dctx, dqkv, dqkv_bf16, B, T, N, heads, D, dr); \
+    else hipLaunchKernelGGL((KERNEL<TT, false>), grid, dim3(256), 0, st, qkv, dctx, dqkv, dqkv_bf16, B, T, N, heads, D, dr);    \
+  } while (0)
   switch (T) {
-    case 1: ATT_BWD(1); break;
-    case 2: ATT_BWD(2); break;
-    case 3: ATT_BWD(3); break;
-    case 4: ATT_BWD(4); break;
-    case 6: ATT_BWD(6); break;
-    case 8:
-      hipLaunchKernelGGL((attention_bwd_kernel_wide<8>), grid, dim3(256), 0, st, qkv, dctx, dqkv, dqkv_bf16, B, T, N, heads, D,
-                         dr);
-      break;
-    case 12:
-      hipLaunchKernelGGL((attention_bwd_kernel_wide<12>), grid, dim3(256), 0, st, qkv, dctx, dqkv, dqkv_bf16, B, T, N, heads, D,
-                         dr);
-      break;
+    case 1: ATT_LAUNCH(attention_bwd_kernel, 1); break;
+    case 2: ATT_LAUNCH(attention_bwd_kernel, 2); break;
+    case 3: ATT_LAUNCH(attention_bwd_kernel, 3); break;
+    case 4: ATT_LAUNCH(attention_bwd_kernel, 4); break;
+    case 6: ATT_LAUNCH(attention_bwd_kernel, 6); break;
+    case 8: ATT_LAUNCH(attention_bwd_kernel_wide, 8); break;
+    case 12: ATT_LAUNCH(attention_bwd_kernel_wide, 12); break;
     default:
-      if (T > 12 && T <= 24)
-        hipLaunchKernelGGL((attention_bwd_kernel_qstream<24>), grid, dim3(256), 0, st, qkv, dctx, dqkv, dqkv_bf16, B, T, N,
-                           heads, D, dr);
-      else
-        ATT_BWD(0);
+      if (T > 12 && T <= 24) ATT_LAUNCH(attention_bwd_kernel_qstream, 24);
+      else ATT_LAUNCH(attention_bwd_kernel, 0);
       break;
   }
-#undef ATT_BWD
+#undef ATT_LAUNCH
   TECM_CHECK_LAUNCH("tecm_attention_bwd");
   return TECM_OK;
 }

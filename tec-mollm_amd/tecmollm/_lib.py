@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TECM_LIB", os.path.join(_HERE, "libtecmollm_hip.so"))   # override for experiments
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 c_f32p = C.c_void_p
 

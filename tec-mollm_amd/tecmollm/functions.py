@@ -22,6 +22,7 @@ from .graph import GraphMeta
 from .ops import (A_KM, A_MK, ACT_GELU_ERF, ACT_GELU_TANH, B_KN, B_NK, colsum, drop, gemm, pick_split_k, win)
 
 PRE16 = os.environ.get("TECM_PRE16", "1")[:1] != "0"     # diagnostics: "0" keeps the GPT-2 MLP pre-activation fp32
+QKV16 = os.environ.get("TECM_QKV16", "1")[:1] != "0"   # diagnostics: "0" keeps qkv fp32 in bf16 mode
 
 import ctypes as C
 
@@ -559,7 +560,9 @@ class GPT2StackFn(torch.autograd.Function):
             wcat = _empty(KE, F3, like=h)                   # [ W ; (alpha/r) B^T ]  K-extended c_attn (backward operand)
             wcat[:D].copy_(Wqkv)
             ops.transpose_scale(lB, LORA_R, wcat, F3, LORA_R, F3, LORA_SCALE, dst_off=D * F3)
-            qkv = _empty(M, F3, like=h)
+            # bf16 mode: qkv is written as bf16 by the c_attn GEMM (what a Linear's output is under autocast) and read as
+            # such by the attention kernels, forward and backward: 644 -> 322 MB per layer, three times over
+            qkv = torch.empty(M, F3, device=h.device, dtype=torch.bfloat16 if (a16 and QKV16) else torch.float32)
             if WqkvT is not None:                           # forward operand in [N][K] form: [ W^T | (alpha/r) B ]
                 wcatT = torch.empty(F3, KE, device=h.device, dtype=WqkvT.dtype)
                 wcatT[:, :D].copy_(WqkvT)

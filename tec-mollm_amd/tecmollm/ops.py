@@ -330,18 +330,22 @@ def groupnorm_gelu_bwd(dact: torch.Tensor, dstride: int, y: torch.Tensor, gamma:
     return dgb[0, :CT], dgb[0, CT:2 * CT], dgb[0, 2 * CT:]
 
 
+ATT_OUT_BF16, ATT_QKV_BF16 = 1, 2      # io_bf16 of tecm_attention_fwd / _bwd
+
+
 def attention_fwd(qkv: torch.Tensor, ctx: torch.Tensor, B: int, T: int, N: int, heads: int, D: int,
                   prob_drop: Optional[TecmDrop] = None) -> None:
     pd = prob_drop if prob_drop is not None else NO_DROP
-    check(lib().tecm_attention_fwd(qkv.data_ptr(), ctx.data_ptr(), 1 if ctx.dtype == torch.bfloat16 else 0, B, T, N,
-                                   heads, D, C.byref(pd), stream_ptr()), "tecm_attention_fwd")
+    io = (ATT_OUT_BF16 if ctx.dtype == torch.bfloat16 else 0) | (ATT_QKV_BF16 if qkv.dtype == torch.bfloat16 else 0)
+    check(lib().tecm_attention_fwd(qkv.data_ptr(), ctx.data_ptr(), io, B, T, N, heads, D, C.byref(pd), stream_ptr()),
+          "tecm_attention_fwd")
 
 
 def attention_bwd(qkv: torch.Tensor, dctx: torch.Tensor, dqkv: torch.Tensor, B: int, T: int, N: int, heads: int,
                   D: int, prob_drop: Optional[TecmDrop] = None) -> None:
     pd = prob_drop if prob_drop is not None else NO_DROP
-    check(lib().tecm_attention_bwd(qkv.data_ptr(), dctx.data_ptr(), dqkv.data_ptr(),
-                                   1 if dqkv.dtype == torch.bfloat16 else 0, B, T, N, heads, D, C.byref(pd),
+    io = (ATT_OUT_BF16 if dqkv.dtype == torch.bfloat16 else 0) | (ATT_QKV_BF16 if qkv.dtype == torch.bfloat16 else 0)
+    check(lib().tecm_attention_bwd(qkv.data_ptr(), dctx.data_ptr(), dqkv.data_ptr(), io, B, T, N, heads, D, C.byref(pd),
                                    stream_ptr()), "tecm_attention_bwd")
 
 

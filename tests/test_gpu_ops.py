@@ -301,6 +301,21 @@ def test_attention_fwd_bwd(dev, T):
     dq16 = torch.empty_like(qkv, dtype=torch.bfloat16)                # bf16 mode's output form: RNE of the same values
     ops.attention_bwd(qkv, dctx, dq16, Bn, T, N, H, D)
     assert torch.equal(dq16, dqkv.bfloat16())
+    # a bf16 qkv (TECM_ATT_QKV_BF16: the bf16 mode's c_attn output) is the same arithmetic on the widened values
+    q16 = qkv.bfloat16()
+    ctx_a, ctx_b = torch.empty_like(ctx), torch.empty_like(ctx)
+    ops.attention_fwd(q16, ctx_a, Bn, T, N, H, D, ops.drop(0.1, 5, 1))
+    ops.attention_fwd(q16.float(), ctx_b, Bn, T, N, H, D, ops.drop(0.1, 5, 1))
+    assert torch.equal(ctx_a, ctx_b)
+    dq_a, dq_b = torch.empty_like(dq16), torch.empty_like(dq16)
+    ops.attention_bwd(q16, dctx, dq_a, Bn, T, N, H, D, ops.drop(0.1, 5, 1))
+    ops.attention_bwd(q16.float(), dctx, dq_b, Bn, T, N, H, D, ops.drop(0.1, 5, 1))
+    # (the two instantiations contract multiply-adds differently: last-bit differences in fp32, i.e. the odd flipped bf16
+    # rounding (bf16 inputs put many results next to rounding ties: 4 % of the elements with dropout on) -- at most one
+    # bf16 ulp (cancelled-out entries: 1e-6 of the largest))
+    diff = (dq_a.float() - dq_b.float()).abs()
+    assert float((diff > 0).float().mean()) < 0.1
+    assert bool((diff <= dq_b.float().abs() * 2.0 ** -7 + 1e-6 * float(dq_b.float().abs().max())).all())
 
 
 def test_attention_dropout_mask_is_consistent(dev):

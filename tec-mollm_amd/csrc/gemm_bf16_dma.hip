@@ -329,6 +329,340 @@ __global__ __launch_bounds__(D2TH, 4) void gemm_bf16_dma2_kernel(const TecmGemm 
   block_epilogue16<MT, NT, WTM, WTN, true, true>(g, acc, smem_raw, wave, lane, wm, wn, m0, n0);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Third geometry (round 3): the 256 x 256 tile of the first kernel on a FOUR-slot ring of 32-deep K-tiles (4 x 32 KiB),
+// because what the two-slot kernel waits for is its own operand DMA: a tile is requested one K-tile (4 k-steps, ~0.9 us
+// of MFMA) before it is needed, which is the latency of an L2 hit under load and less than that of a miss.  Here
+//   * tile t+3 is requested while tile t is multiplied (three K-tiles = ~1.4 us ahead), waits are counted
+//     (`s_waitcnt vmcnt(4)`: everything but the youngest tile's four DMAs of this wave);
+//   * the barrier that publishes tile t+1 sits BETWEEN the two 16-deep k-steps of tile t, and the fragments of tile t+1's
+//     first k-step are read behind it, under the MFMAs of tile t's second k-step: no LDS read latency is exposed after a
+//     barrier, and the slot the new DMA overwrites (tile t-1's) was left by every wave a whole k-step ago.
+// 64-byte LDS rows, swizzle and piece layout as the second geometry; 8 waves as 2(m) x 4(n) of 128 x 64 as the first.
+constexpr int D3M = 256, D3N = 256, D3K = 32, D3TH = 512, D3ST = 4;
+
+__global__ __launch_bounds__(D3TH, 1) void gemm_bf16_dma3_kernel(const TecmGemm g, int tiles_m, int tiles_n) {
+  constexpr int WM = 2, WN = 4;
+  constexpr int WTM = D3M / WM, WTN = D3N / WN;        // 128 x 64 per wave
+  constexpr int MT = WTM / 32, NT = WTN / 32;          // 4 x 2
+  constexpr int A_ELEMS = D3M * D3K, B_ELEMS = D3N * D3K, TILE_ELEMS = A_ELEMS + B_ELEMS;   // 32 KiB
+  constexpr int PIECE = 16 * D3K;                      // 16 rows of 64 B = 1 KiB
+  __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[D3ST * TILE_ELEMS * 2];
+  __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);
+  static_assert(D3ST * TILE_ELEMS * 2 >= 8 * 32 * (WTN + 4) * 4, "epilogue slabs fit in the operand ring");
+
+  const int nwg = tiles_m * tiles_n;
+  const int id = blockIdx.x;
+  const int xcd = id & 7, local = id >> 3;
+  const int q8 = nwg >> 3, r8 = nwg & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
+  const int GROUP_M = g._p1 > 0 ? g._p1 : 4;
+  const int per_group = GROUP_M * tiles_n;
+  const int group = wg / per_group;
+  const int first_m = group * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int in_group = wg - group * per_group;
+  const int tm = first_m + in_group % gsz, tn = in_group / gsz;
+  const int64_t m0 = (int64_t)tm * D3M;
+  const int64_t n0 = (int64_t)tn * D3N;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 31, h = lane >> 5;
+  const int ntiles = (int)g.K / D3K;                   // K % 32 == 0 (host)
+
+  // pieces 0..15 = A rows 16p.., 16..31 = B rows; wave w moves pieces w, w + 8 (A) and 16 + w, 24 + w (B)
+  const __bf16* Ah = reinterpret_cast<const __bf16*>(g.A);
+  const __bf16* Bh = reinterpret_cast<const __bf16*>(g.B);
+  const __bf16* src[4];
+  int dst[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = wave + 8 * i;
+    const bool isb = p >= 16;
+    const int row = (isb ? p - 16 : p) * 16 + (lane >> 2);
+    const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+    if (!isb) {
+      int64_t gm = m0 + row;
+      gm = gm < g.M ? gm : g.M - 1;                    // clamped rows feed accumulator rows that are never stored
+      src[i] = Ah + gm * g.lda + chunk * 8;
+      dst[i] = p * PIECE;
+    } else {
+      int64_t gn = n0 + row;
+      gn = gn < g.N ? gn : g.N - 1;
+      src[i] = Bh + gn * g.ldb + chunk * 8;
+      dst[i] = A_ELEMS + (p - 16) * PIECE;
+    }
+  }
+  auto issue_tile = [&](int slot) {
+    __bf16* buf = smem + slot * TILE_ELEMS;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      dma16(src[i], buf + dst[i]);
+      src[i] += D3K;
+    }
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  int a_off[MT], b_off[NT], a_sw[MT], b_sw[NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int row = wm * WTM + i * 32 + r;
+    a_off[i] = row * D3K;
+    a_sw[i] = (row >> 2) & 3;
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int row = wn * WTN + j * 32 + r;
+    b_off[j] = A_ELEMS + row * D3K;
+    b_sw[j] = (row >> 2) & 3;
+  }
+  auto read_frags = [&](const __bf16* T, int s_, bf16x8 (&af)[MT], bf16x8 (&bf)[NT]) {
+    const int c = 2 * s_ + h;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(T + a_off[i] + ((c ^ a_sw[i]) << 3));
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(T + b_off[j] + ((c ^ b_sw[j]) << 3));
+  };
+  auto do_mfma = [&](const bf16x8 (&af)[MT], const bf16x8 (&bf)[NT]) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+  };
+  auto interleave = [&]() {                            // one LDS read behind each of the first six MFMAs of a k-step
+#pragma unroll
+    for (int m = 0; m < MT * NT; ++m) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (m < MT + NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+  };
+
+  issue_tile(0);
+  if (ntiles > 1) issue_tile(1);
+  if (ntiles > 2) issue_tile(2);
+  // tile 0 has landed once at most the DMAs of the tiles requested after it are outstanding
+  if (ntiles > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (ntiles > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  bf16x8 fa[2][MT], fb[2][NT];
+  read_frags(smem, 0, fa[0], fb[0]);
+  int slot = 0;
+  for (int t = 0; t < ntiles; ++t) {
+    const __bf16* Tc = smem + slot * TILE_ELEMS;
+    const int nslot = (slot + 1) & 3;
+    read_frags(Tc, 1, fa[1], fb[1]);
+    do_mfma(fa[0], fb[0]);
+    interleave();
+    if (t + 1 < ntiles) {
+      // tile t+1 has landed once at most tile t+2's four DMAs of this wave are outstanding
+      if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (t + 3 < ntiles) issue_tile((slot + 3) & 3);  // the slot of tile t-1: every wave left it a k-step ago
+      read_frags(smem + nslot * TILE_ELEMS, 0, fa[0], fb[0]);
+    }
+    do_mfma(fa[1], fb[1]);
+    if (t + 1 < ntiles) interleave();
+    slot = nslot;
+  }
+  __syncthreads();                                      // every wave has left the last K-tile: the ring becomes staging
+  block_epilogue16<MT, NT, WTM, WTN, true>(g, acc, smem_raw, wave, lane, wm, wn, m0, n0);
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Fourth geometry (round 3): the four-slot ring above with the two waves of every SIMD in ANTI-PHASE (see the loop).
+
+__global__ __launch_bounds__(D3TH, 1) void gemm_bf16_dma4_kernel(const TecmGemm g, int tiles_m, int tiles_n) {
+  constexpr int WM = 2, WN = 4;
+  constexpr int WTM = D3M / WM, WTN = D3N / WN;        // 128 x 64 per wave
+  constexpr int MT = WTM / 32, NT = WTN / 32;          // 4 x 2
+  constexpr int A_ELEMS = D3M * D3K, B_ELEMS = D3N * D3K, TILE_ELEMS = A_ELEMS + B_ELEMS;   // 32 KiB
+  constexpr int PIECE = 16 * D3K;                      // 16 rows of 64 B = 1 KiB
+  __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[D3ST * TILE_ELEMS * 2];
+  __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);
+  static_assert(D3ST * TILE_ELEMS * 2 >= 8 * 32 * (WTN + 4) * 4, "epilogue slabs fit in the operand ring");
+
+  const int nwg = tiles_m * tiles_n;
+  const int id = blockIdx.x;
+  const int xcd = id & 7, local = id >> 3;
+  const int q8 = nwg >> 3, r8 = nwg & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
+  const int GROUP_M = g._p1 > 0 ? g._p1 : 4;
+  const int per_group = GROUP_M * tiles_n;
+  const int group = wg / per_group;
+  const int first_m = group * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int in_group = wg - group * per_group;
+  const int tm = first_m + in_group % gsz, tn = in_group / gsz;
+  const int64_t m0 = (int64_t)tm * D3M;
+  const int64_t n0 = (int64_t)tn * D3N;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 31, h = lane >> 5;
+  const int ntiles = (int)g.K / D3K;                   // K % 32 == 0 (host)
+
+  // pieces 0..15 = A rows 16p.., 16..31 = B rows; wave w moves pieces w, w + 8 (A) and 16 + w, 24 + w (B)
+  const __bf16* Ah = reinterpret_cast<const __bf16*>(g.A);
+  const __bf16* Bh = reinterpret_cast<const __bf16*>(g.B);
+  const __bf16* src[4];
+  int dst[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = wave + 8 * i;
+    const bool isb = p >= 16;
+    const int row = (isb ? p - 16 : p) * 16 + (lane >> 2);
+    const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+    if (!isb) {
+      int64_t gm = m0 + row;
+      gm = gm < g.M ? gm : g.M - 1;                    // clamped rows feed accumulator rows that are never stored
+      src[i] = Ah + gm * g.lda + chunk * 8;
+      dst[i] = p * PIECE;
+    } else {
+      int64_t gn = n0 + row;
+      gn = gn < g.N ? gn : g.N - 1;
+      src[i] = Bh + gn * g.ldb + chunk * 8;
+      dst[i] = A_ELEMS + (p - 16) * PIECE;
+    }
+  }
+  auto issue_tile = [&](int slot) {
+    __bf16* buf = smem + slot * TILE_ELEMS;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      dma16(src[i], buf + dst[i]);
+      src[i] += D3K;
+    }
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  int a_off[MT], b_off[NT], a_sw[MT], b_sw[NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int row = wm * WTM + i * 32 + r;
+    a_off[i] = row * D3K;
+    a_sw[i] = (row >> 2) & 3;
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int row = wn * WTN + j * 32 + r;
+    b_off[j] = A_ELEMS + row * D3K;
+    b_sw[j] = (row >> 2) & 3;
+  }
+  auto read_frags = [&](const __bf16* T, int s_, bf16x8 (&af)[MT], bf16x8 (&bf)[NT]) {
+    const int c = 2 * s_ + h;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(T + a_off[i] + ((c ^ a_sw[i]) << 3));
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(T + b_off[j] + ((c ^ b_sw[j]) << 3));
+  };
+  auto do_mfma = [&](const bf16x8 (&af)[MT], const bf16x8 (&bf)[NT]) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+  };
+  auto interleave = [&]() {                            // one LDS read behind each of the first six MFMAs of a k-step
+#pragma unroll
+    for (int m = 0; m < MT * NT; ++m) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (m < MT + NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+  };
+
+  // ---- two wave groups (waves 0-3 / 4-7: one wave of each per SIMD) run the same program ONE BARRIER apart: while one
+  // group multiplies (8 MFMAs = 256 cycles per SIMD, s_setprio 1) the other reads its next fragments from LDS, requests
+  // the next tile and waits at the barrier -- the matrix pipe of a SIMD always has one wave feeding it.  A K-tile is two
+  // such phases (accumulator rows 0-1, then 2-3; the B fragments are read once per K-tile), four barriers.
+  //   * publish: every wave retires its own DMAs of tile t+1 (counted vmcnt) before its third barrier of tile t; the late
+  //     group does so one barrier later, and the early group's first read of tile t+1 sits behind exactly that barrier;
+  //   * recycle: tile t+3 goes into tile t-1's slot after the third barrier of tile t -- the late group issued its last
+  //     reads of tile t-1 five barriers earlier.
+  const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
+  issue_tile(0);
+  if (ntiles > 1) issue_tile(1);
+  if (ntiles > 2) issue_tile(2);
+  if (ntiles > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (ntiles > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                         // tile 0 is visible
+  if (grp) __builtin_amdgcn_s_barrier();                // the stagger
+  bf16x8 fa[2][2], fb[2][NT];
+  int slot = 0;
+  for (int t = 0; t < ntiles; ++t) {
+    const __bf16* Tc = smem + slot * TILE_ELEMS;
+    // ---- phase 0: B fragments of the K-tile, A fragments of accumulator rows 0-1
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+      const int c = 2 * s_ + h;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) fb[s_][j] = *reinterpret_cast<const bf16x8*>(Tc + b_off[j] + ((c ^ b_sw[j]) << 3));
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[s_][i] = *reinterpret_cast<const bf16x8*>(Tc + a_off[i] + ((c ^ a_sw[i]) << 3));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s_][i], fb[s_][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 1: A fragments of accumulator rows 2-3
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+      const int c = 2 * s_ + h;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[s_][i] = *reinterpret_cast<const bf16x8*>(Tc + a_off[2 + i] + ((c ^ a_sw[2 + i]) << 3));
+    }
+    if (t + 1 < ntiles) {                               // this wave's DMAs of tile t+1 have landed
+      if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    if (t + 3 < ntiles) issue_tile((slot + 3) & 3);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[2 + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s_][i], fb[s_][j], acc[2 + i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    slot = (slot + 1) & 3;
+  }
+  if (!grp) __builtin_amdgcn_s_barrier();               // the early group waits for the late one
+  __syncthreads();                                      // every wave has left the last K-tile: the ring becomes staging
+  block_epilogue16<MT, NT, WTM, WTN, true>(g, acc, smem_raw, wave, lane, wm, wn, m0, n0);
+}
+
 }  // namespace tecm_gemm16
 
 // Returns the number of K splits (1) when the DMA kernel served the call, 0 when the call is not eligible.
@@ -351,6 +685,21 @@ int tecm_gemm16_dma_try(const TecmGemm& g, hipStream_t st) {
   }
   const int tiles_m = (int)((g.M + DBM - 1) / DBM);
   const int tiles_n = (int)((g.N + DBN - 1) / DBN);
+  // TECM_BF16_DMA = 3 / 4: the four-slot ring, plain and with anti-phase wave groups (A/B diagnostics, tools/dma_ab.sh).
+  // Per shape the anti-phase ring measured K = 800: 418 -> 352 us, K = 3072 + residual epilogue: 517 -> 481, N = 3072
+  // K = 768: 659 -> 688, 8192^3: 1081 vs 1085 TFLOP/s -- and 396.5 vs 395.9 samples/s in the step, i.e. nothing: it is
+  // not dispatched by default.
+  const bool ring = sel && sel[0] == '4';
+  if (ring) {
+    hipLaunchKernelGGL(gemm_bf16_dma4_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(D3TH), 0, st, g, tiles_m, tiles_n);
+    TECM_CHECK_LAUNCH("tecm_gemm_bf16/dma4");
+    return 1;
+  }
+  if (sel && sel[0] == '3') {                           // A/B diagnostics: the four-slot ring geometry
+    hipLaunchKernelGGL(gemm_bf16_dma3_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(D3TH), 0, st, g, tiles_m, tiles_n);
+    TECM_CHECK_LAUNCH("tecm_gemm_bf16/dma3");
+    return 1;
+  }
   hipLaunchKernelGGL(gemm_bf16_dma_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(DNTH), 0, st, g, tiles_m, tiles_n);
   TECM_CHECK_LAUNCH("tecm_gemm_bf16/dma");
   return 1;

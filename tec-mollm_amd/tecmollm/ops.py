@@ -196,7 +196,10 @@ def _kernel_name(g: TecmGemm, use16: bool = False) -> str:
         if (both16 and g.split_k <= 1 and g.N % 4 == 0 and g.K % 32 == 0 and g.K >= 64 and g.M >= 256 and g.N >= 128
                 and sel != "0"):
             narrow = sel == "2" if sel else 1 <= g.N % 256 <= 128      # the 256 x 128 geometry (N = 800)
-            return "gemm_bf16_dma2_kernel" if narrow else "gemm_bf16_dma_kernel"
+            if narrow:
+                return "gemm_bf16_dma2_kernel"
+            ring = sel == "4"                                                 # the four-slot ring, anti-phase wave groups (A/B)
+            return "gemm_bf16_dma4_kernel" if ring else ("gemm_bf16_dma3_kernel" if sel == "3" else "gemm_bf16_dma_kernel")
         return f"gemm_bf16_kernel<{g.a_layout},{g.b_layout},{win16},{drp16}>"
     av = _vec(g.A, g.lda, g.a_win, g.a_layout == A_MK, g.K)
     bv = _vec(g.B, g.ldb, g.b_win, g.b_layout == B_NK, g.K)

@@ -142,7 +142,7 @@ def test_bf16_resident_operands_and_output_are_bit_identical(dev, M, N, K):
 
 @pytest.mark.parametrize("M,N,K", [(256, 128, 64), (257, 800, 2304), (700, 132, 96), (1031, 2304, 800), (4099, 768, 3072),
                                    (513, 3072, 768), (300, 256, 32 * 7)])
-@pytest.mark.parametrize("geometry", ["1", "2"], ids=["256x256", "256x128x2blocks"])
+@pytest.mark.parametrize("geometry", ["1", "2", "3", "4"], ids=["256x256", "256x128x2blocks", "256x256ring", "256x256antiphase"])
 def test_bf16_dma_kernel_matches_the_register_staged_kernel_bit_for_bit(dev, M, N, K, geometry, monkeypatch):
     """The 256x256 LDS-DMA kernel (gemm_bf16_dma.hip: both operands bf16 in HBM) against the 256x128 register-staged
     kernel on the same tensors: ragged M and N tiles, K tails of 32, single K-tile, every epilogue the GPT-2 stack
@@ -207,6 +207,29 @@ def test_bf16_preactivation_is_rounded_before_the_activation(dev, M, N, K):
     assert _rel(d, want) < TOL
     with pytest.raises(Exception):       # the fp32 kernel has no bf16 pre-activation
         ops.gemm(M, N, K, A16.float(), K, B16.float(), K, c, N, act=ops.ACT_GELU_TANH, preact=(pre16, N))
+
+
+def test_bf16_dma_ring_kernel_is_race_free_over_repeated_full_size_launches(dev, monkeypatch):
+    """The four-slot ring with anti-phase wave groups (gemm_bf16_dma4_kernel) synchronises by counted vmcnt + raw barriers:
+    a misplaced wait would show as rare wrong tiles that come and go with load.  Twelve back-to-back launches of the
+    step's own long-K shapes (M = 69 864 rows: 273 m-tiles over 256 CUs, every CU busy) must all equal the two-slot
+    kernel's result bit for bit."""
+    from tecmollm import ops
+    M = 69864
+    for N, K in ((768, 3072), (2304, 800)):
+        A16 = _rand(M, K, dev=dev, seed=11).bfloat16()
+        B16 = _rand(N, K, dev=dev, seed=12, scale=0.05).bfloat16()
+        bias = _rand(N, dev=dev, seed=13)
+        monkeypatch.setenv("TECM_BF16_DMA", "1")
+        want = torch.empty(M, N, device=dev)
+        ops.gemm(M, N, K, A16, K, B16, K, want, N, bias=bias, bf16=True)
+        monkeypatch.setenv("TECM_BF16_DMA", "4")
+        outs = [torch.empty(M, N, device=dev) for _ in range(12)]
+        for o in outs:
+            ops.gemm(M, N, K, A16, K, B16, K, o, N, bias=bias, bf16=True)
+        torch.cuda.synchronize()
+        for o in outs:
+            assert torch.equal(o, want)
 
 
 @pytest.mark.parametrize("Bn,L,N,Cin,Cout,k", [(2, 48, 5, 24, 64, 3), (2, 24, 7, 64, 128, 7), (1, 48, 300, 24, 64, 5)])

@@ -161,7 +161,17 @@ __global__ __launch_bounds__(DNTH, 1) void gemm_bf16_dma_kernel(const TecmGemm g
     read_frags(Tc, 0, fa[0], fb[0]);
     static_for<4>([&](auto sc) {
       constexpr int s = decltype(sc)::value;
+#ifdef DMA_ABLATE_HALFREADS                              // diagnostics: fragments of every other k-step are not read (wrong results)
+      if constexpr (s == 1) read_frags(Tc, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+      if constexpr (s == 0 || s == 2) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) fa[(s + 1) & 1][i] = fa[s & 1][i];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) fb[(s + 1) & 1][j] = fb[s & 1][j];
+      }
+#else
       if constexpr (s < 3) read_frags(Tc, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+#endif
       do_mfma(fa[s & 1], fb[s & 1]);
       // interleave: one LDS read behind each of the first six MFMAs of the step
 #pragma unroll
@@ -170,7 +180,9 @@ __global__ __launch_bounds__(DNTH, 1) void gemm_bf16_dma_kernel(const TecmGemm g
         if (s < 3 && m < MT + NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // 1 DS read
       }
     });
+#ifndef DMA_ABLATE_NOBARRIER                             // diagnostics: no barrier per K-tile (racy: timing only)
     __syncthreads();                                    // DMA of tile t+1 retired, every wave done with tile t
+#endif
     cur ^= 1;
   }
 

@@ -33,7 +33,6 @@
 // ds_read_b32 per operand from the natural image (no transposition needed: a lane holds one element).  There the kernel
 // is bound by the matrix cores, and what it saves over the split-K window GEMMs is their re-staging of both operands.
 #include "common.h"
-#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -42,6 +41,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace tecm_convdw {
 
+#ifndef CDW_ABLATE
+#define CDW_ABLATE 0         // diagnostics (tools/build_variant.py -DCDW_ABLATE=n): bit0 no HBM loads, bit1 no LDS stores, bit2 no K loop
+#endif
 constexpr int NTH = 512;     // 8 waves = 4 (channel block pair | k range) x 2 tap groups; 8 accumulator tiles each
 constexpr int NB = 4;        // nodes per tile = rows of one transposed-read block
 constexpr int HALO = 3;      // zero time steps in front of / behind the inp image (k = 7)
@@ -53,7 +55,6 @@ struct Args {
   const void* dy;            // bf16 (B, Lc, N, 3 * Cout)
   float* ws;                 // slabs [flavor][(gridDim.x / F) * KS][15][32 * NCIB][32 * CPB]
   int B, Lc, N, ntiles, nblk, TC, nchunk;
-  int ablate;                // diagnostics (TECM_CONV_DW_ABLATE): bit0 no HBM loads, bit1 no LDS stores, bit2 no K loop
 };
 
 template <int LD_IN, int COUT, bool F32>
@@ -292,16 +293,16 @@ __global__ __launch_bounds__(NTH) void conv_dw_seq_kernel(const Args a) {
     for (int s = 0; s < PD; ++s) {
       if (tile < a.ntiles) {                                 // block-uniform
         // outstanding, oldest first: this tile's loads, then those of the PD - 1 tiles requested after it (if they exist)
-        if (PD == 2 && tile + nbf < a.ntiles && !(a.ablate & 1)) wait_loads<G::SBX + G::SBY>();
+        if (PD == 2 && tile + nbf < a.ntiles && !(CDW_ABLATE & 1)) wait_loads<G::SBX + G::SBY>();
         else wait_loads<0>();
 #pragma unroll
         for (int q = 0; q < G::SBX; ++q) land(vx[s][q]);
 #pragma unroll
         for (int q = 0; q < G::SBY; ++q) land(vy[s][q]);
-        if (!(a.ablate & 2)) stage_store(tile, vx[s], vy[s]);
+        if (!(CDW_ABLATE & 2)) stage_store(tile, vx[s], vy[s]);
         __syncthreads();
-        if (tile + PD * nbf < a.ntiles && !(a.ablate & 1)) stage_load(tile + PD * nbf, vx[s], vy[s]);
-        if (!(a.ablate & 4)) compute(min(a.TC, a.Lc - ((tile / a.nblk) % a.nchunk) * a.TC));
+        if (tile + PD * nbf < a.ntiles && !(CDW_ABLATE & 1)) stage_load(tile + PD * nbf, vx[s], vy[s]);
+        if (!(CDW_ABLATE & 4)) compute(min(a.TC, a.Lc - ((tile / a.nblk) % a.nchunk) * a.TC));
         __syncthreads();                                     // every wave is done with the image
       }
       tile += nbf;
@@ -367,10 +368,6 @@ int launch(const TecmConvDw* p, hipStream_t st) {
   Args a;
   a.x = p->inp; a.dy = p->dy; a.ws = p->workspace;
   a.B = p->B; a.Lc = p->Lc; a.N = p->N;
-  {
-    static const int ablate = getenv("TECM_CONV_DW_ABLATE") ? atoi(getenv("TECM_CONV_DW_ABLATE")) : 0;
-    a.ablate = ablate;
-  }
   a.nblk = (p->N + NB - 1) / NB;
   a.TC = p->Lc < TCMAX ? p->Lc : TCMAX;
   a.nchunk = (p->Lc + a.TC - 1) / a.TC;

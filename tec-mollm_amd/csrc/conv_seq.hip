@@ -27,6 +27,7 @@
 // Arithmetic = the bf16 mode's: operands rounded to bf16 (dy by its producer, the weights by the pack kernel, RNE), fp32
 // accumulation; the summation order differs from the GEMM path's (four k ranges), the rounding points do not.
 #include "common.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -490,22 +491,43 @@ __global__ __launch_bounds__(NTH, 2) void conv_fwd_seq_kernel(const FArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
     const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.wpack) + (int64_t)woff * 64 + lane;
-    bf16x8 wf = wp[0];
-    for (int s = 0; s < nsteps; ++s) {
-      bf16x8 wn = wf;
-      if (s + 1 < nsteps) wn = wp[(s + 1) * 64];
-      const int q = 2 * s + h;
-      const int tap = (int)((q * cpt_magic) >> 16), c8 = q - tap * cpt;
-      // data row r of row tile i at this tap: image row (8 i + tap - pad + 3) * 4 + r
-      const int off0 = ((tap - pad + 3) * 4 + r) * a.pitch + c8 * 16;
+    // Operands of step s+1 (weights from L2, data rows from LDS) are requested while step s multiplies.  Every load is
+    // UNCONDITIONAL on a clamped index: a wave-uniform `if` around a load is a branch, and the compiler waits for the
+    // load inside it (vmcnt(0) / lgkmcnt(0) per load: the first version exposed the L2 latency of the weights at every
+    // k-step and the LDS latency in front of every MFMA).
+    // (the row-tile count is dispatched to a compile-time constant: a run-time `if (i < ntt)` around each MFMA puts every
+    // one of them into its own basic block)
+    auto kloop = [&](auto ntc) {
+      constexpr int NTT = decltype(ntc)::value;
+      auto rd = [&](int s, bf16x8 (&df)[NTT]) {
+        const int q = 2 * s + h;
+        const int tap = (int)((q * cpt_magic) >> 16), c8 = q - tap * cpt;
+        // data row r of row tile i at this tap: image row (8 i + tap - pad + 3) * 4 + r
+        const int off0 = ((tap - pad + 3) * 4 + r) * a.pitch + c8 * 16;
 #pragma unroll
-      for (int i = 0; i < MAXT; ++i) {
-        if (i < ntt) {
-          const bf16x8 df = *reinterpret_cast<const bf16x8*>(lds + off0 + 32 * i * a.pitch);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, wf, acc[i], 0, 0, 0);
-        }
+        for (int i = 0; i < NTT; ++i) df[i] = *reinterpret_cast<const bf16x8*>(lds + off0 + 32 * i * a.pitch);
+      };
+      bf16x8 wf = wp[0], df[NTT];
+      rd(0, df);
+      for (int s = 0; s < nsteps; ++s) {
+        const int sn = min(s + 1, nsteps - 1);
+        const bf16x8 wn = wp[sn * 64];
+        bf16x8 dn[NTT];
+        rd(sn, dn);
+#pragma unroll
+        for (int i = 0; i < NTT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df[i], wf, acc[i], 0, 0, 0);
+        wf = wn;
+#pragma unroll
+        for (int i = 0; i < NTT; ++i) df[i] = dn[i];
       }
-      wf = wn;
+    };
+    switch (ntt) {
+      case 1: kloop(std::integral_constant<int, 1>{}); break;
+      case 2: kloop(std::integral_constant<int, 2>{}); break;
+      case 3: kloop(std::integral_constant<int, 3>{}); break;
+      case 4: kloop(std::integral_constant<int, 4>{}); break;
+      case 5: kloop(std::integral_constant<int, 5>{}); break;
+      default: kloop(std::integral_constant<int, MAXT>{}); break;
     }
     // ---- this unit's 32 channels of every row of the tile: accumulator register e of lane (co, h) is data row
     //      (e & 3) + 8 (e >> 2) + 4 h of its row tile, i.e. time step 8 i + 2 (e >> 2) + h, node e & 3
@@ -575,22 +597,41 @@ __global__ __launch_bounds__(NTH, 2) void conv_fwd_seq_f32_kernel(const FArgs a)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
     const f32x4* wp = reinterpret_cast<const f32x4*>(a.wpack) + (int64_t)woff * 64 + lane;
-    f32x4 wf = wp[0];
-    for (int s = 0; s < nsteps; ++s) {
-      f32x4 wn = wf;
-      if (s + 1 < nsteps) wn = wp[(s + 1) * 64];
-      const int q = 2 * s + h;
-      const int tap = (int)((q * cpt_magic) >> 16), c4 = q - tap * cpt;
-      const int off0 = ((tap - pad + 3) * 4 + r) * a.pitch + c4 * 16;
+    // as the bf16 kernel: unconditional clamped loads one step ahead; the four MFMAs a float4 feeds go to the SAME
+    // accumulator, so they are issued tile-interleaved (jj outer, row tile inner) -- back-to-back they would each wait for
+    // the previous one's result
+    auto kloop = [&](auto ntc) {
+      constexpr int NTT = decltype(ntc)::value;
+      auto rd = [&](int s, f32x4 (&df)[NTT]) {
+        const int q = 2 * s + h;
+        const int tap = (int)((q * cpt_magic) >> 16), c4 = q - tap * cpt;
+        const int off0 = ((tap - pad + 3) * 4 + r) * a.pitch + c4 * 16;
 #pragma unroll
-      for (int i = 0; i < MAXT; ++i) {
-        if (i < ntt) {
-          const f32x4 df = *reinterpret_cast<const f32x4*>(lds + off0 + 32 * i * a.pitch);
+        for (int i = 0; i < NTT; ++i) df[i] = *reinterpret_cast<const f32x4*>(lds + off0 + 32 * i * a.pitch);
+      };
+      f32x4 wf = wp[0], df[NTT];
+      rd(0, df);
+      for (int s = 0; s < nsteps; ++s) {
+        const int sn = min(s + 1, nsteps - 1);
+        const f32x4 wn = wp[sn * 64];
+        f32x4 dn[NTT];
+        rd(sn, dn);
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(df[jj], wf[jj], acc[i], 0, 0, 0);
-        }
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+          for (int i = 0; i < NTT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(df[i][jj], wf[jj], acc[i], 0, 0, 0);
+        wf = wn;
+#pragma unroll
+        for (int i = 0; i < NTT; ++i) df[i] = dn[i];
       }
-      wf = wn;
+    };
+    switch (ntt) {
+      case 1: kloop(std::integral_constant<int, 1>{}); break;
+      case 2: kloop(std::integral_constant<int, 2>{}); break;
+      case 3: kloop(std::integral_constant<int, 3>{}); break;
+      case 4: kloop(std::integral_constant<int, 4>{}); break;
+      case 5: kloop(std::integral_constant<int, 5>{}); break;
+      default: kloop(std::integral_constant<int, MAXT>{}); break;
     }
     const float bv = a.bias[col0 + r];
     float* yb = a.y + (((int64_t)b * a.Lc + t0 + h) * a.N + n0) * CT + col0 + r;

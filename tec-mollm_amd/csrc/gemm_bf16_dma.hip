@@ -675,6 +675,179 @@ __global__ __launch_bounds__(D3TH, 1) void gemm_bf16_dma4_kernel(const TecmGemm 
   block_epilogue16<MT, NT, WTM, WTN, true>(g, acc, smem_raw, wave, lane, wm, wn, m0, n0);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Fifth geometry (round 3): the four-slot ring with v_mfma_f32_16x16x32_bf16.  A bare register-only loop of that shape
+// sustains 2.08 PFLOP/s on random operands against 1.87 for 32x32x16 (tools/micro/mfma_bf16_shapes.hip: the chip's power
+// management sets the ceiling, and the 16x16 shape holds a higher clock), and it is the one variable the other four
+// geometries share.  Wave tile 128 x 64 = 8 x 4 tiles of 16 x 16 (128 accumulator registers, as before); a fragment is
+// ONE ds_read_b128 of 16 rows x 64 B: lane l reads row l & 15, 16-byte chunk l >> 4, which is exactly the operand map
+// (A[row l&15][k = 8 (l>>4) + j]).  With 64-byte rows the four lane groups of a ds_read_b128 cover all 64 banks once
+// when chunk c of row r sits at position c ^ (3 * ((r >> 3) & 1)).  Per K-tile (32 deep): 12 fragment reads, 32 MFMAs,
+// in two halves (accumulator rows 0-3 / 4-7) with the publishing barrier between them as in the third geometry.
+// The summation order inside an MFMA differs from the 32x32x16 kernels': results agree to fp32 rounding, not bit for bit.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(D3TH, 1) void gemm_bf16_dma5_kernel(const TecmGemm g, int tiles_m, int tiles_n) {
+  constexpr int WM = 2, WN = 4;
+  constexpr int WTM = D3M / WM, WTN = D3N / WN;        // 128 x 64 per wave
+  constexpr int MT = WTM / 16, NT = WTN / 16;          // 8 x 4 tiles of 16 x 16
+  constexpr int A_ELEMS = D3M * D3K, B_ELEMS = D3N * D3K, TILE_ELEMS = A_ELEMS + B_ELEMS;   // 32 KiB
+  constexpr int PIECE = 16 * D3K;                      // 16 rows of 64 B = 1 KiB
+  __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[D3ST * TILE_ELEMS * 2];
+  __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);
+  static_assert(D3ST * TILE_ELEMS * 2 >= 8 * 32 * (WTN + 4) * 4, "epilogue slabs fit in the operand ring");
+
+  const int nwg = tiles_m * tiles_n;
+  const int id = blockIdx.x;
+  const int xcd = id & 7, local = id >> 3;
+  const int q8 = nwg >> 3, r8 = nwg & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
+  const int GROUP_M = g._p1 > 0 ? g._p1 : 4;
+  const int per_group = GROUP_M * tiles_n;
+  const int group = wg / per_group;
+  const int first_m = group * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int in_group = wg - group * per_group;
+  const int tm = first_m + in_group % gsz, tn = in_group / gsz;
+  const int64_t m0 = (int64_t)tm * D3M;
+  const int64_t n0 = (int64_t)tn * D3N;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int ntiles = (int)g.K / D3K;                   // K % 32 == 0 (host)
+
+  const __bf16* Ah = reinterpret_cast<const __bf16*>(g.A);
+  const __bf16* Bh = reinterpret_cast<const __bf16*>(g.B);
+  const __bf16* src[4];
+  int dst[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = wave + 8 * i;                        // pieces 0..15 = A rows 16p.., 16..31 = B rows
+    const bool isb = p >= 16;
+    const int row = (isb ? p - 16 : p) * 16 + (lane >> 2);
+    const int chunk = (lane & 3) ^ (3 * ((row >> 3) & 1));
+    if (!isb) {
+      int64_t gm = m0 + row;
+      gm = gm < g.M ? gm : g.M - 1;
+      src[i] = Ah + gm * g.lda + chunk * 8;
+      dst[i] = p * PIECE;
+    } else {
+      int64_t gn = n0 + row;
+      gn = gn < g.N ? gn : g.N - 1;
+      src[i] = Bh + gn * g.ldb + chunk * 8;
+      dst[i] = A_ELEMS + (p - 16) * PIECE;
+    }
+  }
+  auto issue_tile = [&](int slot) {
+    __bf16* buf = smem + slot * TILE_ELEMS;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      dma16(src[i], buf + dst[i]);
+      src[i] += D3K;
+    }
+  };
+
+  f32x4v acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+  // fragment addresses: row = tile row 16 i + (lane & 15), chunk lane >> 4 at its swizzled position
+  const int fr = lane & 15, fq = lane >> 4;
+  int a_off[MT], b_off[NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int row = wm * WTM + i * 16 + fr;
+    a_off[i] = row * D3K + ((fq ^ (3 * ((row >> 3) & 1))) << 3);
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int row = wn * WTN + j * 16 + fr;
+    b_off[j] = A_ELEMS + row * D3K + ((fq ^ (3 * ((row >> 3) & 1))) << 3);
+  }
+  auto mfma_half = [&](const bf16x8 (&af)[4], const bf16x8 (&bf)[NT], int i0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        if (i0 == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        else acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[4 + i][j], 0, 0, 0);
+      }
+  };
+
+  issue_tile(0);
+  if (ntiles > 1) issue_tile(1);
+  if (ntiles > 2) issue_tile(2);
+  if (ntiles > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (ntiles > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  bf16x8 fa[2][4], fb[2][NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) fb[0][j] = *reinterpret_cast<const bf16x8*>(smem + b_off[j]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) fa[0][i] = *reinterpret_cast<const bf16x8*>(smem + a_off[i]);
+  int slot = 0;
+  // two K-tiles per iteration so that the B-fragment buffers alternate with compile-time indices
+  auto ktile = [&](int t, auto parity) {
+    constexpr int P = decltype(parity)::value;
+    const __bf16* Tc = smem + slot * TILE_ELEMS;
+    const int nslot = (slot + 1) & 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[1][i] = *reinterpret_cast<const bf16x8*>(Tc + a_off[4 + i]);
+    mfma_half(fa[0], fb[P], 0);
+    if (t + 1 < ntiles) {
+      if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (t + 3 < ntiles) issue_tile((slot + 3) & 3);  // the slot of tile t-1
+      const __bf16* Tn = smem + nslot * TILE_ELEMS;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) fb[P ^ 1][j] = *reinterpret_cast<const bf16x8*>(Tn + b_off[j]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[0][i] = *reinterpret_cast<const bf16x8*>(Tn + a_off[i]);
+    }
+    mfma_half(fa[1], fb[P], 4);
+    slot = nslot;
+  };
+  for (int t = 0; t < ntiles; t += 2) {
+    ktile(t, std::integral_constant<int, 0>{});
+    if (t + 1 < ntiles) ktile(t + 1, std::integral_constant<int, 1>{});
+  }
+  __syncthreads();                                      // every wave has left the last K-tile: the ring becomes staging
+
+  // ---- epilogue: gemm_impl.h's straight-line form over this wave's private staging rows; only the parking of the
+  // accumulators knows the 16x16 C/D map (row = 4 (lane >> 4) + reg, col = lane & 15)
+  constexpr int STG_LD = WTN + 4;
+  const DropCtx odc = make_drop(g.out_drop);
+  float* stg = reinterpret_cast<float*>(smem_raw) + wave * (32 * STG_LD);
+  auto stage_slab = [&](auto ic) {                     // 32 accumulator rows = tile rows 2 i, 2 i + 1
+    constexpr int i = decltype(ic)::value;
+    static_for<2>([&](auto tc) {
+      constexpr int ti = decltype(tc)::value;
+      static_for<NT>([&](auto jc) {
+        constexpr int jn = decltype(jc)::value;
+        static_for<4>([&](auto ec) {
+          constexpr int e = decltype(ec)::value;
+          stg[(16 * ti + 4 * fq + e) * STG_LD + jn * 16 + fr] = acc[2 * i + ti][jn][e];
+        });
+      });
+    });
+  };
+  const int fmode = tecm_gemm::epi_fast_mode(g);         // >= 0: checked on the host (tecm_gemm16_dma_try)
+  constexpr int LPR = WTN / 4, RPI = 64 / LPR;
+  const int lcol = (lane % LPR) * 4, lrow = lane / LPR;
+  const EpiCol ecol = epi_col(g, n0 + wn * WTN + lcol);
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (g.bias && ecol.ok) bias4 = *reinterpret_cast<const float4*>(g.bias + ecol.n);
+  tecm_gemm::epi_fast_dispatch<WTM / 32, 32 / RPI, RPI, STG_LD, true>(fmode, g, odc, stg, lrow, lcol, m0 + wm * WTM, ecol, bias4,
+                                                                  stage_slab);
+}
+
 }  // namespace tecm_gemm16
 
 // Returns the number of K splits (1) when the DMA kernel served the call, 0 when the call is not eligible.
@@ -701,6 +874,20 @@ int tecm_gemm16_dma_try(const TecmGemm& g, hipStream_t st) {
   // Per shape the anti-phase ring measured K = 800: 418 -> 352 us, K = 3072 + residual epilogue: 517 -> 481, N = 3072
   // K = 768: 659 -> 688, 8192^3: 1081 vs 1085 TFLOP/s -- and 396.5 vs 395.9 samples/s in the step, i.e. nothing: it is
   // not dispatched by default.
+  // the 16x16x32 ring wherever its straight-line epilogue serves the call: per shape (M = 69 864, tools/dma_ab.sh) K = 800
+  // 397 -> 348 us (no zero-filled half K-tile), K = 3072 456 -> 412 us plain and a tie with the residual epilogue, N = 3072
+  // K = 768 a tie, K = 768 N = 768 0..-5 %; in the step 392.1 samples/s against 389.0 with it on K = 800 / K >= 2048 only and
+  // 386.8 without (one box).  TECM_BF16_DMA = 5 forces it (also for N = 800), 1 forbids it.
+  {
+    const int streams = (g.residual ? 1 : 0) + (g.dact_src ? 1 : 0) + (g.accumulate ? 1 : 0);
+    const bool can16 = !g.c_win.enabled && !g.rowbias && streams <= 1;     // the straight-line epilogues only
+    const bool want16 = sel ? sel[0] == '5' : true;
+    if (can16 && want16) {
+      hipLaunchKernelGGL(gemm_bf16_dma5_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(D3TH), 0, st, g, tiles_m, tiles_n);
+      TECM_CHECK_LAUNCH("tecm_gemm_bf16/dma5");
+      return 1;
+    }
+  }
   const bool ring = sel && sel[0] == '4';
   if (ring) {
     hipLaunchKernelGGL(gemm_bf16_dma4_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(D3TH), 0, st, g, tiles_m, tiles_n);

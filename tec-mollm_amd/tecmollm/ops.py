@@ -199,6 +199,11 @@ def _kernel_name(g: TecmGemm, use16: bool = False) -> str:
             if narrow:
                 return "gemm_bf16_dma2_kernel"
             ring = sel == "4"                                                 # the four-slot ring, anti-phase wave groups (A/B)
+            can16 = not g.c_win.enabled and not g.rowbias and \
+                (1 if g.residual else 0) + (1 if g.dact_src else 0) + (1 if g.accumulate else 0) <= 1
+            want16 = sel == "5" if sel else True                              # the ring with 16x16x32 MFMAs
+            if can16 and want16:
+                return "gemm_bf16_dma5_kernel"
             return "gemm_bf16_dma4_kernel" if ring else ("gemm_bf16_dma3_kernel" if sel == "3" else "gemm_bf16_dma_kernel")
         return f"gemm_bf16_kernel<{g.a_layout},{g.b_layout},{win16},{drp16}>"
     av = _vec(g.A, g.lda, g.a_win, g.a_layout == A_MK, g.K)

@@ -209,6 +209,36 @@ def test_bf16_preactivation_is_rounded_before_the_activation(dev, M, N, K):
         ops.gemm(M, N, K, A16.float(), K, B16.float(), K, c, N, act=ops.ACT_GELU_TANH, preact=(pre16, N))
 
 
+@pytest.mark.parametrize("geometry", ["5"], ids=["ring"])
+@pytest.mark.parametrize("M,N,K", [(257, 800, 2304), (1031, 2304, 800), (4099, 768, 3072), (513, 3072, 768), (300, 256, 64)])
+def test_bf16_dma_16x16x32_geometry_agrees_to_fp32_rounding(dev, M, N, K, geometry, monkeypatch):
+    """gemm_bf16_dma5_kernel (v_mfma_f32_16x16x32_bf16 on the four-slot ring; TECM_BF16_DMA=5, diagnostics): another
+    summation order inside the MFMA, so not bit-identical -- fp32 outputs agree with the two-slot kernel to 2e-6 of the
+    largest value, bf16 outputs to one ulp; ragged tiles, the GELU + pre-activation, residual + dropout and GELU' forms."""
+    from tecmollm import ops
+    A16, B16 = _rand(M, K, dev=dev, seed=1).bfloat16(), _rand(N, K, dev=dev, seed=2, scale=0.05).bfloat16()
+    bias, res, pre_src = _rand(N, dev=dev, seed=4), _rand(M, N, dev=dev, seed=5), _rand(M, N, dev=dev, seed=6)
+
+    def run():
+        c16, pre = torch.empty(M, N, device=dev, dtype=torch.bfloat16), torch.full((M, N), float("nan"), device=dev)
+        ops.gemm(M, N, K, A16, K, B16, K, c16, N, bias=bias, act=ops.ACT_GELU_TANH, preact=(pre, N), bf16=True)
+        c = torch.full((M, N), float("nan"), device=dev)
+        ops.gemm(M, N, K, A16, K, B16, K, c, N, bias=bias, out_drop=ops.drop(0.1, 77, N), residual=(res, N), bf16=True)
+        d = torch.full((M, N), float("nan"), device=dev)
+        ops.gemm(M, N, K, A16, K, B16, K, d, N, act=ops.ACT_GELU_TANH, dact_src=(pre_src, N), bf16=True)
+        torch.cuda.synchronize()
+        return c16, pre, c, d
+
+    monkeypatch.setenv("TECM_BF16_DMA", "1")
+    want = run()
+    monkeypatch.setenv("TECM_BF16_DMA", geometry)
+    got = run()
+    for g_, w_ in zip(got[1:], want[1:]):
+        assert torch.isfinite(g_).all() and _rel(g_, w_) < 2e-6
+    diff = (got[0].float() - want[0].float()).abs()
+    assert bool((diff <= want[0].float().abs() * 2.0 ** -7 + 1e-6).all())
+
+
 def test_bf16_dma_ring_kernel_is_race_free_over_repeated_full_size_launches(dev, monkeypatch):
     """The four-slot ring with anti-phase wave groups (gemm_bf16_dma4_kernel) synchronises by counted vmcnt + raw barriers:
     a misplaced wait would show as rare wrong tiles that come and go with load.  Twelve back-to-back launches of the

@@ -260,6 +260,18 @@ def test_bf16_dma_ring_kernel_is_race_free_over_repeated_full_size_launches(dev,
         torch.cuda.synchronize()
         for o in outs:
             assert torch.equal(o, want)
+        # the dispatched 16x16x32 ring (another summation order inside the MFMA): every launch the same bits, and those
+        # within fp32 rounding of the two-slot kernel's
+        monkeypatch.delenv("TECM_BF16_DMA")
+        rec = ops.enable_gemm_timing()
+        for o in outs:
+            ops.gemm(M, N, K, A16, K, B16, K, o, N, bias=bias, bf16=True)
+        torch.cuda.synchronize()
+        assert all("dma5" in name for name in ops.summarize_gemm_timing(rec))
+        ops.disable_gemm_timing()
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0])
+        assert _rel(outs[0], want) < 2e-6
 
 
 @pytest.mark.parametrize("Bn,L,N,Cin,Cout,k", [(2, 48, 5, 24, 64, 3), (2, 24, 7, 64, 128, 7), (1, 48, 300, 24, 64, 5)])

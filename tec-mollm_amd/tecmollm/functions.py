@@ -292,7 +292,7 @@ class ConvBlockFn(torch.autograd.Function):
         # bf16 mode: the activations behind the norm and (backward) dy live in HBM as bf16 -- they are only ever read by
         # bf16 contractions, which would round them in their loaders (same bits, half the bytes).  The conv output y
         # stays fp32 (the norm kernels got slower, not faster, reading 8-byte quads).
-        r16 = int(bf16) == ops.PREC_BF16 and Cout >= 64
+        r16 = int(bf16) == ops.PREC_BF16 and Cout >= 64 and ops.gn_reg_ok(Lc, N, Cout)
         adt = torch.bfloat16 if r16 else torch.float32
         side16 = r16
         y = _empty(B, Lc, N, CT, like=inp)

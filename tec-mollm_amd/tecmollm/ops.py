@@ -308,6 +308,17 @@ def layernorm_bwd(dy: torch.Tensor, lddy: int, x: torch.Tensor, ldx: int, gamma:
 GN_OUT_BF16 = 2
 
 
+def gn_reg_ok(L: int, N: int, Cout: int) -> bool:
+    """True when the register-resident GroupNorm+GELU kernels (csrc/norm.hip: gn_reg_pairs with 4 or 8 waves per sequence,
+    at most 9 float4 per lane) serve BOTH directions -- the only kernels that read / write bf16 activations.  Longer
+    sequences (the reference's default L_in = 336) take the multi-pass fp32 kernels, and the conv block then keeps its
+    activations fp32 in bf16 mode too."""
+    quads = L * (3 * Cout // 4)
+    if L * N * 3 * Cout >= 1 << 31:
+        return False
+    return any(quads % (64 * wps) == 0 and quads // (64 * wps) <= 9 for wps in (4, 8))
+
+
 def _gn_io(y: torch.Tensor, out: torch.Tensor) -> int:
     if y.dtype != torch.float32:
         raise _lib.TecmError("groupnorm_gelu: y is fp32 (only act / dy may be bf16)")

@@ -337,6 +337,29 @@ def test_attention_dropout_mask_is_consistent(dev):
     assert _rel(dqkv, g) < TOL
 
 
+@pytest.mark.parametrize("L,Cout", [(48, 64), (24, 128), (96, 64), (336, 64), (168, 128), (100, 64), (12, 256)])
+def test_gn_reg_ok_mirrors_the_library(dev, L, Cout):
+    """ops.gn_reg_ok (what decides whether a conv block keeps bf16 activations) against the library itself: bf16 act / dy
+    are accepted exactly where it says so, and refused loudly elsewhere."""
+    from tecmollm import ops
+    Bn, N, CT = 1, 3, 3 * Cout
+    y = _rand(Bn, L, N, CT, dev=dev, seed=1)
+    g, b = 1 + 0.1 * _rand(CT, dev=dev, seed=2), 0.1 * _rand(CT, dev=dev, seed=3)
+    act16 = torch.empty(Bn, L, N, CT, device=dev, dtype=torch.bfloat16)
+    st = torch.empty(Bn * N, 3, 2, device=dev)
+    dact = _rand(Bn, (L + 1) // 2, N, CT, dev=dev, seed=4)
+    dy16 = torch.empty_like(act16)
+    if ops.gn_reg_ok(L, N, Cout):
+        ops.groupnorm_gelu_fwd(y, g, b, act16, st, Bn, L, N, Cout)
+        ops.groupnorm_gelu_bwd(dact, 2, y, g, b, st, dy16, Bn, L, N, Cout)
+        torch.cuda.synchronize()
+        assert torch.isfinite(act16.float()).all() and torch.isfinite(dy16.float()).all()
+    else:
+        with pytest.raises(Exception):
+            ops.groupnorm_gelu_fwd(y, g, b, act16, st, Bn, L, N, Cout)
+            ops.groupnorm_gelu_bwd(dact, 2, y, g, b, st, dy16, Bn, L, N, Cout)
+
+
 # ----------------------------------------------------------------------------- small ops
 def test_huber_and_transpose(dev):
     from tecmollm import ops

@@ -32,6 +32,9 @@
 // The SAME kernel in exact fp32 (template F32, BASELINE configs[1]): fp32 inp and dy, v_mfma_f32_32x32x2_f32 fed by one
 // ds_read_b32 per operand from the natural image (no transposition needed: a lane holds one element).  There the kernel
 // is bound by the matrix cores, and what it saves over the split-K window GEMMs is their re-staging of both operands.
+// Measured (B = 8, N = 2911, round 3, in the step): bf16 block 1 (Lc 48, ld_in 24, Cout 64) 540 -> 120 us (5.1 TB/s of the
+// two operands), block 2 (Lc 24, 64, 128) 600 -> 170 us (3.7 TB/s) + 17 us of reduction each; fp32 870 -> 620 us and
+// 1450 -> 1150 us (92 / 119 TFLOP/s of MFMA issued; the K loop alone 0.82 of the f32 matrix peak).  DESIGN.md Appendix B.8.
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

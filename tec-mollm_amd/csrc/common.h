@@ -67,10 +67,13 @@ __device__ __forceinline__ float dgelu_erf(float x) {
 // erf-GELU and its derivative from ONE exponential: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far
 // inside the 1e-3 parity bar) whose e^{-z^2}, z = x/sqrt(2), is also the Gaussian pdf of the derivative.  A dozen
 // instructions instead of erff's two-branch polynomial: for kernels that unroll the activation many times.
+// (v_rcp_f32 / v_exp_f32 directly: `__frcp_rn` and `__fdividef` compile to the 11-instruction IEEE division sequence on this
+// toolchain, which made the activation half of the GroupNorm kernels' instruction count and cost the c_fc GEMM 160 us of
+// epilogue per launch; the hardware reciprocal is good to 1 ulp)
 __device__ __forceinline__ void gelu_erf_parts(float x, float& cdf, float& e) {
   const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __frcp_rn(1.0f + 0.3275911f * z);
-  e = __expf(-0.5f * x * x);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+  e = __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);            // e^{-x^2/2}
   const float poly =
       t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
   cdf = 0.5f * (1.0f + copysignf(1.0f - poly * e, x));
@@ -87,19 +90,32 @@ __device__ __forceinline__ float dgelu_erf_fast(float x) {
 }
 // tanh(u) = 1 - 2/(1 + e^{2u}) on the hardware exp/rcp units (abs error ~1e-7 .. 1e-6, saturates cleanly)
 __device__ __forceinline__ float fast_tanh(float u) {
-  const float e = __expf(2.0f * u);
-  return 1.0f - __fdividef(2.0f, 1.0f + e);
+  const float e = __builtin_amdgcn_exp2f(2.88539008177792681472f * u);
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
+}
+// tanh-GELU (transformers "gelu_new", the GPT-2 MLP) in its sigmoid form: with u = sqrt(2/pi) (x + 0.044715 x^3),
+//   0.5 x (1 + tanh u) = x s,   s = E / (1 + E),  E = e^{2u};      1 - s = 1 / (1 + E) = r
+//   d/dx = s + x s r (2 du/dx),                                     2 du/dx = 2 sqrt(2/pi) (1 + 3 * 0.044715 x^2)
+// E = 2^a is clamped at 2^100 so that s = E * r is 1 (not inf * 0) for large x and exactly x * 0 for very negative x;
+// s = E * r has no cancellation on either side.  7 / 12 instructions (two of them transcendental) against 23 / 26.
+__device__ __forceinline__ void gelu_tanh_parts(float x, float x2, float& s, float& r) {
+  float a = x * fmaf(x2, 0.10294324f, 2.3022082f);     // 2 u log2(e): 2 * 0.7978845608 * 1.4426950409 * (1 + 0.044715 x^2)
+  a = fminf(a, 100.0f);
+  const float E = __builtin_amdgcn_exp2f(a);
+  r = __builtin_amdgcn_rcpf(1.0f + E);
+  s = E * r;
 }
 __device__ __forceinline__ float gelu_tanh(float x) {
-  const float u = 0.79788456080286535588f * (x + 0.044715f * x * x * x);
-  return 0.5f * x * (1.0f + fast_tanh(u));
+  float s, r;
+  gelu_tanh_parts(x, x * x, s, r);
+  return x * s;
 }
 __device__ __forceinline__ float dgelu_tanh(float x) {
   const float x2 = x * x;
-  const float u = 0.79788456080286535588f * (x + 0.044715f * x * x2);
-  const float t = fast_tanh(u);
-  const float du = 0.79788456080286535588f * (1.0f + 3.0f * 0.044715f * x2);
-  return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * du;
+  float s, r;
+  gelu_tanh_parts(x, x2, s, r);
+  const float du2 = fmaf(x2, 0.21406445f, 1.5957691f);  // 2 sqrt(2/pi) (1 + 0.134145 x^2)
+  return fmaf(x * du2 * r, s, s);
 }
 __device__ __forceinline__ float apply_act(int act, float v) {
   return act == TECM_ACT_GELU_ERF ? gelu_erf(v) : (act == TECM_ACT_GELU_TANH ? gelu_tanh(v) : v);

@@ -33,7 +33,7 @@ extern "C" {
 #define TECM_E_LAUNCH (-3)     /* hipGetLastError() != hipSuccess after the launch       */
 #define TECM_E_LDS (-4)        /* problem does not fit the 160 KiB LDS budget            */
 
-#define TECM_ABI_VERSION 14
+#define TECM_ABI_VERSION 15
 int tecm_abi_version(void);
 /* Human-readable text for the last error on this thread (host pointer, never NULL). */
 const char* tecm_last_error(void);
@@ -300,6 +300,11 @@ int tecm_conv_fwd_f32(const TecmConvFwd* p, void* stream);
 int tecm_conv_dx_pack_f32(const float* w3, const float* w5, const float* w7, float* wpack, int32_t Cout, int32_t Cin,
                           int32_t ld_in, void* stream);
 int tecm_conv_dx_f32(const TecmConvDx* p, void* stream);
+/* 1 when tecm_conv_fwd_{bf16,f32} / tecm_conv_dx_{bf16,f32} serve the shape -- divisibility AND the LDS bytes of one
+ * sequence tile (64 KiB forward, 160 KiB d-input) -- else 0.  Pure host arithmetic, nothing is launched.  Callers route
+ * the shapes these kernels refuse to the window-view GEMMs (tecm_gemm_*) instead of failing with TECM_E_LDS. */
+int tecm_conv_fwd_supported(int32_t Lc, int32_t Cout, int32_t ld_in, int32_t f32);
+int tecm_conv_dx_supported(int32_t Lc, int32_t Cout, int32_t ld_in, int32_t f32);
 
 /* Weight gradient of the same three Conv1d in ONE launch pair, bf16 mode (replaces the three split-K window GEMMs
  * dY^T . window(inp) behind nn.Conv1d's autograd, modules.py:27,36):

@@ -382,12 +382,10 @@ int launch(const TecmConvDw* p, hipStream_t st) {
   int nbf = p->num_blocks / G::F;                           // blocks per flavor
   if (nbf > tiles) nbf = (int)tiles;
   TECM_REQUIRE(nbf >= 1, TECM_E_ARG, "tecm_conv_dw_bf16: num_blocks must be at least %d", G::F);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dw_seq_kernel<LD_IN, COUT, PD, F32>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  // per launch, not once per process: the attribute belongs to the function ON THE CURRENT DEVICE (see conv_seq.hip)
+  TECM_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dw_seq_kernel<LD_IN, COUT, PD, F32>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
+               TECM_E_LAUNCH, "tecm_conv_dw: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
   hipLaunchKernelGGL((conv_dw_seq_kernel<LD_IN, COUT, PD, F32>), dim3(nbf * G::F), dim3(NTH), lds, st, a);
   TECM_CHECK_LAUNCH("tecm_conv_dw/seq");
   hipLaunchKernelGGL(conv_dw_reduce_kernel, dim3((unsigned)(NTAP * p->Cin * (COUT / 64))), dim3(256), 0, st, p->workspace,

@@ -718,6 +718,24 @@ extern "C" int tecm_conv_fwd_pack(const float* w3, const float* w5, const float*
   return TECM_OK;
 }
 
+// LDS bytes of one forward tile: (TC + 7 halo steps) x NB nodes x an odd number of 16-byte slots per row
+static size_t conv_fwd_lds(int Lc, int ld_in, bool f32, int* pitch_out, int* tc_out) {
+  using namespace tecm_convseq;
+  int slots = ld_in * (f32 ? 4 : 2) / 16;                               // row pitch in 16-byte slots, odd: conflict-free ds_read_b128
+  if (slots % 2 == 0) ++slots;
+  const int pitch = slots * 16;
+  const int TC = 8 * MAXT < Lc ? 8 * MAXT : Lc;
+  if (pitch_out) *pitch_out = pitch;
+  if (tc_out) *tc_out = TC;
+  return (size_t)(TC + 7) * NB * pitch;
+}
+
+// 1 when tecm_conv_fwd_{bf16,f32} serves the shape (callers fall back to the window-view GEMMs otherwise), else 0
+extern "C" int tecm_conv_fwd_supported(int32_t Lc, int32_t Cout, int32_t ld_in, int32_t f32) {
+  if (Lc <= 0 || Lc % 8 != 0 || Cout <= 0 || Cout % 32 != 0 || Cout > 128 || ld_in <= 0 || ld_in % 8 != 0 || ld_in > 128) return 0;
+  return conv_fwd_lds(Lc, ld_in, f32 != 0, nullptr, nullptr) <= 64 * 1024 ? 1 : 0;
+}
+
 static int conv_fwd_launch(const TecmConvFwd* p, void* stream, bool f32, const char* who) {
   using namespace tecm_convseq;
   TECM_REQUIRE(p && p->inp && p->wpack && p->bias && p->y, TECM_E_ARG, "%s: null pointer", who);
@@ -732,13 +750,9 @@ static int conv_fwd_launch(const TecmConvFwd* p, void* stream, bool f32, const c
   a.bias = p->bias;
   a.y = p->y;
   a.B = p->B; a.Lc = p->Lc; a.N = p->N; a.Cout = p->Cout; a.ld_in = p->ld_in;
-  int slots = p->ld_in * (f32 ? 4 : 2) / 16;                           // row pitch in 16-byte slots, odd: conflict-free ds_read_b128
-  if (slots % 2 == 0) ++slots;
-  a.pitch = slots * 16;
-  a.TC = 8 * MAXT < p->Lc ? 8 * MAXT : p->Lc;
+  const size_t lds = conv_fwd_lds(p->Lc, p->ld_in, f32, &a.pitch, &a.TC);
   a.nchunk = (p->Lc + a.TC - 1) / a.TC;
   a.nblk = (p->N + NB - 1) / NB;
-  const size_t lds = (size_t)(a.TC + 7) * NB * a.pitch;
   TECM_REQUIRE(lds <= 64 * 1024, TECM_E_LDS, "%s: %zu B of LDS per tile", who, lds);
   // units (kernel size j, 32-channel block), longest first, each to the least loaded wave
   const int nb32 = p->Cout / 32;
@@ -797,6 +811,36 @@ extern "C" int tecm_conv_dx_pack(const float* w3, const float* w5, const float* 
   return TECM_OK;
 }
 
+// Tile plan of the d-input kernel: time steps per tile (at most MAXT accumulator tiles per wave), the offset of the shared
+// zero row behind the staged image / the exchange buffer, and the LDS bytes of one tile.
+struct ConvDxPlan { int TC, zero_off, row_bytes, pitch, NCI; size_t lds; };
+static ConvDxPlan conv_dx_plan(int Lc, int Cout, int ld_in, bool f32) {
+  using namespace tecm_convseq;
+  ConvDxPlan q;
+  q.NCI = (ld_in + 31) / 32;
+  q.row_bytes = 3 * Cout * (f32 ? 4 : 2);
+  q.pitch = q.row_bytes + 16;
+  int TC = 8 * (MAXT / q.NCI);
+  if (TC > Lc) TC = Lc;
+  auto img_steps = [&](int tc) { return tc + 6 < Lc ? tc + 6 : Lc; };
+  auto zero_of = [&](int tc) {                             // the shared zero row sits behind the image AND the exchange buffer
+    const size_t img = (size_t)img_steps(tc) * NB * q.pitch;
+    const size_t xch = (size_t)(tc / 8) * q.NCI * (f32 ? 4 : 3) * 16 * 64 * 4;   // partial sums of 3 (fp32 round 1: 4) waves
+    return img > xch ? img : xch;
+  };
+  while (TC > 8 && zero_of(TC) + q.pitch > 160 * 1024) TC -= 8;
+  q.TC = TC;
+  q.zero_off = (int)zero_of(TC);
+  q.lds = zero_of(TC) + q.pitch;
+  return q;
+}
+
+// 1 when tecm_conv_dx_{bf16,f32} serves the shape (callers fall back to the window-view GEMMs otherwise), else 0
+extern "C" int tecm_conv_dx_supported(int32_t Lc, int32_t Cout, int32_t ld_in, int32_t f32) {
+  if (Lc <= 0 || Lc % 8 != 0 || Cout <= 0 || Cout % 64 != 0 || ld_in <= 0 || ld_in % 4 != 0 || ld_in > 64) return 0;
+  return conv_dx_plan(Lc, Cout, ld_in, f32 != 0).lds <= 160 * 1024 ? 1 : 0;
+}
+
 static int conv_dx_launch(const TecmConvDx* p, void* stream, bool f32, const char* who) {
   using namespace tecm_convseq;
   TECM_REQUIRE(p && p->dy && p->wpack && p->dinp, TECM_E_ARG, "%s: null pointer", who);
@@ -811,41 +855,30 @@ static int conv_dx_launch(const TecmConvDx* p, void* stream, bool f32, const cha
   a.wpack = p->wpack;
   a.dinp = p->dinp;
   a.B = p->B; a.Lc = p->Lc; a.N = p->N; a.Cout = p->Cout; a.ld_in = p->ld_in;
-  a.NCI = (p->ld_in + 31) / 32;
-  a.row_bytes = 3 * p->Cout * (f32 ? 4 : 2);
-  a.cpr = a.row_bytes / 16;
-  a.pitch = a.row_bytes + 16;
   // time steps per tile: at most MAXT accumulator tiles per wave, and the staged rows (+ 3 halo steps each side) must
   // fit: two blocks per CU when that costs nothing (Lc <= 48 at Cout = 64, Lc <= 24 at Cout = 128), else one
-  int TC = 8 * (MAXT / a.NCI);
-  if (TC > p->Lc) TC = p->Lc;
-  auto img_steps = [&](int tc) { return tc + 6 < p->Lc ? tc + 6 : p->Lc; };
-  auto zero_of = [&](int tc) {                             // the shared zero row sits behind the image AND the exchange buffer
-    const size_t img = (size_t)img_steps(tc) * NB * a.pitch;
-    const size_t xch = (size_t)(tc / 8) * a.NCI * (f32 ? 4 : 3) * 16 * 64 * 4;   // partial sums of 3 (fp32 round 1: 4) waves
-    return img > xch ? img : xch;
-  };
-  while (TC > 8 && zero_of(TC) + a.pitch > 160 * 1024) TC -= 8;
-  const size_t lds = zero_of(TC) + a.pitch;
+  const ConvDxPlan q = conv_dx_plan(p->Lc, p->Cout, p->ld_in, f32);
+  a.NCI = q.NCI;
+  a.row_bytes = q.row_bytes;
+  a.cpr = a.row_bytes / 16;
+  a.pitch = q.pitch;
+  const size_t lds = q.lds;
   TECM_REQUIRE(lds <= 160 * 1024, TECM_E_LDS, "%s: %d channels need %zu B of LDS per tile", who, 3 * p->Cout, lds);
+  const int TC = q.TC;
   a.TC = TC;
-  a.zero_off = (int)zero_of(TC);
+  a.zero_off = q.zero_off;
   a.nchunk = (p->Lc + TC - 1) / TC;
   a.nblk = (p->N + NB - 1) / NB;
   const int64_t tiles = (int64_t)p->B * a.nchunk * a.nblk;
   TECM_REQUIRE(tiles < ((int64_t)1 << 31), TECM_E_ARG, "%s: too many tiles", who);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dx_seq_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        160 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dx_seq_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        160 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dx_seq_f32_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        160 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dx_seq_f32_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        160 * 1024);
-    attr_set = true;
-  }
+  // more than 64 KiB of dynamic LDS needs the attribute on the function of THIS device: set per launch (cheap, and
+  // correct for a process that drives several GPUs or calls from several threads), return code checked
+  const void* fn = f32 ? (a.NCI == 1 ? reinterpret_cast<const void*>(&conv_dx_seq_f32_kernel<1>)
+                                     : reinterpret_cast<const void*>(&conv_dx_seq_f32_kernel<2>))
+                       : (a.NCI == 1 ? reinterpret_cast<const void*>(&conv_dx_seq_kernel<1>)
+                                     : reinterpret_cast<const void*>(&conv_dx_seq_kernel<2>));
+  TECM_REQUIRE(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess, TECM_E_LAUNCH,
+               "%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed", who);
   if (f32) {
     if (a.NCI == 1)
       hipLaunchKernelGGL(conv_dx_seq_f32_kernel<1>, dim3((unsigned)tiles), dim3(NTH32), lds, (hipStream_t)stream, a);

@@ -819,6 +819,19 @@ __global__ __launch_bounds__(D3TH, 1) void gemm_bf16_dma5_kernel(const TecmGemm 
     if (t + 1 < ntiles) ktile(t + 1, std::integral_constant<int, 1>{});
   }
   __syncthreads();                                      // every wave has left the last K-tile: the ring becomes staging
+#ifdef DMA_ABLATE_NOEPI                                  // diagnostics (tools/build_variant.py): K loop without the epilogue
+  {
+    float keep = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) keep += acc[i][j][e];
+    if (keep == 12345.678f) reinterpret_cast<float*>(g.C)[0] = keep;
+    return;
+  }
+#endif
 
   // ---- epilogue: gemm_impl.h's straight-line form over this wave's private staging rows; only the parking of the
   // accumulators knows the 16x16 C/D map (row = 4 (lane >> 4) + reg, col = lane & 15)
@@ -839,6 +852,180 @@ __global__ __launch_bounds__(D3TH, 1) void gemm_bf16_dma5_kernel(const TecmGemm 
     });
   };
   const int fmode = tecm_gemm::epi_fast_mode(g);         // >= 0: checked on the host (tecm_gemm16_dma_try)
+  constexpr int LPR = WTN / 4, RPI = 64 / LPR;
+  const int lcol = (lane % LPR) * 4, lrow = lane / LPR;
+  const EpiCol ecol = epi_col(g, n0 + wn * WTN + lcol);
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (g.bias && ecol.ok) bias4 = *reinterpret_cast<const float4*>(g.bias + ecol.n);
+  tecm_gemm::epi_fast_dispatch<WTM / 32, 32 / RPI, RPI, STG_LD, true>(fmode, g, odc, stg, lrow, lcol, m0 + wm * WTM, ecol, bias4,
+                                                                  stage_slab);
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Sixth geometry (round 4): FOUR waves per block, TWO blocks per CU.  The fifth geometry's wave tile (128 x 64 = 8 x 4
+// tiles of v_mfma_f32_16x16x32_bf16, 128 accumulators, up to 256 registers) in a 256-thread block: block tile
+// BM x BN = (WM * 128) x (WN * 64) with WM * WN = 4, a THREE-slot ring of 32-deep K-tiles ((BM + BN) * 64 B = 24 KiB per
+// slot, 72 KiB per block).  A CU then holds two INDEPENDENT blocks, one wave of each per SIMD: while one block stores its
+// tile (the epilogue moves as many bytes as the K loop of a K = 768 GEMM takes to compute), the other block's waves own
+// the matrix pipes; inside the K loop the two waves of a SIMD are uncorrelated instead of meeting at the same barrier.
+// Ring protocol (per wave 6 DMA pieces per K-tile): in the middle of tile t every wave has issued ALL its fragment reads of
+// tile t (the second half's A fragments are read at the top), waits for them (`lgkmcnt(0)`) and for its own pieces of tile
+// t+1 (`vmcnt(6)`: at most tile t+2's six outstanding), passes the barrier, requests tile t+3 into tile t's slot, and reads
+// tile t+1's first fragments under the second half's 16 MFMAs.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_dma6_kernel(const TecmGemm g, int tiles_m, int tiles_n) {
+  static_assert(WM * WN == 4 && BM == WM * 128 && BN == WN * 64, "four waves of 128 x 64");
+  constexpr int BK = 32, ST = 3;
+  constexpr int WTM = 128, WTN = 64;
+  constexpr int MT = WTM / 16, NT = WTN / 16;          // 8 x 4 tiles of 16 x 16
+  constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK, TILE_ELEMS = A_ELEMS + B_ELEMS;   // 24 KiB
+  constexpr int PIECE = 16 * BK;                       // 16 rows of 64 B = 1 KiB
+  constexpr int PA = BM / 16, PB = BN / 16, NP = (PA + PB) / 4;   // pieces per wave and K-tile: 6
+  static_assert((PA + PB) % 4 == 0 && NP == 6, "six DMA pieces per wave");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[ST * TILE_ELEMS * 2];
+  __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);
+  static_assert(ST * TILE_ELEMS * 2 >= 4 * 32 * (WTN + 4) * 4, "epilogue slabs fit in the operand ring");
+
+  const int nwg = tiles_m * tiles_n;
+  const int id = blockIdx.x;
+  const int xcd = id & 7, local = id >> 3;
+  const int q8 = nwg >> 3, r8 = nwg & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
+  const int GROUP_M = g._p1 > 0 ? g._p1 : 4;
+  const int per_group = GROUP_M * tiles_n;
+  const int group = wg / per_group;
+  const int first_m = group * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int in_group = wg - group * per_group;
+  const int tm = first_m + in_group % gsz, tn = in_group / gsz;
+  const int64_t m0 = (int64_t)tm * BM;
+  const int64_t n0 = (int64_t)tn * BN;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int ntiles = (int)g.K / BK;                    // K % 32 == 0 (host)
+
+  const __bf16* Ah = reinterpret_cast<const __bf16*>(g.A);
+  const __bf16* Bh = reinterpret_cast<const __bf16*>(g.B);
+  const __bf16* src[NP];
+  int dst[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int p = wave + 4 * i;                        // pieces 0..PA-1 = A rows 16p.., then B rows
+    const bool isb = p >= PA;
+    const int row = (isb ? p - PA : p) * 16 + (lane >> 2);
+    const int chunk = (lane & 3) ^ (3 * ((row >> 3) & 1));
+    if (!isb) {
+      int64_t gm = m0 + row;
+      gm = gm < g.M ? gm : g.M - 1;                    // clamped rows feed accumulator rows that are never stored
+      src[i] = Ah + gm * g.lda + chunk * 8;
+      dst[i] = p * PIECE;
+    } else {
+      int64_t gn = n0 + row;
+      gn = gn < g.N ? gn : g.N - 1;
+      src[i] = Bh + gn * g.ldb + chunk * 8;
+      dst[i] = A_ELEMS + (p - PA) * PIECE;
+    }
+  }
+  auto issue_tile = [&](int slot) {
+    __bf16* buf = smem + slot * TILE_ELEMS;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      dma16(src[i], buf + dst[i]);
+      src[i] += BK;
+    }
+  };
+
+  f32x4v acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+  const int fr = lane & 15, fq = lane >> 4;
+  int a_off[MT], b_off[NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int row = wm * WTM + i * 16 + fr;
+    a_off[i] = row * BK + ((fq ^ (3 * ((row >> 3) & 1))) << 3);
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int row = wn * WTN + j * 16 + fr;
+    b_off[j] = A_ELEMS + row * BK + ((fq ^ (3 * ((row >> 3) & 1))) << 3);
+  }
+  auto mfma_half = [&](const bf16x8 (&af)[4], const bf16x8 (&bf)[NT], int i0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        if (i0 == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        else acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[4 + i][j], 0, 0, 0);
+      }
+  };
+
+  issue_tile(0);
+  if (ntiles > 1) issue_tile(1);
+  if (ntiles > 2) issue_tile(2);
+  if (ntiles > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (ntiles > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  bf16x8 fa[2][4], fb[2][NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) fb[0][j] = *reinterpret_cast<const bf16x8*>(smem + b_off[j]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) fa[0][i] = *reinterpret_cast<const bf16x8*>(smem + a_off[i]);
+  int slot = 0;
+  auto ktile = [&](int t, auto parity) {
+    constexpr int P = decltype(parity)::value;
+    const __bf16* Tc = smem + slot * TILE_ELEMS;
+    const int nslot = slot == ST - 1 ? 0 : slot + 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[1][i] = *reinterpret_cast<const bf16x8*>(Tc + a_off[4 + i]);
+    mfma_half(fa[0], fb[P], 0);
+    if (t + 1 < ntiles) {
+      // every fragment read of tile t has returned (its slot is refilled behind the barrier); this wave's pieces of
+      // tile t+1 have landed once at most tile t+2's six are outstanding
+      if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (t + 3 < ntiles) issue_tile(slot);            // tile t+3 into tile t's slot
+      const __bf16* Tn = smem + nslot * TILE_ELEMS;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) fb[P ^ 1][j] = *reinterpret_cast<const bf16x8*>(Tn + b_off[j]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[0][i] = *reinterpret_cast<const bf16x8*>(Tn + a_off[i]);
+    }
+    mfma_half(fa[1], fb[P], 4);
+    slot = nslot;
+  };
+  for (int t = 0; t < ntiles; t += 2) {
+    ktile(t, std::integral_constant<int, 0>{});
+    if (t + 1 < ntiles) ktile(t + 1, std::integral_constant<int, 1>{});
+  }
+  __syncthreads();                                      // every wave has left the last K-tile: the ring becomes staging
+
+  constexpr int STG_LD = WTN + 4;
+  const DropCtx odc = make_drop(g.out_drop);
+  float* stg = reinterpret_cast<float*>(smem_raw) + wave * (32 * STG_LD);
+  auto stage_slab = [&](auto ic) {                     // 32 accumulator rows = tile rows 2 i, 2 i + 1
+    constexpr int i = decltype(ic)::value;
+    static_for<2>([&](auto tc) {
+      constexpr int ti = decltype(tc)::value;
+      static_for<NT>([&](auto jc) {
+        constexpr int jn = decltype(jc)::value;
+        static_for<4>([&](auto ec) {
+          constexpr int e = decltype(ec)::value;
+          stg[(16 * ti + 4 * fq + e) * STG_LD + jn * 16 + fr] = acc[2 * i + ti][jn][e];
+        });
+      });
+    });
+  };
+  const int fmode = tecm_gemm::epi_fast_mode(g);
   constexpr int LPR = WTN / 4, RPI = 64 / LPR;
   const int lcol = (lane % LPR) * 4, lrow = lane / LPR;
   const EpiCol ecol = epi_col(g, n0 + wn * WTN + lcol);
@@ -881,6 +1068,17 @@ int tecm_gemm16_dma_try(const TecmGemm& g, hipStream_t st) {
   {
     const int streams = (g.residual ? 1 : 0) + (g.dact_src ? 1 : 0) + (g.accumulate ? 1 : 0);
     const bool can16 = !g.c_win.enabled && !g.rowbias && streams <= 1;     // the straight-line epilogues only
+    if (can16 && sel && (sel[0] == '6' || sel[0] == '7')) {                // four-wave blocks, two per CU (A/B diagnostics)
+      if (sel[0] == '6') {
+        const int t6m = (int)((g.M + 255) / 256), t6n = (int)((g.N + 127) / 128);
+        hipLaunchKernelGGL((gemm_bf16_dma6_kernel<256, 128, 2, 2>), dim3((unsigned)(t6m * t6n)), dim3(256), 0, st, g, t6m, t6n);
+      } else {
+        const int t6m = (int)((g.M + 127) / 128), t6n = (int)((g.N + 255) / 256);
+        hipLaunchKernelGGL((gemm_bf16_dma6_kernel<128, 256, 1, 4>), dim3((unsigned)(t6m * t6n)), dim3(256), 0, st, g, t6m, t6n);
+      }
+      TECM_CHECK_LAUNCH("tecm_gemm_bf16/dma6");
+      return 1;
+    }
     const bool want16 = sel ? sel[0] == '5' : true;
     if (can16 && want16) {
       hipLaunchKernelGGL(gemm_bf16_dma5_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(D3TH), 0, st, g, tiles_m, tiles_n);

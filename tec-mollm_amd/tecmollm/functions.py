@@ -301,7 +301,7 @@ class ConvBlockFn(torch.autograd.Function):
         # (csrc/conv_seq.hip): exact fp32 from the fp32 input, the bf16 mode's arithmetic from the bf16 copy of the input;
         # otherwise (bf16x3 / bf16x6 modes, odd shapes) three window GEMMs, one 64- / 128-column slice each
         seq_in = inp16 if (side16 and inp16 is not None) else (inp if int(bf16) == ops.PREC_FP32 else None)
-        fwd_seq = seq_in is not None and ops.conv_fwd_seq_ok(Lc, Cout, ld_in)
+        fwd_seq = seq_in is not None and ops.conv_fwd_seq_ok(Lc, Cout, ld_in, f32=seq_in.dtype == torch.float32)
         if fwd_seq:
             ops.conv_fwd(seq_in.detach(), w3.detach(), w5.detach(), w7.detach(), torch.cat([b3, b5, b7]).detach(), y, B, Lc,
                          N, Cout, cin, ld_in)
@@ -362,8 +362,9 @@ class ConvBlockFn(torch.autograd.Function):
         # d inp of the three kernel sizes in ONE launch that reads dy once (csrc/conv_seq.hip) instead of three
         # accumulating window GEMMs: exact fp32 from an fp32 dy, the bf16 mode's roundings from a bf16 dy (the bf16x3 /
         # bf16x6 modes keep the GEMM path)
-        dx_seq = need_dinp and ops.conv_dx_seq_ok(Lc, Cout, ld_in) and int(bf16) in (ops.PREC_FP32, ops.PREC_BF16) \
-            and (dy.dtype == torch.bfloat16 or int(bf16) == ops.PREC_FP32)
+        dx_seq = need_dinp and int(bf16) in (ops.PREC_FP32, ops.PREC_BF16) \
+            and (dy.dtype == torch.bfloat16 or int(bf16) == ops.PREC_FP32) \
+            and ops.conv_dx_seq_ok(Lc, Cout, ld_in, f32=dy.dtype == torch.float32)
         if dx_seq:
             ops.conv_dx(dy, ctx.w357[0], ctx.w357[1], ctx.w357[2], dinp, B, Lc, N, Cout, cin, ld_in)
         grads = []

@@ -67,10 +67,10 @@ def gemm(M: int, N: int, K: int, A: torch.Tensor, lda: int, B: torch.Tensor, ldb
     g.M, g.N, g.K = M, N, K
     io = (IO_A_BF16 if A.dtype == torch.bfloat16 else 0) | (IO_B_BF16 if B.dtype == torch.bfloat16 else 0) | \
          (IO_C_BF16 if Cout.dtype == torch.bfloat16 else 0)
-    pre = preact if preact is not None else dact_src
-    if pre is not None and pre[0].dtype == torch.bfloat16:
-        if preact is not None and dact_src is not None and dact_src[0].dtype != torch.bfloat16:
-            raise ValueError("gemm: preact and dact_src must share a dtype")
+    pre_dt = {t[0].dtype for t in (preact, dact_src) if t is not None}     # ONE flag covers both pointers: they must agree
+    if len(pre_dt) > 1:
+        raise ValueError("gemm: preact and dact_src must share a dtype")
+    if pre_dt == {torch.bfloat16}:
         io |= IO_PRE_BF16
     if io:
         if int(bf16) != PREC_BF16:
@@ -201,6 +201,8 @@ def _kernel_name(g: TecmGemm, use16: bool = False) -> str:
             ring = sel == "4"                                                 # the four-slot ring, anti-phase wave groups (A/B)
             can16 = not g.c_win.enabled and not g.rowbias and \
                 (1 if g.residual else 0) + (1 if g.dact_src else 0) + (1 if g.accumulate else 0) <= 1
+            if can16 and sel in ("6", "7"):                                   # four-wave blocks, two per CU (A/B)
+                return "gemm_bf16_dma6_kernel<256,128,2,2>" if sel == "6" else "gemm_bf16_dma6_kernel<128,256,1,4>"
             want16 = sel == "5" if sel else True                              # the ring with 16x16x32 MFMAs
             if can16 and want16:
                 return "gemm_bf16_dma5_kernel"
@@ -424,10 +426,12 @@ def conv_weight_unpack(dpack: torch.Tensor, Cout: int, Cin: int, k: int) -> torc
     return dw
 
 
-def conv_dx_seq_ok(Lc: int, Cout: int, ld_in: int) -> bool:
-    """Shapes the sequence-tile conv kernels (csrc/conv_seq.hip) serve; everything else takes the window-view GEMMs."""
-    return (Lc % 8 == 0 and Cout % 64 == 0 and ld_in % 4 == 0 and 0 < ld_in <= 64
-            and os.environ.get("TECM_CONV_SEQ", "1")[:1] != "0")
+def conv_dx_seq_ok(Lc: int, Cout: int, ld_in: int, f32: bool = False) -> bool:
+    """Shapes the sequence-tile d-input kernel (csrc/conv_seq.hip) serves IN THIS PRECISION -- divisibility and the LDS
+    bytes of one tile, asked of the library itself (tecm_conv_dx_supported) so that the two can never disagree; everything
+    else takes the window-view GEMMs."""
+    return (os.environ.get("TECM_CONV_SEQ", "1")[:1] != "0"
+            and lib().tecm_conv_dx_supported(Lc, Cout, ld_in, 1 if f32 else 0) == 1)
 
 
 def conv_dx(dy: torch.Tensor, w3: torch.Tensor, w5: torch.Tensor, w7: torch.Tensor, dinp: torch.Tensor, B: int,
@@ -503,9 +507,10 @@ def conv_dw(inp: torch.Tensor, dy: torch.Tensor, B: int, Lc: int, N: int, Cout: 
     return dws
 
 
-def conv_fwd_seq_ok(Lc: int, Cout: int, ld_in: int) -> bool:
-    return (Lc % 8 == 0 and Cout % 32 == 0 and 0 < Cout <= 128 and ld_in % 8 == 0 and 0 < ld_in <= 128
-            and os.environ.get("TECM_CONV_SEQ", "1")[:1] != "0" and os.environ.get("TECM_CONV_FWD_SEQ", "1")[:1] != "0")
+def conv_fwd_seq_ok(Lc: int, Cout: int, ld_in: int, f32: bool = False) -> bool:
+    """As conv_dx_seq_ok, for the forward kernel (tecm_conv_fwd_supported: 64 KiB of LDS per tile)."""
+    return (os.environ.get("TECM_CONV_SEQ", "1")[:1] != "0" and os.environ.get("TECM_CONV_FWD_SEQ", "1")[:1] != "0"
+            and lib().tecm_conv_fwd_supported(Lc, Cout, ld_in, 1 if f32 else 0) == 1)
 
 
 def conv_fwd(inp: torch.Tensor, w3: torch.Tensor, w5: torch.Tensor, w7: torch.Tensor, bias: torch.Tensor,

@@ -284,3 +284,67 @@ def assert_parity(res: dict, tol: Optional[float] = None, kink: bool = False, el
     else:
         assert all(v < 1.0 for v in res.get("kink_elem_tight", {}).values()), brief
     assert res["frozen_with_grad"] == [], brief
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# GATv2Conv known-answer vectors, derived BY HAND from Brody et al. 2021 eq. 7 and PyG's conventions (edge_index[0] = source j,
+# edge_index[1] = target i, messages flow source -> target; lin_l transforms the SOURCE row and is what gets aggregated,
+# lin_r transforms the TARGET row; e_ij = att . LeakyReLU_0.2(x_l[j] + x_r[i]); softmax over the sources j of one target
+# i, self loop included; out_i = sum_j alpha_ij x_l[j] + bias).  Literal numbers, no code shared with oracle/ref_cpu.py or
+# the kernels.  The graph is ASYMMETRIC on purpose: a transposed edge direction or swapped lin_l / lin_r roles give
+# different numbers at every node (the reference's own graph is symmetric and could not tell).
+#
+#   3 nodes, 22 channels, heads = 2 x 11.  Only input features 0 and 1 are non-zero:
+#       x0 = (1, 2), x1 = (-1, 0.5), x2 = (0.5, -1.5)
+#   lin_l: out[0]  = in[0]              (head 0, channel 0)      lin_r: out[0]  = 0.5 in[1] + 0.3
+#          out[11] = in[1]              (head 1, channel 0)             out[11] = -in[0] + 0.1
+#   (all other weights / biases zero, so every other channel of x_l + x_r is exactly 0 and contributes att*lrelu(0) = 0)
+#   att[head 0] = (2, 0, ..), att[head 1] = (-1, 0, ..); output bias[0] = 0.05, bias[11] = -0.07, bias[5] = 0.5
+#   edges (source -> target): 0 -> 1, 2 -> 1, 0 -> 2; self loops are added by the layer.
+#
+#   x_l (h0, h1): n0 (1, 2)  n1 (-1, 0.5)  n2 (0.5, -1.5)        x_r (h0, h1): n0 (1.3, -0.9)  n1 (0.55, 1.1)  n2 (-0.45, -0.4)
+#   target 0, sources {0}:            alpha = 1                                   -> out = (1 + 0.05, 2 - 0.07)
+#   target 1, sources {0, 2, 1}: h0:  s = (1.55, 1.05, -0.45) -> e = 2 lrelu(s) = (3.1, 2.1, -0.18)
+#                                     alpha = (0.711486676, 0.261741321, 0.026772003)
+#                                     out = 0.711486676*1 + 0.261741321*0.5 + 0.026772003*(-1) + 0.05 = 0.865585333
+#                                h1:  s = (3.1, -0.4, 1.6) -> e = -lrelu(s) = (-3.1, 0.08, -1.6)
+#                                     alpha = (0.033865653, 0.814359019, 0.151775328)
+#                                     out = 0.033865653*2 + 0.814359019*(-1.5) + 0.151775328*0.5 - 0.07 = -1.147919557
+#   target 2, sources {0, 2}:    h0:  s = (0.55, 0.05) -> e = (1.1, 0.1); alpha = (0.731058579, 0.268941421)
+#                                     out = 0.731058579*1 + 0.268941421*0.5 + 0.05 = 0.915529289
+#                                h1:  s = (1.6, -1.9) -> e = (-1.6, 0.38); alpha = (0.121318838, 0.878681162)
+#                                     out = 0.121318838*2 + 0.878681162*(-1.5) - 0.07 = -1.145384067
+GAT_KAT_X = ((1.0, 2.0), (-1.0, 0.5), (0.5, -1.5))                     # features 0, 1 of nodes 0..2 (features 2..21 = 0)
+GAT_KAT_EDGES = ((0, 2, 0), (1, 1, 2))                                 # edge_index: row 0 = sources, row 1 = targets
+GAT_KAT_OUT = {                                                       # (node, channel) -> value; every other channel = its bias
+    (0, 0): 1.05, (0, 11): 1.93,
+    (1, 0): 0.8655853329, (1, 11): -1.1479195571,
+    (2, 0): 0.9155292893, (2, 11): -1.1453840674,
+}
+GAT_KAT_BIAS = {0: 0.05, 11: -0.07, 5: 0.5}
+# what the two plausible misreadings would produce at (node 1, channel 0): the test asserts we are NOT there
+GAT_KAT_WRONG_DIRECTION_1_0 = -0.95
+GAT_KAT_WRONG_ROLES_1_0 = 0.8507363001
+
+
+def gat_kat_tensors():
+    """(x (3, 22), edge_index (2, 3) int64, GATv2 parameter dict keyed like the oracle's, expected (3, 22))."""
+    x = torch.zeros(3, 22)
+    for n, (a, b) in enumerate(GAT_KAT_X):
+        x[n, 0], x[n, 1] = a, b
+    Wl, Wr = torch.zeros(22, 22), torch.zeros(22, 22)
+    bl, br = torch.zeros(22), torch.zeros(22)
+    Wl[0, 0], Wl[11, 1] = 1.0, 1.0
+    Wr[0, 1], br[0] = 0.5, 0.3
+    Wr[11, 0], br[11] = -1.0, 0.1
+    att = torch.zeros(1, 2, 11)
+    att[0, 0, 0], att[0, 1, 0] = 2.0, -1.0
+    bias = torch.zeros(22)
+    for c, v in GAT_KAT_BIAS.items():
+        bias[c] = v
+    p = {R.P_GAT + "lin_l.weight": Wl, R.P_GAT + "lin_l.bias": bl, R.P_GAT + "lin_r.weight": Wr,
+         R.P_GAT + "lin_r.bias": br, R.P_GAT + "att": att, R.P_GAT + "bias": bias}
+    want = bias.view(1, 22).repeat(3, 1)
+    for (n, c), v in GAT_KAT_OUT.items():
+        want[n, c] = v
+    return x, torch.tensor(GAT_KAT_EDGES, dtype=torch.int64), p, want

@@ -616,3 +616,27 @@ def test_standalone_spatial_encoder_forward_backward(dev, mode):
         assert_close(a, b, n)
     with pytest.raises(Exception):
         enc(x.to(dev).requires_grad_(True), ei.to(dev)).sum().backward()   # d x is not part of the MI355X path
+
+
+def test_gatv2_kernel_matches_the_hand_derived_known_answer(dev):
+    """The HIP GATv2 kernel against literal numbers derived by hand from Brody et al. eq. 7 and PyG's source -> target
+    convention on a 3-node ASYMMETRIC graph (tests/parity.py GAT_KAT_*; the same vectors pin the oracle in
+    tests/test_oracle.py): edge direction and the lin_l-on-source assignment are checked by something neither the
+    kernel nor the restatement was written from.  Reference call site: modules.py:329-336, :356."""
+    from parity import GAT_KAT_WRONG_DIRECTION_1_0, GAT_KAT_WRONG_ROLES_1_0, gat_kat_tensors
+    from src.model.modules import SpatialEncoder
+    x, ei, p, want = gat_kat_tensors()
+    enc = SpatialEncoder(22, 11, 2).eval()
+    enc.load_state_dict({k[len("spatial_encoder."):]: v for k, v in p.items()})
+    enc = enc.to(dev)
+    enc.gat_graphs = "per_timestep"
+    G = 5
+    out = enc(x.unsqueeze(0).repeat(G, 1, 1).to(dev), ei.to(dev)).cpu()
+    for g in range(G):
+        torch.testing.assert_close(out[g], want, rtol=0, atol=2e-6)
+    assert abs(float(out[0, 1, 0]) - GAT_KAT_WRONG_DIRECTION_1_0) > 0.5
+    assert abs(float(out[0, 1, 0]) - GAT_KAT_WRONG_ROLES_1_0) > 1e-2
+    enc.gat_graphs = "reference"                      # the reference's literal mode: graph 0 has the edges, the rest self loops
+    out = enc(x.unsqueeze(0).repeat(G, 1, 1).to(dev), ei.to(dev)).cpu()
+    torch.testing.assert_close(out[0], want, rtol=0, atol=2e-6)
+    torch.testing.assert_close(out[1:, :, 0], (x[:, 0] + 0.05).expand(G - 1, 3), rtol=0, atol=1e-6)

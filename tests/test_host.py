@@ -50,6 +50,22 @@ def test_binding_matches_header(built_lib):
     _lib.lib()                                              # loads, sets prototypes, checks the ABI version
 
 
+def test_conv_sequence_kernels_report_what_they_serve_including_the_lds_budget(built_lib):
+    """tecm_conv_{fwd,dx}_supported are pure host arithmetic (no GPU call): the predicates ConvBlockFn routes on must say no
+    exactly where the launchers would refuse with TECM_E_LDS, so that such shapes fall back to the window-view GEMMs
+    (Multi_Scale_Conv_Block accepts any channel list, modules.py:19-41).  Cases: the timed shapes; out_channels = 256 with an
+    fp32 d-input image (3088-B rows x 4 nodes x 14 steps > 160 KiB); ld_in = 128 forward in fp32 (528-B rows x 4 x 39 > 64 KiB)."""
+    from tecmollm import ops
+    assert ops.conv_fwd_seq_ok(48, 64, 24, f32=True) and ops.conv_fwd_seq_ok(48, 64, 24, f32=False)
+    assert ops.conv_fwd_seq_ok(24, 128, 64, f32=True) and ops.conv_dx_seq_ok(24, 128, 64, f32=True)
+    assert ops.conv_dx_seq_ok(48, 64, 24, f32=True) and ops.conv_dx_seq_ok(48, 64, 24, f32=False)
+    assert not ops.conv_dx_seq_ok(16, 256, 64, f32=True)          # [64, 256]: the fp32 image does not fit one CU's LDS
+    assert ops.conv_dx_seq_ok(16, 256, 64, f32=False)             # ... the bf16 image does
+    assert not ops.conv_fwd_seq_ok(48, 128, 128, f32=True)        # [128, 128] at L_in = 96: fp32 rows of 528 B
+    assert ops.conv_fwd_seq_ok(48, 128, 128, f32=False)
+    assert not ops.conv_fwd_seq_ok(48, 256, 64) and not ops.conv_dx_seq_ok(20, 64, 24) and not ops.conv_dx_seq_ok(48, 64, 128)
+
+
 def test_product_path_refuses_cpu_tensors(built_lib):
     """No CPU fallback: the model raises instead of silently computing somewhere else."""
     from tests.parity import build_model

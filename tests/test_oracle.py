@@ -127,6 +127,23 @@ def test_gatv2_matches_dense_formulation():
     torch.testing.assert_close(out, _dense_gatv2(x, adj, p, 2), rtol=1e-5, atol=1e-5)
 
 
+def test_gatv2_hand_derived_known_answer_on_an_asymmetric_graph():
+    """Edge direction (edge_index[0] = source -> edge_index[1] = target) and the lin_l-on-source / lin_r-on-target
+    assignment pinned by literal numbers derived by hand from Brody et al. eq. 7 and the PyG convention (tests/parity.py,
+    GAT_KAT_*): nothing here shares code with the restatement.  Reference call site: modules.py:329-336, :356."""
+    from parity import GAT_KAT_WRONG_DIRECTION_1_0, GAT_KAT_WRONG_ROLES_1_0, gat_kat_tensors
+    x, ei, p, want = gat_kat_tensors()
+    out = R.gatv2_conv(x, ei, p, 2)
+    torch.testing.assert_close(out, want, rtol=0, atol=2e-6)
+    assert abs(float(out[1, 0]) - GAT_KAT_WRONG_DIRECTION_1_0) > 0.5 and abs(float(out[1, 0]) - GAT_KAT_WRONG_ROLES_1_0) > 1e-2
+    # the same three nodes as graph 1 of two (rows 3..5): a batched edge_index must give the same answer there, and the
+    # edgeless graph 0 must see self loops only (out = x_l + bias)
+    x2 = torch.cat([x, x])
+    out2 = R.gatv2_conv(x2, ei + 3, p, 2)
+    torch.testing.assert_close(out2[3:], want, rtol=0, atol=2e-6)
+    torch.testing.assert_close(out2[:3, 0], x[:, 0] + 0.05, rtol=0, atol=1e-6)
+
+
 def test_reference_graph_mode_only_touches_graph0():
     """SURVEY section 0 defect 1: with a single-graph edge_index only rows of graph 0 aggregate
     neighbours; every other row reduces to x + lin_l(x) + bias."""

@@ -14,6 +14,9 @@ for L_in, L_out in ((48, 12), (16, 4), (32, 12), (40, 12), (24, 6), (80, 12), (9
     cases.append((f"L_in={L_in} L_out={L_out}", dict(L_in=L_in, L_out=L_out), {}))
 cases.append(("channels [128, 256]", dict(), {"temporal_channel_list": [128, 256]}))
 cases.append(("channels [64, 64]", dict(), {"temporal_channel_list": [64, 64]}))
+# shapes whose fp32 sequence tiles do NOT fit the LDS (tecm_conv_*_supported says no): the window-GEMM fallback serves them
+cases.append(("channels [64, 256] L_in=96", dict(L_in=96, L_out=24), {"temporal_channel_list": [64, 256]}))
+cases.append(("channels [128, 128] L_in=96", dict(L_in=96, L_out=24), {"temporal_channel_list": [128, 128]}))
 cases.append(("strides [1, 2]", dict(), {"temporal_strides": [1, 2], "patch_len": 4}))
 cases.append(("patch_len 2", dict(), {"patch_len": 2}))
 cases.append(("c_in 10 d_emb 12", dict(c_in=10, d_emb=12), {}))

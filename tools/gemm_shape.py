@@ -25,8 +25,9 @@ for spec in os.environ.get("SHAPES", "16384,2048,16384,kn").split(";"):
     kw = {}
     if "bias" in EPI: kw["bias"] = torch.randn(N, device=dev)
     if "gelu" in EPI: kw["act"] = ops.ACT_GELU_TANH
-    if "preact" in EPI: kw["preact"] = (torch.empty(M, N, device=dev), N)
-    if "dact" in EPI: kw["dact_src"] = (torch.randn(M, N, device=dev), N)
+    p16 = torch.bfloat16 if "p" in R16 else torch.float32     # "p": the pre-activation / GELU' source lives as bf16 (the step's form)
+    if "preact" in EPI: kw["preact"] = (torch.empty(M, N, device=dev, dtype=p16), N)
+    if "dact" in EPI: kw["dact_src"] = (torch.randn(M, N, device=dev).to(p16), N)
     if "resid" in EPI: kw["residual"] = (torch.randn(M, N, device=dev), N)
     if "drop" in EPI: kw["out_drop"] = ops.drop(0.1, 1234, N)
     for _ in range(2):

@@ -323,6 +323,13 @@ typedef struct TecmConvDw {
   float* dw7;
   int32_t B, Lc, N, Cout, Cin, ld_in, num_blocks, _pad;
 } TecmConvDw;
+/* The same loss over a logical (B, H, N) index space with one stride triple (elements) per tensor: the model's
+ * prediction is the permuted view (B, L_out, N, 1) of (B, N, L_out) storage (tec_mollm.py:122-123) and the target has its
+ * own layout (train.py:76-78) -- no contiguous copies.  dpred is written with the PREDICTION's strides. */
+int tecm_huber_fwd_bwd_strided(const float* pred, const int64_t* pred_strides /* 3 */, const float* target,
+                               const int64_t* target_strides /* 3 */, float* dpred, float* loss_out, int32_t B, int32_t H,
+                               int32_t N, float delta, float grad_scale, float* workspace /* >= 1024 */, void* stream);
+
 int64_t tecm_conv_dw_workspace(int32_t Cout, int32_t ld_in, int32_t num_blocks);
 int tecm_conv_dw_bf16(const TecmConvDw* p, void* stream);
 /* The same in exact fp32 (BASELINE configs[1]): inp and dy fp32, v_mfma_f32_32x32x2_f32. */
@@ -343,6 +350,18 @@ int tecm_dropout_apply(const float* src, int64_t ld_src, float* dst, int64_t ld_
  * [W ; (alpha/r) * B^T] (modules.py:177-183) and other small transposes. */
 int tecm_transpose_scale(const float* src, int64_t lds, float* dst, int64_t ldd, int32_t rows,
                          int32_t cols, float scale, void* stream);
+
+/* LoRA fold (peft Linear on c_attn, reference modules.py:177-186): writes scale * lora_B (n_out, r) into the r trainable
+ * rows of the K-extended backward operand w_kn = [ W ; scale B^T ] ([k_off + r][n_out], leading dimension ld_kn) and / or
+ * the r trainable columns of the forward operand w_nk = [ W^T | scale B ] ([n_out][k_off + r], ld_nk); either may be
+ * NULL; *_bf16 != 0: that operand is bf16.  The frozen part of both operands is the caller's (filled once). */
+int tecm_lora_fold(const float* lora_B, int32_t n_out, int32_t r, float scale, void* w_kn, int64_t ld_kn, int32_t kn_bf16,
+                   void* w_nk, int64_t ld_nk, int32_t nk_bf16, int32_t k_off, void* stream);
+
+/* dst = srcs[0] | srcs[1] | ... (count <= 12 fp32 vectors of lens[i] elements, host arrays of device pointers): the
+ * per-branch bias / gamma / beta of a Multi_Scale_Conv_Block (modules.py:27-29) as the 3*Cout vectors the fused kernels
+ * read, in one launch. */
+int tecm_pack_vectors(const float* const* srcs, const int32_t* lens, int32_t count, float* dst, void* stream);
 
 /* ------------------------------------------------------------------ the shell around the step
  * (2) optimizer step of train.py:92-109 + :358-366 on FLAT buffers: global-norm clip + AdamW in two

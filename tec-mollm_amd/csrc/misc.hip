@@ -20,6 +20,32 @@ __global__ __launch_bounds__(256) void huber_stage1(const float* __restrict__ pr
   __syncthreads();
   if (threadIdx.x == 0) ws[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
+// the same over a logical (B, H, N) index space with separate strides per tensor: the model's output is a permuted view
+// (B, L_out, N, 1) of its (B, N, L_out) storage (tec_mollm.py:122-123) and the target arrives in its own layout; the
+// gradient is written in the PREDICTION's layout, so the head's backward reads a contiguous tensor
+struct HuberStrides { int64_t pb, ph, pn, tb, th, tn; int32_t H, N; };
+__global__ __launch_bounds__(256) void huber_stage1_strided(const float* __restrict__ pred, const float* __restrict__ target,
+                                                            float* __restrict__ dpred, float* __restrict__ ws, int64_t n,
+                                                            float delta, float gscale, const HuberStrides s) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  // storage order of pred: (b, n, h) with h fastest when ph == 1 -- walk the index space so that pred / dpred coalesce
+  const int64_t HN = (int64_t)s.H * s.N;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / HN;
+    const int64_t rem = i - b * HN;
+    const int32_t nn = (int32_t)(rem / s.H), h = (int32_t)(rem - (int64_t)nn * s.H);
+    const int64_t ip = b * s.pb + h * s.ph + nn * s.pn;
+    const float r = pred[ip] - target[b * s.tb + h * s.th + nn * s.tn];
+    const float a = fabsf(r);
+    acc += a <= delta ? 0.5f * r * r : delta * (a - 0.5f * delta);
+    if (dpred) dpred[ip] = (a <= delta ? r : (r > 0.f ? delta : -delta)) * gscale;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) ws[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
 __global__ __launch_bounds__(256) void huber_stage2(const float* __restrict__ ws, int nb, float* __restrict__ out,
                                                     float inv_n) {
   __shared__ float red[4];
@@ -108,6 +134,76 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
 }
 }  // namespace
 
+// ---- LoRA fold: the 32 trainable rows / columns of the K-extended c_attn operands [ W ; s B^T ] ([K+r][n]) and
+// [ W^T | s B ] ([n][K+r]) from lora_B (n, r), in fp32 or bf16 -- the frozen part of both is filled once per parameter
+// version on the host side (tecmollm/functions.py: _kext), so one tiny launch per layer and step replaces the
+// copy / scale / transpose / cast sequence that rebuilt the whole 7 MB operand
+namespace {
+template <typename TK, typename TN>
+__global__ __launch_bounds__(256) void lora_fold_kernel(const float* __restrict__ lB, int n_out, int r, float scale,
+                                                        TK* __restrict__ w_kn, int64_t ld_kn, TN* __restrict__ w_nk,
+                                                        int64_t ld_nk, int k_off) {
+  const int total = n_out * r;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int n = i / r, j = i - n * r;
+    const float v = scale * lB[i];
+    if (w_kn) w_kn[(int64_t)(k_off + j) * ld_kn + n] = (TK)v;
+    if (w_nk) w_nk[(int64_t)n * ld_nk + k_off + j] = (TN)v;
+  }
+}
+
+// up to 12 small fp32 vectors laid end to end in one buffer (the per-branch bias / gamma / beta of a
+// Multi_Scale_Conv_Block, modules.py:27-29, which the conv and norm kernels read as one 3*Cout vector each)
+struct PackVecArgs { const float* src[12]; int32_t len[12]; int32_t count; };
+__global__ __launch_bounds__(256) void pack_vectors_kernel(const PackVecArgs a, float* __restrict__ dst) {
+  int off = 0;
+  for (int v = 0; v < a.count; ++v) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.len[v]; i += gridDim.x * 256) dst[off + i] = a.src[v][i];
+    off += a.len[v];
+  }
+}
+}  // namespace
+
+extern "C" int tecm_lora_fold(const float* lora_B, int32_t n_out, int32_t r, float scale, void* w_kn, int64_t ld_kn,
+                              int32_t kn_bf16, void* w_nk, int64_t ld_nk, int32_t nk_bf16, int32_t k_off, void* stream) {
+  TECM_REQUIRE(lora_B && (w_kn || w_nk), TECM_E_ARG, "tecm_lora_fold: null pointer");
+  TECM_REQUIRE(n_out > 0 && r > 0 && k_off >= 0 && (!w_kn || ld_kn >= n_out) && (!w_nk || ld_nk >= k_off + r), TECM_E_ARG,
+               "tecm_lora_fold: bad shape");
+  const int total = n_out * r;
+  const dim3 grid((total + 255) / 256), blk(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (kn_bf16 && nk_bf16)
+    hipLaunchKernelGGL((lora_fold_kernel<__bf16, __bf16>), grid, blk, 0, st, lora_B, n_out, r, scale, static_cast<__bf16*>(w_kn),
+                       ld_kn, static_cast<__bf16*>(w_nk), ld_nk, k_off);
+  else if (kn_bf16)
+    hipLaunchKernelGGL((lora_fold_kernel<__bf16, float>), grid, blk, 0, st, lora_B, n_out, r, scale, static_cast<__bf16*>(w_kn),
+                       ld_kn, static_cast<float*>(w_nk), ld_nk, k_off);
+  else if (nk_bf16)
+    hipLaunchKernelGGL((lora_fold_kernel<float, __bf16>), grid, blk, 0, st, lora_B, n_out, r, scale, static_cast<float*>(w_kn),
+                       ld_kn, static_cast<__bf16*>(w_nk), ld_nk, k_off);
+  else
+    hipLaunchKernelGGL((lora_fold_kernel<float, float>), grid, blk, 0, st, lora_B, n_out, r, scale, static_cast<float*>(w_kn),
+                       ld_kn, static_cast<float*>(w_nk), ld_nk, k_off);
+  TECM_CHECK_LAUNCH("tecm_lora_fold");
+  return TECM_OK;
+}
+
+extern "C" int tecm_pack_vectors(const float* const* srcs, const int32_t* lens, int32_t count, float* dst, void* stream) {
+  TECM_REQUIRE(srcs && lens && dst && count > 0 && count <= 12, TECM_E_ARG, "tecm_pack_vectors: 1..12 vectors");
+  PackVecArgs a;
+  int longest = 0;
+  for (int v = 0; v < 12; ++v) {
+    a.src[v] = v < count ? srcs[v] : nullptr;
+    a.len[v] = v < count ? lens[v] : 0;
+    TECM_REQUIRE(v >= count || (srcs[v] && lens[v] > 0), TECM_E_ARG, "tecm_pack_vectors: null / empty vector %d", v);
+    if (a.len[v] > longest) longest = a.len[v];
+  }
+  a.count = count;
+  hipLaunchKernelGGL(pack_vectors_kernel, dim3((longest + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, dst);
+  TECM_CHECK_LAUNCH("tecm_pack_vectors");
+  return TECM_OK;
+}
+
 extern "C" int tecm_cast_bf16(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int32_t cols,
                               void* stream) {
   TECM_REQUIRE(src && dst && rows > 0 && cols > 0, TECM_E_ARG, "tecm_cast_bf16: bad arguments");
@@ -148,6 +244,25 @@ extern "C" int tecm_huber_fwd_bwd(const float* pred, const float* target, float*
   TECM_CHECK_LAUNCH("tecm_huber_fwd_bwd/stage1");
   hipLaunchKernelGGL(huber_stage2, dim3(1), dim3(256), 0, st, workspace, nb, loss_out, 1.0f / (float)n);
   TECM_CHECK_LAUNCH("tecm_huber_fwd_bwd/stage2");
+  return TECM_OK;
+}
+
+extern "C" int tecm_huber_fwd_bwd_strided(const float* pred, const int64_t* pred_strides, const float* target,
+                                          const int64_t* target_strides, float* dpred, float* loss_out, int32_t B, int32_t H,
+                                          int32_t N, float delta, float grad_scale, float* workspace, void* stream) {
+  TECM_REQUIRE(pred && target && loss_out && workspace && pred_strides && target_strides, TECM_E_ARG,
+               "tecm_huber_fwd_bwd_strided: null pointer");
+  TECM_REQUIRE(B > 0 && H > 0 && N > 0 && delta > 0.f, TECM_E_ARG, "tecm_huber_fwd_bwd_strided: bad shape / delta");
+  const int64_t n = (int64_t)B * H * N;
+  HuberStrides s{pred_strides[0], pred_strides[1], pred_strides[2], target_strides[0], target_strides[1], target_strides[2], H, N};
+  const int64_t want = (n + 255) / 256;
+  const int nb = (int)(want < 1024 ? want : 1024);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(huber_stage1_strided, dim3(nb), dim3(256), 0, st, pred, target, dpred, workspace, n, delta,
+                     grad_scale / (float)n, s);
+  TECM_CHECK_LAUNCH("tecm_huber_fwd_bwd_strided/stage1");
+  hipLaunchKernelGGL(huber_stage2, dim3(1), dim3(256), 0, st, workspace, nb, loss_out, 1.0f / (float)n);
+  TECM_CHECK_LAUNCH("tecm_huber_fwd_bwd_strided/stage2");
   return TECM_OK;
 }
 

@@ -159,6 +159,11 @@ EXPORTS = {
                               C.c_int32, C.c_float, C.POINTER(TecmDrop), c_f32p, C.c_void_p]),
     "tecm_huber_fwd_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_float, C.c_float, c_f32p,
                                      C.c_void_p]),
+    "tecm_huber_fwd_bwd_strided": (C.c_int, [c_f32p, C.POINTER(C.c_int64), c_f32p, C.POINTER(C.c_int64), c_f32p, c_f32p,
+                                             C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, c_f32p, C.c_void_p]),
+    "tecm_lora_fold": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
+                                 C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    "tecm_pack_vectors": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int32, c_f32p, C.c_void_p]),
     "tecm_conv_weight_pack": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "tecm_conv_weight_unpack": (C.c_int, [c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "tecm_conv_dx_pack": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

@@ -139,8 +139,12 @@ class SpatialFn(torch.autograd.Function):
         Cc = C_FEAT
         pld = 2 * Cc * Cc + 4 * Cc
         partials = _empty(nblocks, pld, like=x)
-        d_node, d_tod, d_doy = torch.zeros_like(node_tab), torch.zeros_like(tod_tab), torch.zeros_like(doy_tab)
-        d_year, d_season = torch.zeros_like(year_tab), torch.zeros_like(season_tab)
+        tabs = (node_tab, tod_tab, doy_tab, year_tab, season_tab)          # the kernel accumulates into them: ONE zero fill
+        zbuf = torch.zeros(sum(t.numel() for t in tabs), device=x.device, dtype=torch.float32)
+        offs = [0]
+        for t in tabs:
+            offs.append(offs[-1] + t.numel())
+        d_node, d_tod, d_doy, d_year, d_season = (zbuf[a:b].view_as(t) for t, a, b in zip(tabs, offs[:-1], offs[1:]))
         g = TecmSpatialGrads()
         g.dout = dout.data_ptr()
         g.d_node_tab, g.d_tod_tab, g.d_doy_tab = d_node.data_ptr(), d_tod.data_ptr(), d_doy.data_ptr()
@@ -302,11 +306,19 @@ class ConvBlockFn(torch.autograd.Function):
         # otherwise (bf16x3 / bf16x6 modes, odd shapes) three window GEMMs, one 64- / 128-column slice each
         seq_in = inp16 if (side16 and inp16 is not None) else (inp if int(bf16) == ops.PREC_FP32 else None)
         fwd_seq = seq_in is not None and ops.conv_fwd_seq_ok(Lc, Cout, ld_in, f32=seq_in.dtype == torch.float32)
+        # bias | gamma | beta of the three branches as the 3*Cout vectors the kernels read: one launch, not three cats
+        bgb = ops.pack_vectors([b3, b5, b7, g3, g5, g7, be3, be5, be7])
+        bias3, gamma, beta = bgb[:CT], bgb[CT:2 * CT], bgb[2 * CT:]
         if fwd_seq:
-            ops.conv_fwd(seq_in.detach(), w3.detach(), w5.detach(), w7.detach(), torch.cat([b3, b5, b7]).detach(), y, B, Lc,
-                         N, Cout, cin, ld_in)
+            ops.conv_fwd(seq_in.detach(), w3.detach(), w5.detach(), w7.detach(), bias3, y, B, Lc, N, Cout, cin, ld_in)
+        # the window-GEMM operands ([Cout][k*ld_in] forward, [k*Cout][ld_in] d-input) are only packed when a GEMM will read
+        # them: the forward below, or a backward whose sequence-tile kernels do not serve this shape / precision
+        dx_gemm = need_dinp and not ConvBlockFn._dx_seq(bf16, r16, Lc, Cout, ld_in)
         for j, (w, b) in enumerate(zip(ws, bs)):
             k = w.shape[2]
+            if fwd_seq and not dx_gemm:
+                packs.append(w.new_empty(0))
+                continue
             wp = w if ld_in == cin else torch.nn.functional.pad(w, (0, 0, 0, ld_in - cin))
             fp, bp = ops.conv_weight_pack(wp.contiguous(), want_bwd=True)
             packs.append(bp)
@@ -315,8 +327,6 @@ class ConvBlockFn(torch.autograd.Function):
             a_in = inp16 if (inp16 is not None and side16 and ld_in % 8 == 0) else inp
             gemm(M, Cout, k * ld_in, a_in, ld_in, fp, k * ld_in, y, CT, c_off=j * Cout,
                  a_win=win(N, Lc, Lc, 1, k, ld_in, (k - 1) // 2), bias=b, bf16=bf16)
-        gamma = torch.cat([g3, g5, g7])
-        beta = torch.cat([be3, be5, be7])
         act = torch.empty(B, Lc, N, CT, device=inp.device, dtype=adt)
         stats = _empty(B * N, 3, 2, like=inp)
         ops.groupnorm_gelu_fwd(y, gamma, beta, act, stats, B, Lc, N, Cout)
@@ -338,6 +348,12 @@ class ConvBlockFn(torch.autograd.Function):
         ctx.inp16 = inp16 if (side16 and inp16 is not None and ld_in % 8 == 0) else None   # dW reads it instead of inp
         ctx.dims = (B, Lc, N, ld_in, cin, Cout, stride, Lo, need_dinp, bf16)
         return out, out16
+
+    @staticmethod
+    def _dx_seq(bf16, dy16: bool, Lc: int, Cout: int, ld_in: int) -> bool:
+        """Does the one-launch d-input kernel serve this block?  (dy16: the backward's dy is a bf16 tensor)"""
+        return int(bf16) in (ops.PREC_FP32, ops.PREC_BF16) and (dy16 or int(bf16) == ops.PREC_FP32) \
+            and ops.conv_dx_seq_ok(Lc, Cout, ld_in, f32=not dy16)
 
     @staticmethod
     def backward(ctx, dout, _dout16=None):
@@ -362,9 +378,7 @@ class ConvBlockFn(torch.autograd.Function):
         # d inp of the three kernel sizes in ONE launch that reads dy once (csrc/conv_seq.hip) instead of three
         # accumulating window GEMMs: exact fp32 from an fp32 dy, the bf16 mode's roundings from a bf16 dy (the bf16x3 /
         # bf16x6 modes keep the GEMM path)
-        dx_seq = need_dinp and int(bf16) in (ops.PREC_FP32, ops.PREC_BF16) \
-            and (dy.dtype == torch.bfloat16 or int(bf16) == ops.PREC_FP32) \
-            and ops.conv_dx_seq_ok(Lc, Cout, ld_in, f32=dy.dtype == torch.float32)
+        dx_seq = need_dinp and ConvBlockFn._dx_seq(bf16, dy.dtype == torch.bfloat16, Lc, Cout, ld_in)
         if dx_seq:
             ops.conv_dx(dy, ctx.w357[0], ctx.w357[1], ctx.w357[2], dinp, B, Lc, N, Cout, cin, ld_in)
         grads = []
@@ -482,6 +496,17 @@ def _frozen_copy(W: torch.Tensor, kind: str) -> Optional[torch.Tensor]:
         out = Wd.t().contiguous().bfloat16()
     elif kind == "kn16":
         out = Wd.contiguous().bfloat16()
+    elif kind in ("kext_kn32", "kext_kn16", "kext_nk32", "kext_nk16"):
+        # K-extended c_attn operands with room for the LoRA slice (ops.lora_fold refreshes it every step):
+        # "kext_kn*" = [ W ; 0 ] as [K + r][N] (backward), "kext_nk*" = [ W^T | 0 ] as [N][K + r] (forward)
+        K, N = Wd.shape
+        dt = torch.bfloat16 if kind.endswith("16") else torch.float32
+        if "_kn" in kind:
+            out = torch.zeros(K + LORA_R, N, device=W.device, dtype=dt)
+            out[:K].copy_(Wd)
+        else:
+            out = torch.zeros(N, K + LORA_R, device=W.device, dtype=dt)
+            out[:, :K].copy_(Wd.t())
     else:
         raise ValueError(kind)
     _NK_CACHE[key] = (weakref.ref(W), W._version, W.data_ptr(), out)
@@ -542,14 +567,14 @@ class GPT2StackFn(torch.autograd.Function):
              bpr) = params[i * GPT2StackFn.PER_LAYER:(i + 1) * GPT2StackFn.PER_LAYER]
             F3, F4 = Wqkv.shape[1], Wfc.shape[1]
             b16 = int(plan.bf16) == ops.PREC_BF16           # bf16 mode: weights and GEMM-only activations live in HBM as bf16
-            WqkvT = _frozen_copy(Wqkv, "nk16" if b16 else "nk32")
+            wcatT = _frozen_copy(Wqkv, "kext_nk16" if b16 else "kext_nk32")   # [ W^T | (alpha/r) B ]: forward operand
             Wo_f, ldo_f, lay_o = _fwd_weight(Wo, D, D, plan.bf16)
             Wfc_f, ldfc_f, lay_fc = _fwd_weight(Wfc, D, F4, plan.bf16)
             Wpr_f, ldpr_f, lay_pr = _fwd_weight(Wpr, F4, D, plan.bf16)
             # Activations whose ONLY reader is a bf16 GEMM are written as bf16 by their producer (rounded once there
             # instead of in that GEMM's loader: bit-identical, half the bytes both ways): LN1's output for c_attn, the
             # attention context for attn.c_proj, LN2's output for c_fc, gelu(c_fc) for mlp.c_proj.
-            a16 = b16 and all(w is not None and w.dtype == torch.bfloat16 for w in (WqkvT, Wo_f, Wfc_f, Wpr_f))
+            a16 = b16 and all(w is not None and w.dtype == torch.bfloat16 for w in (wcatT, Wo_f, Wfc_f, Wpr_f))
             u = _empty(M, KE, like=h)                       # [ LN1(h) | z = drop(LN1(h)) A^T ]  (fp32: the LoRA gradients read it)
             u16 = torch.empty(M, KE, device=h.device, dtype=torch.bfloat16) if a16 else None
             st1 = _empty(M, 2, like=h)
@@ -558,21 +583,16 @@ class GPT2StackFn(torch.autograd.Function):
             gemm(M, LORA_R, D, u, KE, lA, D, u, KE, c_off=D, a_drop=lspec, bf16=plan.bf16)
             if a16:
                 ops.cast_bf16(u, KE, u16, KE, M, LORA_R, src_off=D, dst_off=D)
-            wcat = _empty(KE, F3, like=h)                   # [ W ; (alpha/r) B^T ]  K-extended c_attn (backward operand)
-            wcat[:D].copy_(Wqkv)
-            ops.transpose_scale(lB, LORA_R, wcat, F3, LORA_R, F3, LORA_SCALE, dst_off=D * F3)
+            # [ W ; (alpha/r) B^T ]  K-extended c_attn, backward operand ([KE][F3]) and forward operand ([F3][KE]): the
+            # frozen 768 x 2304 part of both is cached per parameter version (_frozen_copy), ONE launch refreshes the 32
+            # LoRA rows / columns of both from lora_B.  (The buffers are the cache's: they are rewritten by the next
+            # forward of this layer, i.e. after the backward that reads `wcat` has run.)
+            wcat = _frozen_copy(Wqkv, "kext_kn16" if b16 else "kext_kn32")
+            ops.lora_fold(lB.detach(), LORA_SCALE, wcat, wcatT, D)
             # bf16 mode: qkv is written as bf16 by the c_attn GEMM (what a Linear's output is under autocast) and read as
             # such by the attention kernels, forward and backward: 644 -> 322 MB per layer, three times over
             qkv = torch.empty(M, F3, device=h.device, dtype=torch.bfloat16 if (a16 and QKV16) else torch.float32)
-            if WqkvT is not None:                           # forward operand in [N][K] form: [ W^T | (alpha/r) B ]
-                wcatT = torch.empty(F3, KE, device=h.device, dtype=WqkvT.dtype)
-                wcatT[:, :D].copy_(WqkvT)
-                wcatT[:, D:].copy_(lB.detach() * LORA_SCALE)
-                if b16:                                     # the backward's [KE][F3] operand in bf16 as well
-                    wcat = wcat.bfloat16()
-                gemm(M, F3, KE, u16 if a16 else u, KE, wcatT, KE, qkv, F3, b_layout=B_NK, bias=bqkv, bf16=plan.bf16)
-            else:
-                gemm(M, F3, KE, u, KE, wcat, F3, qkv, F3, b_layout=B_KN, bias=bqkv, bf16=plan.bf16)
+            gemm(M, F3, KE, u16 if a16 else u, KE, wcatT, KE, qkv, F3, b_layout=B_NK, bias=bqkv, bf16=plan.bf16)
             cx = torch.empty(M, D, device=h.device, dtype=torch.bfloat16 if a16 else torch.float32)
             aspec = plan.spec(site_attn(i), 1)
             ops.attention_fwd(qkv, cx, B, T, N, GPT_HEADS, D, aspec)
@@ -751,14 +771,17 @@ class HuberFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pred, target, delta: float):
-        p = pred.contiguous()
-        t = target.contiguous()
-        loss, dpred = ops.huber_fwd_bwd(p, t, delta, 1.0, want_grad=True)
+        if pred.dim() == 4 and pred.shape[3] == 1 and pred.shape == target.shape:
+            # the model's permuted output view and the target, each in its own layout: no contiguous copies, and the
+            # gradient comes back in the prediction's storage order (what the head's backward reads)
+            loss, dpred = ops.huber_fwd_bwd_strided(pred, target, delta, 1.0, want_grad=True)
+        else:
+            loss, dpred = ops.huber_fwd_bwd(pred.contiguous(), target.contiguous(), delta, 1.0, want_grad=True)
+            dpred = dpred.view(pred.shape)
         ctx.save_for_backward(dpred)
-        ctx.shape = pred.shape
         return loss[0]
 
     @staticmethod
     def backward(ctx, gloss):
         (dpred,) = ctx.saved_tensors
-        return dpred.view(ctx.shape) * gloss, None, None
+        return dpred * gloss, None, None

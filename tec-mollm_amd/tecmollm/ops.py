@@ -410,6 +410,53 @@ def huber_fwd_bwd(pred: torch.Tensor, target: torch.Tensor, delta: float = 1.0, 
     return loss, dpred
 
 
+def huber_fwd_bwd_strided(pred: torch.Tensor, target: torch.Tensor, delta: float = 1.0, grad_scale: float = 1.0,
+                          want_grad: bool = True) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """HuberLoss(delta, mean) of pred (B, H, N, 1) against target (same shape), each in its own layout (any strides): no
+    contiguous copies.  Returns (loss (1,), dpred with pred's shape AND strides -- or None)."""
+    if pred.shape != target.shape or pred.dim() != 4 or pred.shape[3] != 1:
+        raise _lib.TecmError("huber_fwd_bwd_strided: pred and target are (B, L_out, N, 1) tensors of one shape")
+    _lib.require_gpu_tensor(pred, "pred")
+    _lib.require_gpu_tensor(target, "target")
+    B, H, N, _ = pred.shape
+    loss = torch.empty(1, device=pred.device, dtype=torch.float32)
+    dpred = torch.empty_strided(pred.shape, pred.stride(), device=pred.device, dtype=torch.float32) if want_grad else None
+    if want_grad and max(st * (sz - 1) for st, sz in zip(pred.stride(), pred.shape)) + 1 > pred.numel():
+        raise _lib.TecmError("huber_fwd_bwd_strided: pred must be a dense (permuted) tensor")
+    ws = torch.empty(1024, device=pred.device, dtype=torch.float32)
+    ps = (C.c_int64 * 3)(*pred.stride()[:3])
+    tst = (C.c_int64 * 3)(*target.stride()[:3])
+    check(lib().tecm_huber_fwd_bwd_strided(pred.data_ptr(), ps, target.data_ptr(), tst, ptr(dpred), loss.data_ptr(), B, H, N,
+                                           delta, grad_scale, ws.data_ptr(), stream_ptr()), "tecm_huber_fwd_bwd_strided")
+    return loss, dpred
+
+
+def lora_fold(lB: torch.Tensor, scale: float, w_kn: Optional[torch.Tensor], w_nk: Optional[torch.Tensor], k_off: int) -> None:
+    """The LoRA rows of [ W ; s B^T ] (w_kn: (k_off + r, n)) and / or the LoRA columns of [ W^T | s B ] (w_nk: (n, k_off + r))
+    from lora_B (n, r); either operand fp32 or bf16, in place."""
+    n, r = lB.shape
+    for w, shape in ((w_kn, (k_off + r, n)), (w_nk, (n, k_off + r))):
+        if w is not None and (tuple(w.shape) != shape or not w.is_contiguous() or w.dtype not in (torch.float32, torch.bfloat16)):
+            raise _lib.TecmError(f"lora_fold: operand must be a contiguous {shape} fp32 / bf16 tensor")
+    check(lib().tecm_lora_fold(lB.data_ptr(), n, r, float(scale), ptr(w_kn), n, int(w_kn is not None and w_kn.dtype == torch.bfloat16),
+                               ptr(w_nk), k_off + r, int(w_nk is not None and w_nk.dtype == torch.bfloat16), k_off,
+                               stream_ptr()), "tecm_lora_fold")
+
+
+def pack_vectors(vecs, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """torch.cat of up to 12 small contiguous fp32 device vectors in ONE launch."""
+    vecs = [v.detach() for v in vecs]
+    if any(v.dtype != torch.float32 or not v.is_contiguous() or v.dim() != 1 for v in vecs) or not 1 <= len(vecs) <= 12:
+        raise _lib.TecmError("pack_vectors: 1..12 contiguous fp32 vectors")
+    total = sum(v.numel() for v in vecs)
+    if out is None:
+        out = torch.empty(total, device=vecs[0].device, dtype=torch.float32)
+    srcs = (C.c_void_p * len(vecs))(*[v.data_ptr() for v in vecs])
+    lens = (C.c_int32 * len(vecs))(*[v.numel() for v in vecs])
+    check(lib().tecm_pack_vectors(srcs, lens, len(vecs), out.data_ptr(), stream_ptr()), "tecm_pack_vectors")
+    return out
+
+
 def conv_weight_pack(w: torch.Tensor, want_bwd: bool = True) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     Cout, Cin, k = w.shape
     fwd = torch.empty(Cout, k * Cin, device=w.device, dtype=torch.float32)

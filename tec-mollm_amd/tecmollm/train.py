@@ -135,8 +135,17 @@ class TrainStep:
         if self.native:
             self.optimizer.detach_grads()              # backward hands its gradient tensors over; one add for all of them
         out = self.model(x, time_features, edge_index, edge_weight)
-        loss = self._loss(out, y)
-        (loss / self.accumulation_steps).backward()
+        if self.native and self.fused_huber and out.dim() == 4 and out.shape[3] == 1 and out.shape == y.shape:
+            # loss and d loss / d out (already divided by accumulation_steps, train.py:78) from ONE strided kernel pair, fed
+            # to autograd as the output gradient: no contiguous copies of the permuted prediction / the target, no ones_like,
+            # no divide, no multiply by the upstream scalar
+            from . import ops
+            loss, dout = ops.huber_fwd_bwd_strided(out.detach(), y, 1.0, 1.0 / self.accumulation_steps)
+            out.backward(dout)
+            loss = loss[0]
+        else:
+            loss = self._loss(out, y)
+            (loss / self.accumulation_steps).backward()
         if self.native:
             self.optimizer.absorb_grads()
         self._micro += 1                               # micro-batches since the last optimizer step (train.py:92: (i+1) % acc

@@ -375,6 +375,65 @@ def test_huber_and_transpose(dev):
     assert torch.equal(dst[8:], 2.0 * src.t()) and float(dst[:8].abs().max()) == 0.0
 
 
+def test_huber_strided_on_the_models_permuted_output_view(dev):
+    """tecm_huber_fwd_bwd_strided: HuberLoss(delta=1, mean) (train.py:372) of the model's permuted (B, L_out, N, 1) view of
+    (B, N, L_out) storage (tec_mollm.py:122-123) against a target in its own layout (train.py:76-78), no contiguous
+    copies; the gradient comes back with the PREDICTION's strides and a folded 1/accumulation_steps."""
+    from tecmollm import TecmError, ops
+    B, N, H = 3, 211, 12
+    store = _rand(B, N, H, dev=dev, seed=1, scale=2.0)
+    pred = store.permute(0, 2, 1).unsqueeze(-1)                        # (B, H, N, 1), strides (N*H, 1, H, .)
+    tgt = _rand(B, 7, 31, H, dev=dev, seed=2)[:, :, :N // 7 + 1].reshape(B, -1, H)[:, :N].permute(0, 2, 1).unsqueeze(-1)
+    assert not pred.is_contiguous() and pred.shape == tgt.shape
+    loss, dp = ops.huber_fwd_bwd_strided(pred, tgt, 1.0, 0.25)
+    pd = pred.double().detach().requires_grad_(True)
+    ref = torch.nn.functional.huber_loss(pd, tgt.double(), delta=1.0)
+    (g,) = torch.autograd.grad(ref, pd)
+    assert abs(loss.item() - ref.item()) < 1e-5 * abs(ref.item()) + 1e-7
+    assert dp.shape == pred.shape and dp.stride() == pred.stride() and _rel(dp, 0.25 * g) < TOL
+    # contiguous target (bench.py's synthetic y) and the contiguous kernel agree
+    tc = tgt.contiguous()
+    loss2, dp2 = ops.huber_fwd_bwd_strided(pred, tc, 1.0, 0.25)
+    loss3, dp3 = ops.huber_fwd_bwd(pred.contiguous(), tc, 1.0, 0.25)
+    assert torch.equal(dp2, dp) and torch.equal(dp2.contiguous(), dp3) and abs(loss2.item() - loss3.item()) < 1e-6
+    with pytest.raises(TecmError):
+        ops.huber_fwd_bwd_strided(pred.squeeze(-1), tgt.squeeze(-1))
+    with pytest.raises(TecmError):
+        ops.huber_fwd_bwd_strided(pred.expand(B, H, N, 1)[:, :, ::2], tgt[:, :, ::2])   # not dense: no layout for the gradient
+
+
+@pytest.mark.parametrize("dt_kn,dt_nk", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16),
+                                         (torch.float32, torch.bfloat16), (torch.bfloat16, None), (None, torch.float32)])
+def test_lora_fold_writes_only_the_lora_slices(dev, dt_kn, dt_nk):
+    """tecm_lora_fold: (alpha/r) * lora_B into rows K.. of [ W ; s B^T ] ([K + r][n]) and columns K.. of [ W^T | s B ]
+    ([n][K + r]) (peft Linear on c_attn, modules.py:177-186), fp32 or bf16, everything else untouched."""
+    from tecmollm import TecmError, ops
+    n, r, K = 2304, 32, 768
+    lB = _rand(n, r, dev=dev, seed=5, scale=0.02)
+    base_kn = _rand(K + r, n, dev=dev, seed=6)
+    base_nk = _rand(n, K + r, dev=dev, seed=7)
+    w_kn = base_kn.to(dt_kn).clone() if dt_kn is not None else None
+    w_nk = base_nk.to(dt_nk).clone() if dt_nk is not None else None
+    ops.lora_fold(lB, 2.0, w_kn, w_nk, K)
+    if w_kn is not None:
+        assert torch.equal(w_kn[:K], base_kn.to(dt_kn)[:K]) and torch.equal(w_kn[K:], (2.0 * lB).t().to(dt_kn))
+    if w_nk is not None:
+        assert torch.equal(w_nk[:, :K], base_nk.to(dt_nk)[:, :K]) and torch.equal(w_nk[:, K:], (2.0 * lB).to(dt_nk))
+    with pytest.raises(TecmError):
+        ops.lora_fold(lB, 2.0, base_kn[:-1], None, K)
+
+
+def test_pack_vectors_is_torch_cat_in_one_launch(dev):
+    from tecmollm import TecmError, ops
+    vecs = [_rand(n, dev=dev, seed=i) for i, n in enumerate((64, 64, 64, 128, 5, 1, 300, 64, 64))]
+    assert torch.equal(ops.pack_vectors(vecs), torch.cat(vecs))
+    assert torch.equal(ops.pack_vectors(vecs[:1]), vecs[0])
+    with pytest.raises(TecmError):
+        ops.pack_vectors(vecs + vecs)                                  # more than 12
+    with pytest.raises(TecmError):
+        ops.pack_vectors([vecs[0].double()])
+
+
 # ----------------------------------------------------------------------------- dropout_apply (tec_mollm.py:115)
 def test_dropout_apply_rejects_what_it_cannot_serve(dev):
     from tecmollm import TecmError, ops

@@ -164,25 +164,6 @@ PRECISION_TEXT = {
 }
 
 
-def pmc_traffic(kernel: str, args, precision: str):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
-    separate runs of this same command, gfx950 corrections applied by tools/pmc_traffic.py); None when the
-    committed passes do not cover this configuration."""
-    if args.batch != 8 or args.L_in != 48 or args.gat != "per_timestep" or precision not in ("fp32", "bf16"):
-        return None
-    for tag in ("r03", "r02", "r01"):
-        rel = os.path.join("profiles", f"{tag}_pmc_traffic_{precision}_B8.json")
-        try:
-            with open(os.path.join(ROOT, rel)) as f:
-                k = json.load(f)["kernels"].get(kernel)
-        except (OSError, KeyError, ValueError):
-            continue
-        if k is not None:
-            return {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "fetch": k["fetch_bytes_per_launch"],
-                    "write": k["write_bytes_per_launch"], "source": rel}
-    return None
-
-
 def cpu_baseline(cfg, args):
     """SURVEY 8d protocol: the CPU oracle's full train step (forward + Huber + backward + clip + AdamW) in training
     mode (dropout masks drawn inside the step, p = 0.1 at every site, as the reference does), fp32, on the host cores
@@ -254,21 +235,142 @@ def rmse_vs_ref(cfg, args, dev, ref):
             "sample": f"eval forward at B={B} on the cpu_baseline batch, scaled units, {out.shape[1]} horizons"}
 
 
-def roofline_of(agg: dict, dt_s: float, args, precision: str):
-    """The GEMM variant with the largest total time inside the timed region: achieved = sum 2MNK / sum event time."""
+ALG_GFLOP_PER_SAMPLE = {48: 887.5, 96: 1822.6}    # fwd + bwd, dX-only for the frozen GPT-2 GEMMs, no recompute
+
+# GPT-2 layer GEMMs (modeling_gpt2.py:262-310 + peft LoRA, modules.py:177-186) by (N, K, epilogue) of their M = B*T*N rows
+_LAYER_SHAPES = [
+    ("c_attn + LoRA-B fwd", lambda n, k, f: n == 2304 and k == 800),
+    ("attn.c_proj fwd (+bias, dropout, residual)", lambda n, k, f: n == 768 and k == 768 and f["res"]),
+    ("mlp.c_fc fwd (+bias, GELU, pre-activation)", lambda n, k, f: n == 3072 and k == 768 and f["pre"]),
+    ("mlp.c_proj fwd (+bias, dropout, residual)", lambda n, k, f: n == 768 and k == 3072 and f["res"]),
+    ("d mlp.c_proj (x GELU')", lambda n, k, f: n == 3072 and k == 768 and f["dact"]),
+    ("d mlp.c_fc", lambda n, k, f: n == 768 and k == 3072 and not f["res"]),
+    ("d attn.c_proj", lambda n, k, f: n == 768 and k == 768 and not f["res"]),
+    ("d c_attn (+ d z)", lambda n, k, f: n == 800 and k == 2304),
+]
+
+
+def _parse_detail(key: str):
+    """'kernel M=.. N=.. K=.. win=000 drop=000 split=1 act=0 acc=0 dact=0 res=0 pre=0' -> (kernel, dict)."""
+    parts = key.split(" ")
+    kern = parts[0]
+    f = {}
+    for tok in parts[1:]:
+        if "=" in tok:
+            k, v = tok.split("=", 1)
+            f[k] = v
+    return kern, f
+
+
+def latest_profile_json(precision: str, args):
+    """The newest committed PMC traffic summary of this configuration (profiles/rNN_pmc_traffic_<prec>_B8.json)."""
+    if args.batch != 8 or args.L_in != 48 or args.gat != "per_timestep" or precision not in ("fp32", "bf16"):
+        return None, None
+    for tag in ("r04", "r03", "r02", "r01"):
+        rel = os.path.join("profiles", f"{tag}_pmc_traffic_{precision}_B8.json")
+        try:
+            with open(os.path.join(ROOT, rel)) as f:
+                return json.load(f)["kernels"], rel
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
+def pmc_traffic(kernel: str, args, precision: str):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
+    separate runs of this same command, gfx950 corrections applied by tools/make_profiles.py); None when the
+    committed passes do not cover this configuration."""
+    kernels, rel = latest_profile_json(precision, args)
+    k = (kernels or {}).get(kernel.split("<")[0] if kernel.startswith("gemm_bf16_dma6") else kernel)
+    if k is None:
+        return None
+    return {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "fetch": k["fetch_bytes_per_launch"],
+            "write": k["write_bytes_per_launch"], "source": rel}
+
+
+def non_gemm_block(args, precision: str):
+    """The largest kernels of the step that are NOT dense contractions -- HBM-bound by construction -- with the HBM-side
+    bytes per launch and the rate from the committed PMC passes (counter traffic / average duration under the counters)."""
+    kernels, rel = latest_profile_json(precision, args)
+    if not kernels:
+        return None
+    rows = []
+    for name, k in kernels.items():
+        if "gemm" in name or "conv_fwd_seq" in name or "conv_dx_seq" in name or "conv_dw_seq" in name or k["avg_us_under_pmc"] <= 0:
+            continue
+        tot = k["avg_us_under_pmc"] * k["launches"]
+        rate = k["hbm_bytes_per_launch"] / (k["avg_us_under_pmc"] * 1e-6) / 1e9
+        rows.append((tot, {"kernel": name, "launches_in_trace": k["launches"], "avg_us": k["avg_us_under_pmc"],
+                           "hbm_mb_per_launch": round(k["hbm_bytes_per_launch"] / 1e6, 1), "achieved_gbs": round(rate, 1),
+                           "frac_of_hbm_peak": round(rate / HBM_PEAK_GBS, 3)}))
+    rows.sort(key=lambda r: -r[0])
+    return {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "source": rel,
+            "note": "counter traffic (FETCH_SIZE x2 + WRITE_SIZE) per launch / average launch duration in the PMC pass",
+            "kernels": [r[1] for r in rows[:8]]}
+
+
+def roofline_of(agg: dict, step_ms: float, steps: int, args, precision: str, batch: int, L_in: int):
+    """agg: per-call-site GEMM records (ops.enable_gemm_timing(detail=True)) of `steps` steps taken in a SEPARATE short
+    pass after the timed region (`value` carries no event bracketing).  Headline = the kernel with the largest total
+    time: achieved = sum 2MNK / sum event time against the dense MFMA peak of its dtype.  `shapes` = every large GEMM
+    call site with its own bound: max(flops / MFMA peak, algorithmic bytes / 8 TB/s)."""
     if not agg:
         return None
-    name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
+    by_kernel: dict = {}
+    for key, a in agg.items():
+        kern, _ = _parse_detail(key)
+        t = by_kernel.setdefault(kern, {"ms": 0.0, "flops": 0.0, "n": 0})
+        t["ms"] += a["ms"]; t["flops"] += a["flops"]; t["n"] += a["n"]
+    name, a = max(by_kernel.items(), key=lambda kv: kv[1]["ms"])
     achieved = a["flops"] / (a["ms"] * 1e-3) / 1e12
     peak = BF16_MFMA_PEAK_TFLOPS if ("bf16" in name or "x3" in name) else F32_MFMA_PEAK_TFLOPS
     if "x3_kernel<2" in name:
         achieved *= 3.0                                # three bf16 MFMA products per fp32 product
     elif "x3_kernel<3" in name:
         achieved *= 6.0
+    shapes = []
+    for key, r in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+        kern, f = _parse_detail(key)
+        if "M" not in f or r["flops"] / r["n"] < 2e10:
+            continue
+        n_, k_ = int(f["N"]), int(f["K"])
+        flags = {"res": f.get("res") == "1", "pre": f.get("pre") == "1", "dact": f.get("dact") == "1"}
+        label = next((lab for lab, pred in _LAYER_SHAPES if int(f["M"]) == batch * 2911 * (L_in // 16) and pred(n_, k_, flags)), None)
+        pk = BF16_MFMA_PEAK_TFLOPS if ("bf16" in kern or "x3" in kern) else F32_MFMA_PEAK_TFLOPS
+        fl, by, us = r["flops"] / r["n"], r["bytes"] / r["n"], r["ms"] / r["n"] * 1e3
+        t_mfma, t_hbm = fl / (pk * 1e12) * 1e6, by / (HBM_PEAK_GBS * 1e9) * 1e6
+        shapes.append({"site": label or "other", "kernel": kern, "M": int(f["M"]), "N": n_, "K": k_,
+                       "launches_per_step": round(r["n"] / steps, 2), "avg_us": round(us, 1), "gflop": round(fl / 1e9, 1),
+                       "algorithmic_mb": round(by / 1e6, 1), "t_mfma_us": round(t_mfma, 1), "t_hbm_us": round(t_hbm, 1),
+                       "bound": "mfma" if t_mfma >= t_hbm else "hbm", "frac_of_bound": round(max(t_mfma, t_hbm) / us, 3),
+                       "tflops": round(fl / us / 1e6, 1), "gbs": round(by / us / 1e3, 1)})
+    gf = ALG_GFLOP_PER_SAMPLE.get(L_in)
+    step = None
+    if gf is not None:
+        tf = gf * batch / step_ms / 1e3
+        step_peak = BF16_MFMA_PEAK_TFLOPS if precision in ("bf16", "bf16x3", "bf16x6") else F32_MFMA_PEAK_TFLOPS
+        step = {"algorithmic_tflops": round(tf, 1), "peak": step_peak, "frac_of_peak": round(tf / step_peak, 4),
+                "gflop_per_sample": gf, "note": "SURVEY 8d algorithmic flops (fwd + bwd, no recompute) x samples / step time"}
+    all_ms = sum(v["ms"] for v in by_kernel.values()) / steps
     return {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": pmc_traffic(name, args, precision), "launches": a["n"],
-            "avg_launch_ms": round(a["ms"] / a["n"], 4), "share_of_step": round(a["ms"] / (dt_s * 1e3), 4),
-            "all_gemm_share_of_step": round(sum(v["ms"] for v in agg.values()) / (dt_s * 1e3), 4)}
+            "avg_launch_ms": round(a["ms"] / a["n"], 4), "share_of_step": round(a["ms"] / steps / step_ms, 4),
+            "all_gemm_share_of_step": round(all_ms / step_ms, 4),
+            "timing": f"events on the launch stream around every GEMM in a separate pass of {steps} steps after the timed "
+                      "region (the timed steps carry no event bracketing)",
+            "step": step, "shapes": shapes[:14], "non_gemm": non_gemm_block(args, precision)}
+
+
+def shape_pass(ts, batch_fn, ei, ew, steps: int = 3):
+    """Per-call-site GEMM timing of `steps` extra steps (not part of `value`)."""
+    from tecmollm import ops
+    rec = ops.enable_gemm_timing(detail=True)
+    for _ in range(steps):
+        xb, tfb, yb = batch_fn()
+        ts.step(xb, tfb, ei, ew, yb)
+    agg = ops.summarize_gemm_timing(rec)
+    ops.disable_gemm_timing()
+    return agg, steps
 
 
 def extra_config(cfg, args, dev, mode, ei, ew, workload, L_in=None, L_out=None, with_roofline=True, steps=10):
@@ -298,18 +400,17 @@ def extra_config(cfg, args, dev, mode, ei, ew, workload, L_in=None, L_out=None, 
     for _ in range(3):
         ts.step(x, tf, ei, ew, y)
     torch.cuda.synchronize()
-    prof = ops.enable_gemm_timing() if with_roofline else None
     t0 = time.perf_counter()
     for _ in range(steps):
         ts.step(x, tf, ei, ew, y)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    ops.disable_gemm_timing()
     res = {"samples_per_s": round(steps * B / dt, 2), "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps,
            "dtype": {"fp32": "f32"}.get(mode, mode), "workload": workload}
     if with_roofline:
         a2.precision = mode
-        res["roofline"] = roofline_of(ops.summarize_gemm_timing(prof), dt, a2, mode)
+        agg, nsteps = shape_pass(ts, lambda: (x, tf, y), ei, ew)
+        res["roofline"] = roofline_of(agg, dt / steps * 1e3, nsteps, a2, mode, B, a2.L_in)
     del ts, model
     torch.cuda.empty_cache()
     return res
@@ -414,7 +515,7 @@ def main():
     graph_.get(ei, 2911, dev, 22 - args.c_in)          # host-side CSR / tile windows of the graph (cached per process)
     host_graph_s = time.perf_counter() - t_setup
     ts = TrainStep(model, world_size=world, time_collective=True)   # rank 0's parameters broadcast (train.py:354)
-    feed = WindowFeed(args, dev, rank, args.warmup + args.steps) if args.data == "window" else None
+    feed = WindowFeed(args, dev, rank, args.warmup + args.steps + 3) if args.data == "window" else None   # + the shape pass
 
     def batch(timed):
         return feed.next(timed) if feed is not None else (x, tf, y)
@@ -432,7 +533,6 @@ def main():
         ts.step(xb, tfb, ei, ew, yb)
     barrier()
     ts.reset_collective_timing()
-    prof = None if args.no_kernel_timing else ops.enable_gemm_timing()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     marks[0].record()
@@ -442,8 +542,11 @@ def main():
         marks[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
-    ops.disable_gemm_timing()
     check_device_errors(dev, sync=True)                # bad time indices / diverged ranks reported by any step
+    # the roofline's per-GEMM events are collected in a SEPARATE short pass: `value` above carries no event bracketing
+    shape_agg = None
+    if not args.no_kernel_timing:                      # every rank runs it: the steps contain the collective
+        shape_agg = shape_pass(ts, lambda: batch(False), ei, ew)
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]      # this rank's device time per step
     if world > 1:
@@ -476,7 +579,8 @@ def main():
 
     if rank == 0:
         total = B * world * args.steps
-        roof = roofline_of(ops.summarize_gemm_timing(prof), dt, args, args.precision) if prof is not None else None
+        roof = roofline_of(shape_agg[0], dt / args.steps * 1e3, shape_agg[1], args, args.precision, B, args.L_in) \
+            if shape_agg is not None else None
         line = {
             "metric": "train samples/sec", "value": round(total / dt, 3), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -193,14 +193,19 @@ int tecm_spatial_bwd_blocks(const TecmSpatial* d);
  * its only readers are bf16 matrix-core GEMMs that would round it in their loaders (train.py:68 autocast semantics).
  * y, the statistics and all arithmetic stay fp32. */
 #define TECM_GN_OUT_BF16 2
+/* backward only, with TECM_GN_OUT_BF16: dact is a bf16 tensor (written by the bf16 GEMM of the strided 1x1 conv's d-input) */
+#define TECM_GN_DACT_BF16 4
+/* act_stride s >= 1: only the time steps t % s == 0 are written, into a COMPACT (B, ceil(L / s), N, CT) tensor -- the
+ * stride-s 1x1 conv behind the block (modules.py:36-41) reads nothing else; the statistics cover every step.  s > 1 is
+ * served by the register-resident kernels only (TECM_E_ARG otherwise: callers ask tecm_gn_reg_ok first). */
 int tecm_groupnorm_gelu_fwd(const void* y, const float* gamma, const float* beta, void* act,
                             float* stats, int32_t B, int32_t L, int32_t N, int32_t Cout, float eps,
-                            int32_t io_bf16, void* stream);
+                            int32_t io_bf16, int32_t act_stride, void* stream);
 /* dact is (B, L/dstride, N, CT): the gradient exists only at t % dstride == 0 (stride-s 1x1 conv).
  * dgb_partials: (num_blocks, 3*CT) per-block [dgamma | dbeta | column sums of dy] -- the last third is the
  * gradient of the Conv1d biases in front of the norm (modules.py:27), free here since dy is being written;
  * returns num_blocks via *num_blocks when dy == NULL (query mode, nothing launched). */
-int tecm_groupnorm_gelu_bwd(const float* dact, int32_t dstride, const void* y, const float* gamma,
+int tecm_groupnorm_gelu_bwd(const void* dact, int32_t dstride, const void* y, const float* gamma,
                             const float* beta, const float* stats, void* dy, float* dgb_partials,
                             int32_t* num_blocks, int32_t B, int32_t L, int32_t N, int32_t Cout,
                             int32_t io_bf16, void* stream);
@@ -210,18 +215,31 @@ int tecm_groupnorm_gelu_bwd(const float* dact, int32_t dstride, const void* y, c
 /* y (fp32) and / or y16 (bf16, RNE): the bf16 copy feeds a bf16 matrix-core GEMM (BASELINE configs[2]) that would
  * round the fp32 value in its loader anyway -- same bits, half the bytes; either pointer may be NULL, not both. */
 int tecm_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y,
-                       int64_t ldy, void* y16, int64_t ldy16, float* stats /* (M,2) mean,rstd */, int64_t M, int32_t D,
-                       float eps, void* stream);
+                       int64_t ldy, void* y16, int64_t ldy16,
+                       void* y16d /* optional third output: bf16(dropout(y, drop)) -- the LoRA branch's input, peft
+                                     lora_dropout in front of lora_A (modules.py:181), cast as autocast casts it */,
+                       int64_t ldy16d, const TecmDrop* drop /* of y16d; element index row*drop->ld + c */,
+                       float* stats /* (M,2) mean,rstd */, int64_t M, int32_t D, float eps, void* stream);
 /* dx = dres (optional) + LN'(dy).  Optional second output dx_masked = dropout(dx, mask_drop): the
  * residual-stream gradient is consumed twice in GPT2Block's backward, once as is (residual path) and
  * once through the resid dropout in front of a GEMM; emitting the masked copy here costs one extra
  * store instead of one hash per element per GEMM column tile.  dgb_partials (num_blocks, 2*D);
  * dx == NULL only queries *num_blocks. */
 /* masked_bf16 != 0: dx_masked is a bf16 (M, D) matrix (its only reader is a bf16 GEMM). */
+/* Optional LoRA back-path folded into dy before the LayerNorm backward (peft Linear on c_attn, modules.py:177-186):
+ *   dy[row][c] += keep(row*drop.ld + c) / (1 - p) * sum_j dz[row][j] * A[j][c],   dz (M, r) fp32, A = lora_A (r, D) fp32;
+ * bf16_operands != 0: dz and A are rounded to bf16 first (the bf16 mode's contraction), accumulation is fp32 either way. */
+typedef struct TecmLoraBack {
+  const float* dz;
+  int64_t ld_dz;
+  const float* A;
+  int32_t r, bf16_operands;
+  TecmDrop drop;
+} TecmLoraBack;
 int tecm_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                        const float* stats, const float* dres, float* dx, void* dx_masked, int32_t masked_bf16,
                        const TecmDrop* mask_drop, float* dgb_partials, int32_t* num_blocks, int64_t M, int32_t D,
-                       void* stream);
+                       const TecmLoraBack* lora /* NULL: none */, void* stream);
 
 /* Causal multi-head self-attention over T tokens per sequence (GPT2Attention, modeling_gpt2.py:54-73,
  * :144-226; all-ones attention_mask tec_mollm.py:111 => pure causal).  qkv: (B,T,N,3*D) time-major

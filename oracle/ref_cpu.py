@@ -192,6 +192,34 @@ def stored(t: torch.Tensor, q: "Rounding") -> torch.Tensor:
     return t if q.fwd is None else _StoreRounded.apply(t, q.fwd)
 
 
+class _GradStoreRounded(torch.autograd.Function):
+    """Identity whose GRADIENT is rounded where it is stored: a backward tensor kept in bf16 between the contraction that
+    produces it and a non-contraction reader (the gradient at the strided 1x1 conv's input, read by the GroupNorm + GELU
+    backward -- what the backward of a bf16 Conv1d hands to fp32 ops under autocast)."""
+
+    @staticmethod
+    def forward(ctx, t, fn):
+        ctx.fn = fn
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.fn(g), None
+
+
+def grad_stored(t: torch.Tensor, q: "Rounding") -> torch.Tensor:
+    return t if q.bwd is None else _GradStoreRounded.apply(t, q.bwd)
+
+
+def conv_acts_bf16(L: int, Cout: int) -> bool:
+    """Mirror of the device policy (tecmollm/ops.py:gn_reg_ok, ConvBlockFn): the conv block keeps its activations behind
+    the GroupNorm -- and the gradient at the 1x1 conv's input -- as bf16 tensors only when the register-resident norm
+    kernels serve the sequence (L * 3*Cout/4 quads over 4 or 8 waves, at most 9 per lane) and Cout >= 64; longer
+    sequences (L_in = 336) keep fp32 tensors whose readers round in their loaders."""
+    quads = L * (3 * Cout // 4)
+    return Cout >= 64 and any(quads % (64 * w) == 0 and quads // (64 * w) <= 9 for w in (4, 8))
+
+
 class _MatMul(torch.autograd.Function):
     """y = a @ b with a (..., K), b (K, N): the three contractions of a Linear, each with its own operand rounding."""
 
@@ -261,6 +289,8 @@ def conv_block(x: torch.Tensor, p: Params, idx: int, stride: int, q: Rounding = 
         y = F.group_norm(y, 1, p[pre + "1.weight"], p[pre + "1.bias"], eps=1e-5)
         outs.append(F.gelu(y))
     cat = torch.cat(outs, dim=1)
+    if conv_acts_bf16(x.shape[-1], outs[0].shape[1]):
+        cat = grad_stored(cat, q)                            # the device stores d cat as the bf16 tensor its GEMM writes
     pre = f"{P_CONV}{idx}.final_conv."
     return conv1d(cat, p[pre + "weight"], p[pre + "bias"], q, stride=stride)
 
@@ -302,8 +332,9 @@ def gpt2_lora(h: torch.Tensor, p: Params, n_layers: int, q: Rounding = FP32, mas
     ("lora{i}", modules.py:181), attention-probability dropout ("attn{i}", (S, heads, T, T), attn_pdrop),
     residual dropouts after attn.c_proj and mlp.c_proj ("res1_{i}", "res2_{i}", resid_pdrop).
     bf16 mode (q = BF16), as the HIP path runs it: c_attn + LoRA-B is ONE contraction with K = 768 + 32 over
-    [LN1(h) | z] and [W ; 2 B^T]; the LoRA-A product z (32 output columns) runs on the exact kernel in the forward,
-    while its two backward contractions (768 output columns each) are bf16."""
+    [LN1(h) | z] and [W ; 2 B^T]; the LoRA-A product z reads the bf16 copy of drop(LN1(h)) the LayerNorm kernel stores
+    (what autocast casts in front of lora_A) -- a bf16 contraction like its two backward ones (round 4; it ran on the
+    exact kernel before)."""
     S, T, D = h.shape
     hd = D // GPT2_HEADS
     h = _mul(h + p[P_GPT + "wpe.weight"][:T], masks, "embd")
@@ -313,7 +344,7 @@ def gpt2_lora(h: torch.Tensor, p: Params, n_layers: int, q: Rounding = FP32, mas
         u = F.layer_norm(h, (D,), p[pre + "ln_1.weight"], p[pre + "ln_1.bias"], LN_EPS)
         A = p[pre + "attn.c_attn.lora_A.default.weight"]     # (r, 768)
         Bm = p[pre + "attn.c_attn.lora_B.default.weight"]    # (2304, r)
-        z = mm(_mul(u, masks, f"lora{i}"), A.t(), q, f=False)
+        z = mm(_mul(u, masks, f"lora{i}"), A.t(), q)
         wcat = torch.cat([p[pre + "attn.c_attn.base_layer.weight"], LORA_SCALE * Bm.t()], 0)     # (768 + r, 2304)
         qkv = stored(mm(torch.cat([u, z], -1), wcat, q) + p[pre + "attn.c_attn.base_layer.bias"], q)   # a bf16 tensor under autocast
         qq, k, v = qkv.split(D, dim=-1)

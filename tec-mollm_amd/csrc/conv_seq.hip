@@ -433,6 +433,12 @@ __global__ __launch_bounds__(256) void conv_dx_pack_kernel(const float* __restri
 namespace tecm_convseq {
 
 constexpr int FMAXU = 12;      // units: 3 kernel sizes x Cout / 32 channel blocks (Cout <= 128)
+#ifndef CFW_PD
+#define CFW_PD 4               // weight-prefetch depth of the forward K loops, in k-steps (tools/build_variant.py sweeps it)
+#endif
+#ifndef CFW_PD32
+#define CFW_PD32 1             // the same for the exact-fp32 kernel (a k-step there is 4 NTT MFMAs of 64 cycles: already long)
+#endif
 struct FArgs {
   const void* inp;             // bf16 or fp32 (B, Lc, N, ld_in)
   const void* wpack;           // fragment-ordered weights, the element type of inp
@@ -507,16 +513,22 @@ __global__ __launch_bounds__(NTH, 2) void conv_fwd_seq_kernel(const FArgs a) {
 #pragma unroll
         for (int i = 0; i < NTT; ++i) df[i] = *reinterpret_cast<const bf16x8*>(lds + off0 + 32 * i * a.pitch);
       };
-      bf16x8 wf = wp[0], df[NTT];
+      // weights: a register ring CFW_PD steps deep (a k-step is NTT MFMAs = 100-200 cycles, an L2 hit under load costs
+      // 300-500: one step of prefetch left every step waiting for its weights); data rows: one step ahead (LDS)
+      bf16x8 wq[CFW_PD], df[NTT];
+#pragma unroll
+      for (int p_ = 0; p_ < CFW_PD; ++p_) wq[p_] = wp[min(p_, nsteps - 1) * 64];
       rd(0, df);
       for (int s = 0; s < nsteps; ++s) {
         const int sn = min(s + 1, nsteps - 1);
-        const bf16x8 wn = wp[sn * 64];
+        const bf16x8 wn = wp[min(s + CFW_PD, nsteps - 1) * 64];
         bf16x8 dn[NTT];
         rd(sn, dn);
 #pragma unroll
-        for (int i = 0; i < NTT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df[i], wf, acc[i], 0, 0, 0);
-        wf = wn;
+        for (int i = 0; i < NTT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df[i], wq[0], acc[i], 0, 0, 0);
+#pragma unroll
+        for (int p_ = 0; p_ + 1 < CFW_PD; ++p_) wq[p_] = wq[p_ + 1];
+        wq[CFW_PD - 1] = wn;
 #pragma unroll
         for (int i = 0; i < NTT; ++i) df[i] = dn[i];
       }
@@ -609,18 +621,22 @@ __global__ __launch_bounds__(NTH, 2) void conv_fwd_seq_f32_kernel(const FArgs a)
 #pragma unroll
         for (int i = 0; i < NTT; ++i) df[i] = *reinterpret_cast<const f32x4*>(lds + off0 + 32 * i * a.pitch);
       };
-      f32x4 wf = wp[0], df[NTT];
+      f32x4 wq[CFW_PD32], df[NTT];
+#pragma unroll
+      for (int p_ = 0; p_ < CFW_PD32; ++p_) wq[p_] = wp[min(p_, nsteps - 1) * 64];
       rd(0, df);
       for (int s = 0; s < nsteps; ++s) {
         const int sn = min(s + 1, nsteps - 1);
-        const f32x4 wn = wp[sn * 64];
+        const f32x4 wn = wp[min(s + CFW_PD32, nsteps - 1) * 64];
         f32x4 dn[NTT];
         rd(sn, dn);
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-          for (int i = 0; i < NTT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(df[i][jj], wf[jj], acc[i], 0, 0, 0);
-        wf = wn;
+          for (int i = 0; i < NTT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(df[i][jj], wq[0][jj], acc[i], 0, 0, 0);
+#pragma unroll
+        for (int p_ = 0; p_ + 1 < CFW_PD32; ++p_) wq[p_] = wq[p_ + 1];
+        wq[CFW_PD32 - 1] = wn;
 #pragma unroll
         for (int i = 0; i < NTT; ++i) df[i] = dn[i];
       }

@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ y,
                                                             int64_t ldy, void* __restrict__ y16, int64_t ldy16,
+                                                            void* __restrict__ y16d, int64_t ldy16d, DropCtxN dd,
                                                             float* __restrict__ stats, int64_t M, int D, float eps) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * 4 + wave;
@@ -70,6 +71,16 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
       if (y) *reinterpret_cast<float4*>(y + row * ldy + c) = o;
       // bf16 copy for a bf16 matrix-core GEMM that only ever reads the rounded value (rounded once here)
       if (y16) tecm_store_bf16x4(static_cast<__bf16*>(y16) + row * ldy16 + c, o.x, o.y, o.z, o.w);
+      // ... and bf16(dropout(o)): the LoRA branch's input (peft lora_dropout in front of lora_A, modules.py:181), the
+      // cast autocast applies to the DROPPED fp32 value; read by the LoRA-A GEMM and by its weight gradient
+      if (y16d) {
+        const uint64_t di = (uint64_t)(row * dd.ld + c);
+        tecm_store_bf16x4(static_cast<__bf16*>(y16d) + row * ldy16d + c,
+                          o.x * tecm_drop_mult(dd.seed, di, dd.thresh, dd.inv),
+                          o.y * tecm_drop_mult(dd.seed, di + 1, dd.thresh, dd.inv),
+                          o.z * tecm_drop_mult(dd.seed, di + 2, dd.thresh, dd.inv),
+                          o.w * tecm_drop_mult(dd.seed, di + 3, dd.thresh, dd.inv));
+      }
     }
   }
   if (lane == 0) {
@@ -78,16 +89,39 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   }
 }
 
-template <int NCH>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, int64_t lddy,
+// NW waves per block.  LORA: the rank-r LoRA back-path of peft's c_attn (modules.py:177-186) is folded into the row's dy
+// before anything else is done with it:   dy[row][c] += keep(row, c) / (1 - p) * sum_j dz[row][j] * A[j][c]
+// (dz = d z of the LoRA-A product, A = lora_A (r, D), the mask = lora_dropout's) -- the separate K = r GEMM that used to
+// read-modify-write the whole M x D gradient (430 MB per layer at B = 8) is gone.  A sits in LDS as fp32 (r * D floats,
+// rounded to bf16 first when `lora_bf16`: the bf16 mode's contraction with bf16 operands and fp32 accumulation); the
+// per-wave reduction rows of the parameter gradients alias the same LDS once the row loop is over.
+struct LoraBack {
+  const float* dz;      // (M, r) with leading dimension lddz
+  int64_t lddz;
+  const float* A;       // (r, D)
+  int32_t r, bf16;
+  DropCtxN drop;
+};
+
+__device__ __forceinline__ float ln_round_bf16(float v) { return (float)(__bf16)v; }
+
+template <int NCH, int NW, bool LORA>
+__global__ __launch_bounds__(64 * NW) void layernorm_bwd_kernel(const float* __restrict__ dy, int64_t lddy,
                                                             const float* __restrict__ x, int64_t ldx,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ stats,
                                                             const float* __restrict__ dres, float* __restrict__ dx,
                                                             float* __restrict__ dxm, int dxm_bf16, DropCtxN odc,
-                                                            float* __restrict__ partials, int64_t M, int D) {
-  __shared__ float red[4][2 * 4 * 64 * NCH];
+                                                            float* __restrict__ partials, int64_t M, int D, LoraBack lb) {
+  constexpr int RED = 2 * 4 * 64 * NCH;                      // floats per wave in the final reduction
+  extern __shared__ __attribute__((aligned(16))) float lds_ln[];   // max(NW * RED, r * D) floats
+  float* red = lds_ln;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if constexpr (LORA) {
+    const int tot = lb.r * D;
+    for (int i = threadIdx.x; i < tot; i += 64 * NW) lds_ln[i] = lb.bf16 ? ln_round_bf16(lb.A[i]) : lb.A[i];
+    __syncthreads();
+  }
   float4 dg[NCH], db[NCH], gm[NCH];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
@@ -97,16 +131,55 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     gm[i] = c < D ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const float invD = 1.0f / (float)D;
-  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
+  for (int64_t row = (int64_t)blockIdx.x * NW + wave; row < M; row += (int64_t)gridDim.x * NW) {
     const float mean = stats[2 * row], rstd = stats[2 * row + 1];
-    float4 xh[NCH], g[NCH];
+    float4 xh[NCH], g[NCH], dv[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = 4 * (lane + 64 * i);
+      dv[i] = c < D ? *reinterpret_cast<const float4*>(dy + row * lddy + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if constexpr (LORA) {
+      float dzl = lane < lb.r ? lb.dz[row * lb.lddz + lane] : 0.f;
+      if (lb.bf16) dzl = ln_round_bf16(dzl);
+      float4 acc[NCH];
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int j = 0; j < lb.r; ++j) {
+        const float sj = __shfl(dzl, j);
+        const float* Aj = lds_ln + j * D;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          const int c = 4 * (lane + 64 * i);
+          if (c < D) {
+            const float4 a = *reinterpret_cast<const float4*>(Aj + c);
+            acc[i].x = fmaf(sj, a.x, acc[i].x); acc[i].y = fmaf(sj, a.y, acc[i].y);
+            acc[i].z = fmaf(sj, a.z, acc[i].z); acc[i].w = fmaf(sj, a.w, acc[i].w);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = 4 * (lane + 64 * i);
+        if (c < D) {
+          if (lb.drop.thresh) {
+            const uint64_t di = (uint64_t)(row * lb.drop.ld + c);
+            acc[i].x *= tecm_drop_mult(lb.drop.seed, di, lb.drop.thresh, lb.drop.inv);
+            acc[i].y *= tecm_drop_mult(lb.drop.seed, di + 1, lb.drop.thresh, lb.drop.inv);
+            acc[i].z *= tecm_drop_mult(lb.drop.seed, di + 2, lb.drop.thresh, lb.drop.inv);
+            acc[i].w *= tecm_drop_mult(lb.drop.seed, di + 3, lb.drop.thresh, lb.drop.inv);
+          }
+          dv[i].x += acc[i].x; dv[i].y += acc[i].y; dv[i].z += acc[i].z; dv[i].w += acc[i].w;
+        }
+      }
+    }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = 4 * (lane + 64 * i);
       if (c < D) {
         const float4 xv = *reinterpret_cast<const float4*>(x + row * ldx + c);
-        const float4 d = *reinterpret_cast<const float4*>(dy + row * lddy + c);
+        const float4 d = dv[i];
         xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
         g[i] = make_float4(d.x * gm[i].x, d.y * gm[i].y, d.z * gm[i].z, d.w * gm[i].w);
         dg[i].x += d.x * xh[i].x; dg[i].y += d.y * xh[i].y; dg[i].z += d.z * xh[i].z; dg[i].w += d.w * xh[i].w;
@@ -145,19 +218,23 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       }
     }
   }
-  // block reduction of the per-lane parameter gradients -> one partial row per block
+  // block reduction of the per-lane parameter gradients -> one partial row per block (the LDS image of A is dead)
+  if constexpr (LORA) __syncthreads();
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = 4 * (lane + 64 * i);
-    float* r0 = &red[wave][c];
-    float* r1 = &red[wave][4 * 64 * NCH + c];
+    float* r0 = &red[wave * RED + c];
+    float* r1 = &red[wave * RED + 4 * 64 * NCH + c];
     r0[0] = dg[i].x; r0[1] = dg[i].y; r0[2] = dg[i].z; r0[3] = dg[i].w;
     r1[0] = db[i].x; r1[1] = db[i].y; r1[2] = db[i].z; r1[3] = db[i].w;
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < 2 * D; c += 256) {
+  for (int c = threadIdx.x; c < 2 * D; c += 64 * NW) {
     const int src = c < D ? c : (4 * 64 * NCH + (c - D));
-    partials[(int64_t)blockIdx.x * 2 * D + c] = (red[0][src] + red[1][src]) + (red[2][src] + red[3][src]);
+    float t = red[src];                                     // waves in a fixed order: bit-reproducible
+#pragma unroll
+    for (int w = 1; w < NW; ++w) t += red[w * RED + src];
+    partials[(int64_t)blockIdx.x * 2 * D + c] = t;
   }
 }
 
@@ -385,7 +462,10 @@ __device__ __forceinline__ void seq_reduce3(float (&v)[3], float (*xch)[3], int 
 template <int CPB, int WPS, int GN_NPMAX, bool IO16>
 __global__ __launch_bounds__((GnGeom<CPB, WPS>::NTHR)) void gn_gelu_fwd_reg(const void* __restrict__ y, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, void* __restrict__ act,
-                                                       float* __restrict__ stats, int B, int L, int N, float eps, int NP) {
+                                                       float* __restrict__ stats, int B, int L, int N, float eps, int NP,
+                                                       int astride) {
+  // astride > 1: only the time steps t % astride == 0 are written, into a COMPACT (B, ceil(L / astride), N, CT) tensor --
+  // the strided 1x1 conv behind the block (modules.py:36-41) reads nothing else, while the statistics need every step
   using G = GnGeom<CPB, WPS>;
   __shared__ float xch[G::NTHR / 64][3];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -412,11 +492,15 @@ __global__ __launch_bounds__((GnGeom<CPB, WPS>::NTHR)) void gn_gelu_fwd_reg(cons
   }
   float4 v[GN_NPMAX];
   int32_t off[GN_NPMAX];                                 // relative to the sequence base (host checks L*N*CT < 2^31)
+  int32_t aoff[GN_NPMAX];                                // the same in the (compact) act tensor; -1: this step is not written
+  const int La = (L + astride - 1) / astride;
+  const int64_t abase = ((int64_t)b * La * N + n) * G::CT;
   {
     int t = l2 / G::QPR, q = l2 % G::QPR;
 #pragma unroll
     for (int i = 0; i < GN_NPMAX; ++i) {
       off[i] = t * (int32_t)tstride + q * 4;
+      aoff[i] = (t % astride) == 0 ? (t / astride) * (int32_t)tstride + q * 4 : -1;
       if (i < NP) v[i] = gn_ld4<false>(y, base + off[i]);      // y stays fp32: 8-byte loads make the kernel slower, not faster
       t += G::DT;
       q += G::DQ;
@@ -466,14 +550,14 @@ __global__ __launch_bounds__((GnGeom<CPB, WPS>::NTHR)) void gn_gelu_fwd_reg(cons
   if (live) {
 #pragma unroll
     for (int i = 0; i < GN_NPMAX; ++i)
-      if (i < NP) {
+      if (i < NP && aoff[i] >= 0) {
         const int s_ = i % 3;
         float4 o;
         o.x = gelu_erf_fast((v[i].x - ms[s_]) * rs[s_] * gm[s_].x + bt[s_].x);
         o.y = gelu_erf_fast((v[i].y - ms[s_]) * rs[s_] * gm[s_].y + bt[s_].y);
         o.z = gelu_erf_fast((v[i].z - ms[s_]) * rs[s_] * gm[s_].z + bt[s_].z);
         o.w = gelu_erf_fast((v[i].w - ms[s_]) * rs[s_] * gm[s_].w + bt[s_].w);
-        gn_st4<IO16>(act, base + off[i], o);
+        gn_st4<IO16>(act, abase + aoff[i], o);
       }
     if (half == 0 && lane < 3) {
       stats[(sidx * 3 + lane) * 2] = sel3(lane, mean[0], mean[1], mean[2]);
@@ -482,8 +566,8 @@ __global__ __launch_bounds__((GnGeom<CPB, WPS>::NTHR)) void gn_gelu_fwd_reg(cons
   }
 }
 
-template <int CPB, int WPS, int GN_NPMAX, bool IO16>
-__global__ __launch_bounds__((GnGeom<CPB, WPS>::NTHR)) void gn_gelu_bwd_reg(const float* __restrict__ dact, int dstride, int L2,
+template <int CPB, int WPS, int GN_NPMAX, bool IO16, bool D16 = false>
+__global__ __launch_bounds__((GnGeom<CPB, WPS>::NTHR)) void gn_gelu_bwd_reg(const void* __restrict__ dact, int dstride, int L2,
                                                        const void* __restrict__ y, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const float* __restrict__ stats,
                                                        void* __restrict__ dy, float* __restrict__ partials, int B,
@@ -537,7 +621,6 @@ __global__ __launch_bounds__((GnGeom<CPB, WPS>::NTHR)) void gn_gelu_bwd_reg(cons
     }
     float4 yh[GN_NPMAX], gd[GN_NPMAX];                    // y (then y_hat) and dact (then d y_hat)
     int32_t off[GN_NPMAX];
-    const float* db = dact + dbase;
     {
       int t = l2 / G::QPR, q = l2 % G::QPR;
 #pragma unroll
@@ -546,7 +629,8 @@ __global__ __launch_bounds__((GnGeom<CPB, WPS>::NTHR)) void gn_gelu_bwd_reg(cons
         if (i < NP) {
           yh[i] = gn_ld4<false>(y, ybase + off[i]);
           const bool has = (t % dstride) == 0;
-          gd[i] = has ? *reinterpret_cast<const float4*>(db + (t / dstride) * (int32_t)tstride + q * 4)
+          // (D16: the gradient of the strided 1x1 conv's input arrives as the bf16 tensor its bf16 GEMM wrote)
+          gd[i] = has ? gn_ld4<D16>(dact, dbase + (t / dstride) * (int32_t)tstride + q * 4)
                       : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         t += G::DT;
@@ -782,9 +866,13 @@ int gn_blocks(int64_t S) {
 }  // namespace
 
 extern "C" int tecm_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y,
-                                  int64_t ldy, void* y16, int64_t ldy16, float* stats, int64_t M, int32_t D, float eps,
-                                  void* stream) {
+                                  int64_t ldy, void* y16, int64_t ldy16, void* y16d, int64_t ldy16d, const TecmDrop* drop,
+                                  float* stats, int64_t M, int32_t D, float eps, void* stream) {
   TECM_REQUIRE(x && gamma && beta && (y || y16) && stats, TECM_E_ARG, "tecm_layernorm_fwd: null pointer");
+  TECM_REQUIRE(!y16d || (tecm_aligned(y16d, 8) && ldy16d % 4 == 0 && ldy16d >= D), TECM_E_ALIGN,
+               "tecm_layernorm_fwd: the dropped bf16 output must be 8-byte aligned with a leading dimension multiple of 4");
+  TECM_REQUIRE(!y16d || (drop && drop->p >= 0.f && drop->p < 1.f), TECM_E_ARG, "tecm_layernorm_fwd: y16d needs its dropout spec");
+  const DropCtxN dd = make_dropn(y16d ? drop : nullptr);
   TECM_REQUIRE(!y16 || (tecm_aligned(y16, 8) && ldy16 % 4 == 0 && ldy16 >= D), TECM_E_ALIGN,
                "tecm_layernorm_fwd: the bf16 output must be 8-byte aligned with a leading dimension multiple of 4");
   TECM_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAXCH, TECM_E_ARG,
@@ -796,7 +884,8 @@ extern "C" int tecm_layernorm_fwd(const float* x, int64_t ldx, const float* gamm
   const int nch = (D + 255) / 256;
   hipStream_t st = (hipStream_t)stream;
 #define LN_FWD(NCH) \
-  hipLaunchKernelGGL((layernorm_fwd_kernel<NCH>), grid, dim3(256), 0, st, x, ldx, gamma, beta, y, ldy, y16, ldy16, stats, M, D, eps)
+  hipLaunchKernelGGL((layernorm_fwd_kernel<NCH>), grid, dim3(256), 0, st, x, ldx, gamma, beta, y, ldy, y16, ldy16, y16d, ldy16d, \
+                     dd, stats, M, D, eps)
   switch (nch) {
     case 1: LN_FWD(1); break;
     case 2: LN_FWD(2); break;
@@ -811,9 +900,11 @@ extern "C" int tecm_layernorm_fwd(const float* x, int64_t ldx, const float* gamm
 extern "C" int tecm_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                                   const float* stats, const float* dres, float* dx, void* dx_masked,
                                   int32_t masked_bf16, const TecmDrop* mask_drop, float* dgb_partials,
-                                  int32_t* num_blocks, int64_t M, int32_t D, void* stream) {
+                                  int32_t* num_blocks, int64_t M, int32_t D, const TecmLoraBack* lora, void* stream) {
   TECM_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAXCH, TECM_E_ARG, "tecm_layernorm_bwd: bad M/D");
-  const int nb = ln_blocks(M);
+  const bool has_lora = lora != nullptr && lora->dz != nullptr;
+  // the LoRA variant keeps lora_A (r x D floats) in LDS: one 1024-thread block per CU, 16 rows in flight per block
+  const int nb = has_lora ? (int)((M + 15) / 16 < 256 ? (M + 15) / 16 : 256) : ln_blocks(M);
   if (num_blocks) *num_blocks = nb;
   if (dx == nullptr) return TECM_OK;   // query mode
   TECM_REQUIRE(dy && x && gamma && stats && dgb_partials, TECM_E_ARG, "tecm_layernorm_bwd: null pointer");
@@ -824,9 +915,39 @@ extern "C" int tecm_layernorm_bwd(const float* dy, int64_t lddy, const float* x,
   const DropCtxN odc = make_dropn(mask_drop);
   const int nch = (D + 255) / 256;
   hipStream_t st = (hipStream_t)stream;
-#define LN_BWD(NCH)                                                                                              \
-  hipLaunchKernelGGL((layernorm_bwd_kernel<NCH>), dim3(nb), dim3(256), 0, st, dy, lddy, x, ldx, gamma, stats, dres, \
-                     dx, static_cast<float*>(dx_masked), (int)masked_bf16, odc, dgb_partials, M, D)
+  LoraBack lb{};
+  if (has_lora) {
+    TECM_REQUIRE(lora->A && lora->r > 0 && lora->r <= 64 && lora->ld_dz >= lora->r, TECM_E_ARG,
+                 "tecm_layernorm_bwd: the LoRA back-path needs lora_A and 1 <= r <= 64");
+    TECM_REQUIRE(tecm_aligned(lora->A, 16), TECM_E_ALIGN, "tecm_layernorm_bwd: lora_A must be 16-byte aligned");
+    lb.dz = lora->dz; lb.lddz = lora->ld_dz; lb.A = lora->A; lb.r = lora->r; lb.bf16 = lora->bf16_operands;
+    lb.drop = make_dropn(&lora->drop);
+    constexpr int NW = 16;
+    const size_t red = (size_t)NW * 2 * 4 * 64 * nch * sizeof(float), img = (size_t)lora->r * D * sizeof(float);
+    const size_t lds = red > img ? red : img;
+    TECM_REQUIRE(lds <= 160 * 1024, TECM_E_LDS, "tecm_layernorm_bwd: lora_A (%d x %d) does not fit the LDS", lora->r, D);
+#define LN_BWD_L(NCH)                                                                                                   \
+  {                                                                                                                     \
+    const void* fn = reinterpret_cast<const void*>(&layernorm_bwd_kernel<NCH, NW, true>);                               \
+    TECM_REQUIRE(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,          \
+                 TECM_E_LAUNCH, "tecm_layernorm_bwd: hipFuncSetAttribute failed");                                       \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<NCH, NW, true>), dim3(nb), dim3(64 * NW), lds, st, dy, lddy, x, ldx, gamma, \
+                       stats, dres, dx, static_cast<float*>(dx_masked), (int)masked_bf16, odc, dgb_partials, M, D, lb);  \
+  }
+    switch (nch) {
+      case 1: LN_BWD_L(1); break;
+      case 2: LN_BWD_L(2); break;
+      case 3: LN_BWD_L(3); break;
+      default: LN_BWD_L(4); break;
+    }
+#undef LN_BWD_L
+    TECM_CHECK_LAUNCH("tecm_layernorm_bwd/lora");
+    return TECM_OK;
+  }
+#define LN_BWD(NCH)                                                                                                    \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<NCH, 4, false>), dim3(nb), dim3(256), (size_t)4 * 2 * 4 * 64 * NCH * sizeof(float), \
+                     st, dy, lddy, x, ldx, gamma, stats, dres, dx, static_cast<float*>(dx_masked), (int)masked_bf16, odc,   \
+                     dgb_partials, M, D, lb)
   switch (nch) {
     case 1: LN_BWD(1); break;
     case 2: LN_BWD(2); break;
@@ -840,10 +961,11 @@ extern "C" int tecm_layernorm_bwd(const float* dy, int64_t lddy, const float* x,
 
 extern "C" int tecm_groupnorm_gelu_fwd(const void* y_, const float* gamma, const float* beta, void* act_,
                                        float* stats, int32_t B, int32_t L, int32_t N, int32_t Cout, float eps,
-                                       int32_t io_bf16, void* stream) {
+                                       int32_t io_bf16, int32_t act_stride, void* stream) {
   const float* y = reinterpret_cast<const float*>(y_);
   float* act = reinterpret_cast<float*>(act_);
   TECM_REQUIRE(io_bf16 == 0 || io_bf16 == TECM_GN_OUT_BF16, TECM_E_ARG, "tecm_groupnorm_gelu_fwd: io_bf16 is 0 or TECM_GN_OUT_BF16");
+  TECM_REQUIRE(act_stride >= 1, TECM_E_ARG, "tecm_groupnorm_gelu_fwd: act_stride must be at least 1");
   const bool io16 = io_bf16 != 0;
   TECM_REQUIRE(y && gamma && beta && act && stats, TECM_E_ARG, "tecm_groupnorm_gelu_fwd: null pointer");
   TECM_REQUIRE(B > 0 && L > 0 && N > 0, TECM_E_ARG, "tecm_groupnorm_gelu_fwd: bad shape");
@@ -857,10 +979,10 @@ extern "C" int tecm_groupnorm_gelu_fwd(const void* y_, const float* gamma, const
   do {                                                                                                            \
     if (io16)                                                                                                     \
       hipLaunchKernelGGL((gn_gelu_fwd_reg<CPB, WPS, NPM, true>), GRID, dim3(WPS > 4 ? 64 * WPS : 256), 0, st, y_, gamma, \
-                         beta, act_, stats, B, L, N, eps, np);                                                    \
+                         beta, act_, stats, B, L, N, eps, np, (int)act_stride);                                   \
     else                                                                                                          \
       hipLaunchKernelGGL((gn_gelu_fwd_reg<CPB, WPS, NPM, false>), GRID, dim3(WPS > 4 ? 64 * WPS : 256), 0, st, y_, gamma, \
-                         beta, act_, stats, B, L, N, eps, np);                                                    \
+                         beta, act_, stats, B, L, N, eps, np, (int)act_stride);                                   \
   } while (0)
   int np = gn_reg_pairs(L, N, Cout, 4, 9, y, act);
   if (np > 0) {
@@ -890,8 +1012,9 @@ extern "C" int tecm_groupnorm_gelu_fwd(const void* y_, const float* gamma, const
     return TECM_OK;
   }
 #undef GN_FWD_REG
-  TECM_REQUIRE(!io16, TECM_E_ARG,
-               "tecm_groupnorm_gelu_fwd: bf16 tensors are served by the register-resident kernels only (L * Cout too large)");
+  TECM_REQUIRE(!io16 && act_stride == 1, TECM_E_ARG,
+               "tecm_groupnorm_gelu_fwd: bf16 tensors and a compact strided act are served by the register-resident kernels only "
+               "(L * Cout too large)");
   if (Cout == 64)
     hipLaunchKernelGGL((gn_gelu_fwd_kernel<1>), grid, dim3(256), 0, st, y, gamma, beta, act, stats, B, L, N, eps);
   else if (Cout == 128)
@@ -902,14 +1025,17 @@ extern "C" int tecm_groupnorm_gelu_fwd(const void* y_, const float* gamma, const
   return TECM_OK;
 }
 
-extern "C" int tecm_groupnorm_gelu_bwd(const float* dact, int32_t dstride, const void* y_, const float* gamma,
+extern "C" int tecm_groupnorm_gelu_bwd(const void* dact_, int32_t dstride, const void* y_, const float* gamma,
                                        const float* beta, const float* stats, void* dy_, float* dgb_partials,
                                        int32_t* num_blocks, int32_t B, int32_t L, int32_t N, int32_t Cout,
                                        int32_t io_bf16, void* stream) {
   const float* y = reinterpret_cast<const float*>(y_);
   float* dy = reinterpret_cast<float*>(dy_);
-  TECM_REQUIRE(io_bf16 == 0 || io_bf16 == TECM_GN_OUT_BF16, TECM_E_ARG, "tecm_groupnorm_gelu_bwd: io_bf16 is 0 or TECM_GN_OUT_BF16");
-  const bool io16 = io_bf16 != 0;
+  TECM_REQUIRE((io_bf16 & ~(TECM_GN_OUT_BF16 | TECM_GN_DACT_BF16)) == 0 &&
+                   (!(io_bf16 & TECM_GN_DACT_BF16) || (io_bf16 & TECM_GN_OUT_BF16)),
+               TECM_E_ARG, "tecm_groupnorm_gelu_bwd: io_bf16 is 0, TECM_GN_OUT_BF16 or TECM_GN_OUT_BF16 | TECM_GN_DACT_BF16");
+  const bool io16 = (io_bf16 & TECM_GN_OUT_BF16) != 0, d16 = (io_bf16 & TECM_GN_DACT_BF16) != 0;
+  const float* dact = reinterpret_cast<const float*>(dact_);
   TECM_REQUIRE(B > 0 && L > 0 && N > 0 && dstride > 0, TECM_E_ARG, "tecm_groupnorm_gelu_bwd: bad shape");
   TECM_REQUIRE(Cout == 64 || Cout == 128 || Cout == 256, TECM_E_ARG,
                "tecm_groupnorm_gelu_bwd: Cout must be 64, 128 or 256 (got %d)", Cout);
@@ -921,11 +1047,14 @@ extern "C" int tecm_groupnorm_gelu_bwd(const float* dact, int32_t dstride, const
   hipStream_t st = (hipStream_t)stream;
 #define GN_BWD_REG(CPB, WPS, NT, NPV)                                                                              \
   do {                                                                                                            \
-    if (io16)                                                                                                     \
-      hipLaunchKernelGGL((gn_gelu_bwd_reg<CPB, WPS, 9, true>), dim3(nb), dim3(NT), 0, st, dact, dstride, L2, y_, gamma, beta, \
+    if (io16 && d16)                                                                                              \
+      hipLaunchKernelGGL((gn_gelu_bwd_reg<CPB, WPS, 9, true, true>), dim3(nb), dim3(NT), 0, st, dact_, dstride, L2, y_, gamma, \
+                         beta, stats, dy_, dgb_partials, B, L, N, NPV);                                           \
+    else if (io16)                                                                                                \
+      hipLaunchKernelGGL((gn_gelu_bwd_reg<CPB, WPS, 9, true>), dim3(nb), dim3(NT), 0, st, dact_, dstride, L2, y_, gamma, beta, \
                          stats, dy_, dgb_partials, B, L, N, NPV);                                                 \
     else                                                                                                          \
-      hipLaunchKernelGGL((gn_gelu_bwd_reg<CPB, WPS, 9, false>), dim3(nb), dim3(NT), 0, st, dact, dstride, L2, y_, gamma, beta, \
+      hipLaunchKernelGGL((gn_gelu_bwd_reg<CPB, WPS, 9, false>), dim3(nb), dim3(NT), 0, st, dact_, dstride, L2, y_, gamma, beta, \
                          stats, dy_, dgb_partials, B, L, N, NPV);                                                 \
   } while (0)
   const int np = tecm_aligned(dact, 16) ? gn_reg_pairs(L, N, Cout, 4, 9, y, dy) : 0;
@@ -951,7 +1080,7 @@ extern "C" int tecm_groupnorm_gelu_bwd(const float* dact, int32_t dstride, const
     return TECM_OK;
   }
 #undef GN_BWD_REG
-  TECM_REQUIRE(!io16, TECM_E_ARG,
+  TECM_REQUIRE(!io16 && !d16, TECM_E_ARG,
                "tecm_groupnorm_gelu_bwd: bf16 tensors are served by the register-resident kernels only (L * Cout too large)");
   if (Cout == 64)
     hipLaunchKernelGGL((gn_gelu_bwd_kernel<1>), dim3(nb), dim3(256), 0, st, dact, dstride, L2, y, gamma, beta, stats,

@@ -76,6 +76,11 @@ class TecmSpatialGrads(C.Structure):
     ]
 
 
+class TecmLoraBack(C.Structure):
+    _fields_ = [("dz", c_f32p), ("ld_dz", C.c_int64), ("A", c_f32p), ("r", C.c_int32), ("bf16_operands", C.c_int32),
+                ("drop", TecmDrop)]
+
+
 class TecmAdamW(C.Structure):
     _fields_ = [
         ("n", C.c_int64),
@@ -141,15 +146,16 @@ EXPORTS = {
     "tecm_spatial_bwd": (C.c_int, [C.POINTER(TecmSpatial), C.POINTER(TecmSpatialGrads), C.c_void_p]),
     "tecm_spatial_bwd_blocks": (C.c_int, [C.POINTER(TecmSpatial)]),
     "tecm_groupnorm_gelu_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32,
-                                          C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
+                                          C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_void_p]),
     "tecm_groupnorm_gelu_bwd": (C.c_int, [c_f32p, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                           C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                           C.c_int32, C.c_void_p]),
     "tecm_layernorm_fwd": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_void_p, C.c_int64,
+                                     C.c_void_p, C.c_int64, C.POINTER(TecmDrop),
                                      c_f32p, C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
     "tecm_layernorm_bwd": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p,
                                      C.c_int32, C.POINTER(TecmDrop), c_f32p, C.POINTER(C.c_int32), C.c_int64, C.c_int32,
-                                     C.c_void_p]),
+                                     C.POINTER(TecmLoraBack), C.c_void_p]),
     "tecm_attention_fwd": (C.c_int, [c_f32p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                      C.c_int32, C.POINTER(TecmDrop), C.c_void_p]),
     "tecm_cast_bf16": (C.c_int, [c_f32p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),

@@ -327,26 +327,31 @@ class ConvBlockFn(torch.autograd.Function):
             a_in = inp16 if (inp16 is not None and side16 and ld_in % 8 == 0) else inp
             gemm(M, Cout, k * ld_in, a_in, ld_in, fp, k * ld_in, y, CT, c_off=j * Cout,
                  a_win=win(N, Lc, Lc, 1, k, ld_in, (k - 1) // 2), bias=b, bf16=bf16)
-        act = torch.empty(B, Lc, N, CT, device=inp.device, dtype=adt)
-        stats = _empty(B * N, 3, 2, like=inp)
-        ops.groupnorm_gelu_fwd(y, gamma, beta, act, stats, B, Lc, N, Cout)
         Lo = (Lc - 1) // stride + 1
+        # bf16 mode: the activation is only kept at the time steps the stride-s 1x1 conv reads (a COMPACT (B, Lo, N, CT)
+        # tensor: half the bytes at stride 2, and that conv and its weight gradient become plain GEMMs, no window view)
+        compact = r16 and stride > 1
+        La = Lo if compact else Lc
+        act = torch.empty(B, La, N, CT, device=inp.device, dtype=adt)
+        stats = _empty(B * N, 3, 2, like=inp)
+        ops.groupnorm_gelu_fwd(y, gamma, beta, act, stats, B, Lc, N, Cout, act_stride=stride if compact else 1)
         out = _empty(B, Lo, N, Cout, like=inp)
         wf2 = wf.view(Cout, CT)
         out16 = None
+        awin = None if compact else win(N, Lc, Lo, stride, 1, CT, 0)
         if side16:
             # one epilogue, two forms of the same values: the fp32 tensor autograd sees (written through the epilogue's
             # pre-activation store; there is no activation here) and a bf16 copy for the window GEMMs that read it next
             out16 = torch.empty(B, Lo, N, Cout, device=inp.device, dtype=torch.bfloat16)
-            gemm(B * Lo * N, Cout, CT, act, CT, wf2, CT, out16, Cout, a_win=win(N, Lc, Lo, stride, 1, CT, 0), bias=bf,
-                 preact=(out, Cout), bf16=bf16)
+            gemm(B * Lo * N, Cout, CT, act, CT, wf2, CT, out16, Cout, a_win=awin, bias=bf, preact=(out, Cout), bf16=bf16)
             ctx.mark_non_differentiable(out16)
         else:
-            gemm(B * Lo * N, Cout, CT, act, CT, wf2, CT, out, Cout, a_win=win(N, Lc, Lo, stride, 1, CT, 0), bias=bf, bf16=bf16)
+            gemm(B * Lo * N, Cout, CT, act, CT, wf2, CT, out, Cout, a_win=awin, bias=bf, bf16=bf16)
         ctx.save_for_backward(inp, y, act, stats, gamma, beta, wf, *packs)
         ctx.w357 = (w3.detach(), w5.detach(), w7.detach())       # raw (Cout, cin, k) weights: the fused d-inp kernel packs them
         ctx.inp16 = inp16 if (side16 and inp16 is not None and ld_in % 8 == 0) else None   # dW reads it instead of inp
         ctx.dims = (B, Lc, N, ld_in, cin, Cout, stride, Lo, need_dinp, bf16)
+        ctx.compact = compact
         return out, out16
 
     @staticmethod
@@ -368,8 +373,12 @@ class ConvBlockFn(torch.autograd.Function):
         dbf = colsum(dout, Cout, Mo, 1, 1, Cout)[0]
         dwf = _empty(Cout, CT, like=inp)
         gemm(Cout, CT, Mo, dout, Cout, act, CT, dwf, CT, a_layout=A_KM, b_layout=B_KN,
-             b_win=win(N, Lc, Lo, stride, 1, CT, 0), split_k=pick_split_k(Cout, CT, Mo, prec=bf16), bf16=bf16)
-        dact = _empty(B, Lo, N, CT, like=inp)
+             b_win=None if ctx.compact else win(N, Lc, Lo, stride, 1, CT, 0),
+             split_k=pick_split_k(Cout, CT, Mo, prec=bf16), bf16=bf16)
+        # the gradient at the 1x1 conv's input: a bf16 tensor in bf16 mode (what the backward of a bf16 Conv1d hands to the
+        # fp32 GELU backward under autocast), read once by the GroupNorm + GELU backward
+        d16 = act.dtype == torch.bfloat16 and ops.uses_bf16(CT, Cout, Cout, CT, b_layout=B_KN)
+        dact = torch.empty(B, Lo, N, CT, device=inp.device, dtype=torch.bfloat16 if d16 else torch.float32)
         gemm(Mo, CT, Cout, dout, Cout, wf2, CT, dact, CT, b_layout=B_KN, bf16=bf16)
         # GroupNorm + GELU
         dy = torch.empty(B, Lc, N, CT, device=inp.device, dtype=act.dtype)
@@ -575,14 +584,26 @@ class GPT2StackFn(torch.autograd.Function):
             # instead of in that GEMM's loader: bit-identical, half the bytes both ways): LN1's output for c_attn, the
             # attention context for attn.c_proj, LN2's output for c_fc, gelu(c_fc) for mlp.c_proj.
             a16 = b16 and all(w is not None and w.dtype == torch.bfloat16 for w in (wcatT, Wo_f, Wfc_f, Wpr_f))
-            u = _empty(M, KE, like=h)                       # [ LN1(h) | z = drop(LN1(h)) A^T ]  (fp32: the LoRA gradients read it)
-            u16 = torch.empty(M, KE, device=h.device, dtype=torch.bfloat16) if a16 else None
             st1 = _empty(M, 2, like=h)
-            ops.layernorm_fwd(h, D, ln1w, ln1b, u, KE, st1, M, D, y16=u16, ldy16=KE)
             lspec = plan.spec(site_lora(i), KE)
-            gemm(M, LORA_R, D, u, KE, lA, D, u, KE, c_off=D, a_drop=lspec, bf16=plan.bf16)
             if a16:
-                ops.cast_bf16(u, KE, u16, KE, M, LORA_R, src_off=D, dst_off=D)
+                # bf16 mode: [ LN1(h) | z ] only ever feeds bf16 contractions, so it exists as bf16 alone (u16); the LoRA
+                # branch's input drop(LN1(h)) -- what autocast casts in front of lora_A -- is a second bf16 output of the
+                # LayerNorm kernel (u16d), read by the LoRA-A GEMM here and by its weight gradient in the backward, and z
+                # is written straight into u16's last 32 columns as bf16
+                u = None
+                u16 = torch.empty(M, KE, device=h.device, dtype=torch.bfloat16)
+                u16d = torch.empty(M, D, device=h.device, dtype=torch.bfloat16) if lspec is not None else None
+                ops.layernorm_fwd(h, D, ln1w, ln1b, None, KE, st1, M, D, y16=u16, ldy16=KE, y16d=u16d, ldy16d=D, drop16d=lspec)
+                a_lora, ld_lora = (u16d, D) if u16d is not None else (u16, KE)
+                gemm(M, LORA_R, D, a_lora, ld_lora, lA, D, u16, KE, c_off=D, bf16=plan.bf16)
+                u_s, ud_s = u16, (u16d if u16d is not None else h.new_empty(0))
+            else:
+                u = _empty(M, KE, like=h)                   # [ LN1(h) | z = drop(LN1(h)) A^T ]  (fp32: the LoRA gradients read it)
+                u16 = None
+                ops.layernorm_fwd(h, D, ln1w, ln1b, u, KE, st1, M, D)
+                gemm(M, LORA_R, D, u, KE, lA, D, u, KE, c_off=D, a_drop=lspec, bf16=plan.bf16)
+                u_s, ud_s = u, h.new_empty(0)
             # [ W ; (alpha/r) B^T ]  K-extended c_attn, backward operand ([KE][F3]) and forward operand ([F3][KE]): the
             # frozen 768 x 2304 part of both is cached per parameter version (_frozen_copy), ONE launch refreshes the 32
             # LoRA rows / columns of both from lora_B.  (The buffers are the cache's: they are rewritten by the next
@@ -617,8 +638,8 @@ class GPT2StackFn(torch.autograd.Function):
             h3 = _empty(M, D, like=h)
             gemm(M, D, F4, f, F4, Wpr_f, ldpr_f, h3, D, b_layout=lay_pr, bias=bpr, out_drop=plan.spec(site_res2(i), D),
                  residual=(h2, D), bf16=plan.bf16)
-            del cx, u2, f, u16                              # forward-only buffers: the backward needs none of them
-            saved += [h, u, st1, wcat, qkv, h2, st2, a]
+            del cx, u2, f                                   # forward-only buffers: the backward needs none of them
+            saved += [h, u_s, ud_s, st1, wcat, qkv, h2, st2, a]
             h = h3
         lnfw, lnfb = params[n_layers * GPT2StackFn.PER_LAYER:]
         out = _empty(B, T, N, D, like=h)
@@ -662,7 +683,7 @@ class GPT2StackFn(torch.autograd.Function):
         for i in reversed(range(n_layers)):
             (ln1w, ln1b, Wqkv, bqkv, lA, lB, Wo, bo, ln2w, ln2b, Wfc, bfc, Wpr,
              bpr) = params[i * GPT2StackFn.PER_LAYER:(i + 1) * GPT2StackFn.PER_LAYER]
-            h, u, st1, wcat, qkv, h2, st2, a = saved[i * 8:(i + 1) * 8]
+            h, u, ud, st1, wcat, qkv, h2, st2, a = saved[i * 9:(i + 1) * 9]
             F3, F4 = Wqkv.shape[1], Wfc.shape[1]
             # MLP:  h3 = h2 + drop(gelu(u2 Wfc + b) Wpr + b)
             Wpr_b, Wfc_b = _bwd_weight(Wpr, plan.bf16), _bwd_weight(Wfc, plan.bf16)
@@ -695,16 +716,22 @@ class GPT2StackFn(torch.autograd.Function):
             gemm(F3, LORA_R, M, dqkv, F3, u, KE, dlB, LORA_R, a_layout=A_KM, b_layout=B_KN, b_off=D,
                  alpha=LORA_SCALE, split_k=pick_split_k(F3, LORA_R, M), bf16=plan.bf16)
             dlA = _empty(LORA_R, D, like=dh)
-            gemm(LORA_R, D, M, du, KE, u, KE, dlA, D, a_layout=A_KM, b_layout=B_KN, a_off=D, b_drop=lspec,
-                 split_k=pick_split_k(LORA_R, D, M, prec=plan.bf16), bf16=plan.bf16)
-            # LoRA path back to LN1's output: du[:, :D] += mask * (dz A)
-            gemm(M, D, LORA_R, du, KE, lA, D, du, KE, b_layout=B_KN, a_off=D, out_drop=lspec, accumulate=True, bf16=plan.bf16)
+            if u.dtype == torch.bfloat16:                     # bf16 mode: drop(LN1(h)) was stored as bf16 by the forward
+                b_in, ldb_in = (ud, D) if ud.numel() else (u, KE)
+                gemm(LORA_R, D, M, du, KE, b_in, ldb_in, dlA, D, a_layout=A_KM, b_layout=B_KN, a_off=D,
+                     split_k=pick_split_k(LORA_R, D, M, prec=plan.bf16), bf16=plan.bf16)
+            else:
+                gemm(LORA_R, D, M, du, KE, u, KE, dlA, D, a_layout=A_KM, b_layout=B_KN, a_off=D, b_drop=lspec,
+                     split_k=pick_split_k(LORA_R, D, M, prec=plan.bf16), bf16=plan.bf16)
+            # LoRA path back to LN1's output, du[:, :D] += mask * (dz A): folded into the LayerNorm backward's read of du
+            # (it used to be a K = 32 GEMM that read and re-wrote the whole M x 768 gradient)
             dhn = _empty(M, D, like=dh)
             sp = plan.spec(site_res2(i - 1), D) if i > 0 else None
             dhm = masked_buf(sp, params[(i - 1) * GPT2StackFn.PER_LAYER + 12]) if sp is not None else dhn
             dg1, db1 = ops.layernorm_bwd(du, KE, h, D, ln1w, st1, dh2, dhn, M, D,
                                          dx_masked=dhm if sp is not None else None, mask_drop=sp,
-                                         need_dgb=nig[pb + 0] or nig[pb + 1])
+                                         need_dgb=nig[pb + 0] or nig[pb + 1],
+                                         lora=(du, KE, D, lA.detach().contiguous(), lspec, b16))
             dh = dhn
             base = i * GPT2StackFn.PER_LAYER
             pgrads[base + 0], pgrads[base + 1] = dg1, db1

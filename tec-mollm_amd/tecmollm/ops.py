@@ -121,8 +121,16 @@ def gemm(M: int, N: int, K: int, A: torch.Tensor, lda: int, B: torch.Tensor, ldb
     if _timing_detail:
         name += (f" M={M} N={N} K={K} win={g.a_win.enabled}{g.b_win.enabled}{g.c_win.enabled}"
                  f" drop={int(g.a_drop.p > 0)}{int(g.b_drop.p > 0)}{int(g.out_drop.p > 0)} split={g.split_k}"
-                 f" act={g.act} acc={g.accumulate}")
-    _timing.append((name, 2.0 * M * N * K, e0, e1))
+                 f" act={g.act} acc={g.accumulate} dact={int(dact_src is not None)} res={int(residual is not None)}"
+                 f" pre={int(preact is not None)}")
+    # algorithmic HBM bytes of the call: every operand / result element once (a windowed operand: its source tensor once)
+    ea, eb, ec = A.element_size(), B.element_size(), Cout.element_size()
+    nbytes = (min(A.numel(), M * K) if g.a_win.enabled else M * K) * ea + (min(B.numel(), N * K) if g.b_win.enabled else N * K) * eb
+    nbytes += M * N * ec * (2 if accumulate else 1)
+    for t in (preact, dact_src, residual):
+        if t is not None:
+            nbytes += M * N * t[0].element_size()
+    _timing.append((name, 2.0 * M * N * K, e0, e1, float(nbytes)))
 
 
 PREC_FP32, PREC_BF16, PREC_BF16X3, PREC_BF16X6 = 0, 1, 2, 3
@@ -244,10 +252,12 @@ def disable_gemm_timing() -> None:
 def summarize_gemm_timing(records: list) -> dict:
     torch.cuda.synchronize()
     agg: dict = {}
-    for name, flops, e0, e1 in records:
-        a = agg.setdefault(name, {"ms": 0.0, "flops": 0.0, "n": 0})
+    for rec in records:
+        name, flops, e0, e1 = rec[:4]
+        a = agg.setdefault(name, {"ms": 0.0, "flops": 0.0, "n": 0, "bytes": 0.0})
         a["ms"] += e0.elapsed_time(e1)
         a["flops"] += flops
+        a["bytes"] += rec[4] if len(rec) > 4 else 0.0
         a["n"] += 1
     return agg
 
@@ -270,44 +280,66 @@ def pick_split_k(Mo: int, No: int, K: int, target_blocks: int = 512, min_chunk: 
 
 def layernorm_fwd(x: torch.Tensor, ldx: int, gamma: torch.Tensor, beta: torch.Tensor, y: Optional[torch.Tensor], ldy: int,
                   stats: torch.Tensor, M: int, D: int, eps: float = 1e-5, y_off: int = 0,
-                  y16: Optional[torch.Tensor] = None, ldy16: int = 0) -> None:
-    """y (fp32) and / or y16 (bf16 copy for a bf16 matrix-core GEMM, BASELINE configs[2])."""
-    if y16 is not None and y16.dtype != torch.bfloat16:
-        raise _lib.TecmError("layernorm_fwd: y16 must be a bfloat16 tensor")
+                  y16: Optional[torch.Tensor] = None, ldy16: int = 0, y16d: Optional[torch.Tensor] = None, ldy16d: int = 0,
+                  drop16d: Optional[TecmDrop] = None) -> None:
+    """y (fp32) and / or y16 (bf16 copy for a bf16 matrix-core GEMM, BASELINE configs[2]); y16d: a third, optional bf16
+    output = dropout(y, drop16d) rounded -- the LoRA branch's input (peft lora_dropout, modules.py:181)."""
+    for t, what in ((y16, "y16"), (y16d, "y16d")):
+        if t is not None and t.dtype != torch.bfloat16:
+            raise _lib.TecmError(f"layernorm_fwd: {what} must be a bfloat16 tensor")
+    if y16d is not None and drop16d is None:
+        raise _lib.TecmError("layernorm_fwd: y16d needs its dropout spec")
     check(lib().tecm_layernorm_fwd(x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(),
-                                   None if y is None else _off(y, y_off), ldy, ptr(y16), ldy16,
+                                   None if y is None else _off(y, y_off), ldy, ptr(y16), ldy16, ptr(y16d), ldy16d,
+                                   C.byref(drop16d) if drop16d is not None else None,
                                    stats.data_ptr(), M, D, eps, stream_ptr()), "tecm_layernorm_fwd")
 
 
-def layernorm_bwd_blocks(M: int, D: int) -> int:
+def _lora_back(lora) -> Optional["_lib.TecmLoraBack"]:
+    """lora = (du, ld, col_off, lora_A (r, D), drop spec or None, bf16_operands): dz = du[:, col_off:col_off + r]."""
+    if lora is None:
+        return None
+    du, ld, off, A, dspec, b16 = lora
+    if A.dtype != torch.float32 or not A.is_contiguous() or du.dtype != torch.float32:
+        raise _lib.TecmError("layernorm_bwd: the LoRA back-path takes fp32 dz and a contiguous fp32 lora_A")
+    return _lib.TecmLoraBack(dz=_off(du, off), ld_dz=ld, A=A.data_ptr(), r=A.shape[0], bf16_operands=1 if b16 else 0,
+                             drop=dspec if dspec is not None else NO_DROP)
+
+
+def layernorm_bwd_blocks(M: int, D: int, lora=None) -> int:
     nb = C.c_int32(0)
+    lb = _lora_back(lora)
     check(lib().tecm_layernorm_bwd(None, 0, None, 0, None, None, None, None, None, 0, None, None, C.byref(nb), M, D,
-                                   None), "tecm_layernorm_bwd(query)")
+                                   C.byref(lb) if lb is not None else None, None), "tecm_layernorm_bwd(query)")
     return nb.value
 
 
 def layernorm_bwd(dy: torch.Tensor, lddy: int, x: torch.Tensor, ldx: int, gamma: torch.Tensor, stats: torch.Tensor,
                   dres: Optional[torch.Tensor], dx: torch.Tensor, M: int, D: int,
                   dx_masked: Optional[torch.Tensor] = None,
-                  mask_drop: Optional[TecmDrop] = None, need_dgb: bool = True):
+                  mask_drop: Optional[TecmDrop] = None, need_dgb: bool = True, lora=None):
     """dx = dres + LN'(dy); optional dx_masked = dropout(dx, mask_drop) -- fp32, or bf16 when its only reader is a bf16
-    GEMM.  Returns (dgamma, dbeta), or (None, None) when need_dgb is False (frozen LayerNorm: the per-block partials are
-    not reduced)."""
+    GEMM.  lora = (du, ld, col_off, lora_A, drop, bf16_operands): the rank-r LoRA back-path
+    dy += dropmask * (du[:, col_off:col_off + r] @ lora_A) is folded into the row before the LayerNorm backward (no separate
+    K = r GEMM over the M x D gradient).  Returns (dgamma, dbeta), or (None, None) when need_dgb is False (frozen
+    LayerNorm: the per-block partials are not reduced)."""
     m16 = 1 if (dx_masked is not None and dx_masked.dtype == torch.bfloat16) else 0
-    nb = layernorm_bwd_blocks(M, D)
+    lb = _lora_back(lora)
+    nb = layernorm_bwd_blocks(M, D, lora)
     partials = torch.empty(nb, 2 * D, device=dx.device, dtype=torch.float32)
     nbc = C.c_int32(0)
     od = mask_drop if mask_drop is not None else NO_DROP
     check(lib().tecm_layernorm_bwd(dy.data_ptr(), lddy, x.data_ptr(), ldx, gamma.data_ptr(), stats.data_ptr(),
                                    ptr(dres), dx.data_ptr(), ptr(dx_masked), m16, C.byref(od), partials.data_ptr(),
-                                   C.byref(nbc), M, D, stream_ptr()), "tecm_layernorm_bwd")
+                                   C.byref(nbc), M, D, C.byref(lb) if lb is not None else None, stream_ptr()),
+          "tecm_layernorm_bwd")
     if not need_dgb:
         return None, None
     dgb = colsum(partials, 2 * D, nb, 1, 1, 2 * D)
     return dgb[0, :D], dgb[0, D:]
 
 
-GN_OUT_BF16 = 2
+GN_OUT_BF16, GN_DACT_BF16 = 2, 4
 
 
 def gn_reg_ok(L: int, N: int, Cout: int) -> bool:
@@ -328,25 +360,35 @@ def _gn_io(y: torch.Tensor, out: torch.Tensor) -> int:
 
 
 def groupnorm_gelu_fwd(y: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, act: torch.Tensor,
-                       stats: torch.Tensor, B: int, L: int, N: int, Cout: int, eps: float = 1e-5) -> None:
-    """act: fp32, or bf16 in bf16 mode (its dtype says which); y is fp32."""
+                       stats: torch.Tensor, B: int, L: int, N: int, Cout: int, eps: float = 1e-5, act_stride: int = 1) -> None:
+    """act: fp32, or bf16 in bf16 mode (its dtype says which); y is fp32.  act_stride s > 1: act is the COMPACT
+    (B, ceil(L / s), N, 3*Cout) tensor of the time steps t % s == 0 (all the stride-s 1x1 conv behind it reads)."""
+    La = (L + act_stride - 1) // act_stride
+    if act.numel() != B * La * N * 3 * Cout:
+        raise _lib.TecmError(f"groupnorm_gelu_fwd: act must hold (B, {La}, N, 3*Cout) values for act_stride {act_stride}")
     check(lib().tecm_groupnorm_gelu_fwd(y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), act.data_ptr(),
-                                        stats.data_ptr(), B, L, N, Cout, eps, _gn_io(y, act), stream_ptr()),
+                                        stats.data_ptr(), B, L, N, Cout, eps, _gn_io(y, act), act_stride, stream_ptr()),
           "tecm_groupnorm_gelu_fwd")
 
 
 def groupnorm_gelu_bwd(dact: torch.Tensor, dstride: int, y: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
                        stats: torch.Tensor, dy: torch.Tensor, B: int, L: int, N: int,
                        Cout: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    """Returns (dgamma, dbeta, colsum(dy)), each (3*Cout,); the last is the conv-bias gradient."""
+    """Returns (dgamma, dbeta, colsum(dy)), each (3*Cout,); the last is the conv-bias gradient.  dact: fp32, or (bf16 mode,
+    together with a bf16 dy) the bf16 tensor the strided 1x1 conv's d-input GEMM wrote."""
     nb = C.c_int32(0)
     check(lib().tecm_groupnorm_gelu_bwd(None, dstride, None, None, None, None, None, None, C.byref(nb), B, L, N, Cout,
                                         0, None), "tecm_groupnorm_gelu_bwd(query)")
     CT = 3 * Cout
     partials = torch.empty(nb.value, 3 * CT, device=dy.device, dtype=torch.float32)
+    io = _gn_io(y, dy)
+    if dact.dtype == torch.bfloat16:
+        if not io:
+            raise _lib.TecmError("groupnorm_gelu_bwd: a bf16 dact comes with a bf16 dy")
+        io |= GN_DACT_BF16
     check(lib().tecm_groupnorm_gelu_bwd(dact.data_ptr(), dstride, y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                         stats.data_ptr(), dy.data_ptr(), partials.data_ptr(), C.byref(nb), B, L, N,
-                                        Cout, _gn_io(y, dy), stream_ptr()), "tecm_groupnorm_gelu_bwd")
+                                        Cout, io, stream_ptr()), "tecm_groupnorm_gelu_bwd")
     dgb = colsum(partials, 3 * CT, nb.value, 1, 1, 3 * CT)
     return dgb[0, :CT], dgb[0, CT:2 * CT], dgb[0, 2 * CT:]
 

@@ -226,6 +226,74 @@ def test_layernorm_fwd_bwd(dev, M, D):
     assert torch.equal(dx2, dx) and torch.equal(dxm, dx * mult)
 
 
+@pytest.mark.parametrize("M", [1000, 37])
+def test_layernorm_fwd_dropped_bf16_output_is_the_lora_branch_input(dev, M):
+    """tecm_layernorm_fwd's third output: bf16(dropout(LN(x))) with the device hash at index row*ld + c -- the cast autocast
+    applies to lora_dropout(x) in front of lora_A (modules.py:181, train.py:68) -- next to the fp32 / bf16 outputs."""
+    from tecmollm import ops, rng
+    D, KE = 768, 800
+    x = _rand(M, D, dev=dev, seed=1)
+    g, b = 1 + 0.1 * _rand(D, dev=dev, seed=2), 0.1 * _rand(D, dev=dev, seed=3)
+    y = torch.empty(M, KE, device=dev)
+    y16 = torch.zeros(M, KE, device=dev, dtype=torch.bfloat16)
+    y16d = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
+    st = torch.empty(M, 2, device=dev)
+    ops.layernorm_fwd(x, D, g, b, y, KE, st, M, D, y16=y16, ldy16=KE, y16d=y16d, ldy16d=D, drop16d=ops.drop(0.1, 1234, KE))
+    idx = (np.arange(M, dtype=np.uint64)[:, None] * np.uint64(KE) + np.arange(D, dtype=np.uint64)[None, :])
+    mult = torch.from_numpy(rng.keep_mult(1234, idx, 0.1)).to(dev)
+    assert torch.equal(y16[:, :D], y[:, :D].bfloat16()) and float(y16[:, D:].float().abs().max()) == 0.0
+    assert torch.equal(y16d, (y[:, :D] * mult).bfloat16())
+    assert 0.05 < float((y16d == 0).float().mean()) < 0.15
+    # bf16-only call (the bf16 mode's LN1): no fp32 output at all
+    y16b, y16db = torch.empty_like(y16), torch.empty_like(y16d)
+    ops.layernorm_fwd(x, D, g, b, None, KE, st, M, D, y16=y16b, ldy16=KE, y16d=y16db, ldy16d=D, drop16d=ops.drop(0.1, 1234, KE))
+    assert torch.equal(y16b[:, :D], y16[:, :D]) and torch.equal(y16db, y16d)
+
+
+@pytest.mark.parametrize("M,bf16", [(1000, False), (1000, True), (37, False), (4099, True)])
+def test_layernorm_bwd_folds_the_lora_back_path(dev, M, bf16):
+    """tecm_layernorm_bwd with TecmLoraBack: dy[:, :D] += mask * (dz @ lora_A) before the LayerNorm backward (peft Linear
+    on c_attn, modules.py:177-186) equals the separate K = 32 accumulate GEMM followed by the plain kernel -- in exact
+    fp32, and in the bf16 mode's arithmetic (dz and lora_A rounded to bf16, fp32 accumulation)."""
+    from tecmollm import ops, rng
+    D, R, KE = 768, 32, 800
+    x = _rand(M, D, dev=dev, seed=1)
+    g = 1 + 0.1 * _rand(D, dev=dev, seed=2)
+    st = torch.empty(M, 2, device=dev)
+    ops.layernorm_fwd(x, D, g, torch.zeros(D, device=dev), torch.empty(M, D, device=dev), D, st, M, D)
+    du = _rand(M, KE, dev=dev, seed=4)
+    lA = _rand(R, D, dev=dev, seed=5, scale=0.05)
+    dres = _rand(M, D, dev=dev, seed=6)
+    spec = ops.drop(0.1, 4321, KE)
+    # reference composition: the GEMM the fused form replaces, then the plain LayerNorm backward
+    du_ref = du.clone()
+    ops.gemm(M, D, R, du_ref, KE, lA, D, du_ref, KE, b_layout=ops.B_KN, a_off=D, out_drop=spec, accumulate=True, bf16=bf16)
+    dx_ref, dxm_ref = torch.empty(M, D, device=dev), torch.empty(M, D, device=dev)
+    dg_ref, db_ref = ops.layernorm_bwd(du_ref, KE, x, D, g, st, dres, dx_ref, M, D, dx_masked=dxm_ref, mask_drop=ops.drop(0.1, 7, D))
+    dx, dxm = torch.empty(M, D, device=dev), torch.empty(M, D, device=dev)
+    dg, db = ops.layernorm_bwd(du, KE, x, D, g, st, dres, dx, M, D, dx_masked=dxm, mask_drop=ops.drop(0.1, 7, D),
+                               lora=(du, KE, D, lA, spec, bf16))
+    tol = 2e-5
+    assert _rel(dx, dx_ref) < tol and _rel(dxm, dxm_ref) < tol and _rel(dg, dg_ref) < tol and _rel(db, db_ref) < tol
+    # and against fp64 from first principles (the mask from the NumPy mirror of the device hash)
+    idx = (np.arange(M, dtype=np.uint64)[:, None] * np.uint64(KE) + np.arange(D, dtype=np.uint64)[None, :])
+    mult = torch.from_numpy(rng.keep_mult(4321, idx, 0.1)).to(dev).double()
+    dz, A = du[:, D:].double(), lA.double()
+    if bf16:
+        dz, A = du[:, D:].bfloat16().double(), lA.bfloat16().double()
+    dy_tot = du[:, :D].double() + mult * (dz @ A)
+    xd = x.double().requires_grad_(True)
+    gd = g.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xd, (D,), gd, None, 1e-5)
+    gx, gg = torch.autograd.grad(ref, (xd, gd), dy_tot)
+    assert _rel(dx, gx + dres.double()) < TOL and _rel(dg, gg) < TOL and _rel(db, dy_tot.sum(0)) < TOL
+    # eval mode: no mask
+    dx0 = torch.empty(M, D, device=dev)
+    ops.layernorm_bwd(du, KE, x, D, g, st, None, dx0, M, D, lora=(du, KE, D, lA, None, bf16))
+    gx0, = torch.autograd.grad(torch.nn.functional.layer_norm(xd, (D,), gd, None, 1e-5), (xd,), du[:, :D].double() + dz @ A)
+    assert _rel(dx0, gx0) < TOL
+
+
 # register-resident kernels: 4 waves/sequence (2304 quads), 8 waves (4608 quads: L_in = 96), forward-only 2 waves
 # (1152 quads, odd sequence count), Cout = 256; (2, 6, 3, 64, 1) and the backward of the 2-wave case take the
 # generic multi-pass kernels
@@ -258,6 +326,34 @@ def test_groupnorm_gelu_fwd_bwd(dev, Bn, L, N, Cout, stride):
     gy, gg, gb = torch.autograd.grad(ref, (yd, gd, bd), full)
     assert _rel(dy, gy) < TOL and _rel(dg, gg) < TOL and _rel(db, gb) < TOL
     assert _rel(dysum, gy.sum((0, 1, 2))) < TOL
+
+
+@pytest.mark.parametrize("Bn,L,N,Cout,stride", [(2, 48, 5, 64, 2), (1, 24, 9, 128, 2), (1, 96, 3, 64, 2), (1, 48, 3, 64, 3)])
+def test_groupnorm_gelu_compact_strided_act_and_bf16_dact(dev, Bn, L, N, Cout, stride):
+    """act_stride = s: only the time steps the stride-s 1x1 conv reads (modules.py:36-41) are written, into a compact
+    (B, ceil(L / s), N, CT) tensor, bit-identical to those rows of the full activation; the statistics still cover every
+    step.  Backward: a bf16 dact (TECM_GN_DACT_BF16) gives the result of the fp32 kernel fed the same rounded values."""
+    from tecmollm import TecmError, ops
+    CT = 3 * Cout
+    y = _rand(Bn, L, N, CT, dev=dev, seed=1)
+    g, b = 1 + 0.1 * _rand(CT, dev=dev, seed=2), 0.1 * _rand(CT, dev=dev, seed=3)
+    La = (L + stride - 1) // stride
+    for dt in (torch.float32, torch.bfloat16):
+        full, st = torch.empty(Bn, L, N, CT, device=dev, dtype=dt), torch.empty(Bn * N, 3, 2, device=dev)
+        comp, st2 = torch.full((Bn, La, N, CT), float("nan"), device=dev, dtype=dt), torch.empty(Bn * N, 3, 2, device=dev)
+        ops.groupnorm_gelu_fwd(y, g, b, full, st, Bn, L, N, Cout)
+        ops.groupnorm_gelu_fwd(y, g, b, comp, st2, Bn, L, N, Cout, act_stride=stride)
+        assert torch.equal(comp, full[:, ::stride]) and torch.equal(st, st2)
+    with pytest.raises(TecmError):
+        ops.groupnorm_gelu_fwd(y, g, b, full, st, Bn, L, N, Cout, act_stride=stride)      # wrong size for a compact act
+    dact = _rand(Bn, La, N, CT, dev=dev, seed=4)
+    d16 = dact.bfloat16()
+    dy_a, dy_b = torch.empty(Bn, L, N, CT, device=dev, dtype=torch.bfloat16), torch.empty(Bn, L, N, CT, device=dev, dtype=torch.bfloat16)
+    ra = ops.groupnorm_gelu_bwd(d16, stride, y, g, b, st, dy_a, Bn, L, N, Cout)
+    rb = ops.groupnorm_gelu_bwd(d16.float(), stride, y, g, b, st, dy_b, Bn, L, N, Cout)
+    assert torch.equal(dy_a, dy_b) and all(torch.equal(p, q) for p, q in zip(ra, rb))
+    with pytest.raises(TecmError):
+        ops.groupnorm_gelu_bwd(d16, stride, y, g, b, st, torch.empty(Bn, L, N, CT, device=dev), Bn, L, N, Cout)   # bf16 dact, fp32 dy
 
 
 def test_colsum_segments_and_dropout(dev):

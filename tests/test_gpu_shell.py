@@ -414,6 +414,32 @@ def test_bench_py_starts_its_own_ranks(dev):
     assert len(sm["mean"]) == 2 and 0 < sm["min_over_ranks"] <= sm["max_over_ranks"] <= sm["slowest_single_step"] * 1.0001
 
 
+def test_bench_py_four_rank_rehearsal_on_one_card(dev):
+    """The widest rank count this pool's process guard admits on one card (at most 6 of our processes may hold the GPU:
+    the test runner + 4 ranks; the launcher parent never touches it): `bench.py --gpus 4 --batch 1` over gloo -- four
+    children from the sysfs-counting launcher, an 8-float checksum tail, rank-0-only stdout.  (The 8-rank form of the same
+    host logic runs on CPU: tests/test_host.py::test_data_parallel_step_eight_ranks_one_sample_each.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TECM_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1",
+                        "--batch", "1", "--no-kernel-timing", "--precision", "bf16"], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                              # rank 0 alone prints
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 4 and line["config"]["global_batch"] == 4 and line["config"]["parallelism"] == "dp4"
+    d = line["config"]["dist"]
+    assert d["world_size"] == 4 and d["allreduce_of_ones"] == 4.0 and d["param_checksum_min_eq_max"] is True
+    assert len(d["allreduce_ms"]["per_rank_mean"]) == 4 and len(d["step_ms_per_rank"]["mean"]) == 4
+    assert d["allreduce_ms"]["bytes"] == 4 * (3_081_996 - 52_896 + (2911 + 12 + 366 + 13 + 4) * 12 + 2 * 4)
+
+
 def _bench_line(extra, env_extra=None, launcher=None):
     import json
     import subprocess

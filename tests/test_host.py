@@ -266,6 +266,54 @@ def test_data_parallel_step_two_ranks_equals_single_rank_on_global_batch():
     assert torch.allclose(out[0], single, rtol=1e-5, atol=1e-6)
 
 
+def _dp8_worker(rank, world, port, out, odd_rank):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tecmollm.train import TrainStep
+        torch.manual_seed(0 if rank != odd_rank else 999)  # odd_rank >= 0: that one rank starts from other weights
+        model = _Toy()
+        ts = TrainStep(model, world_size=world, fused_huber=False, optimizer="torch", broadcast_init=odd_rank < 0)
+        assert ts.flat_grad_ext.numel() - ts.flat_grad.numel() == 2 * world      # the checksum tail: 2 floats per rank
+        g = torch.Generator().manual_seed(100)
+        X = torch.randn(world, 5, 9, 6, generator=g)
+        Y = torch.randn(world, 12, 9, 1, generator=g)
+        try:
+            for _ in range(3):
+                ts.step(X[rank:rank + 1], None, None, None, Y[rank:rank + 1])
+            out[rank] = ("ok", torch.cat([p.detach().flatten() for p in model.parameters()]))
+        except RuntimeError as e:
+            out[rank] = ("diverged", str(e))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_step_eight_ranks_one_sample_each():
+    """The reference's widest configuration (BASELINE configs[3]: 8 ranks): world_size 8 over gloo, one sample per rank --
+    the ONE all-reduce per step carries the flat gradient plus a 16-float checksum tail; the ranks stay bit-identical and
+    reproduce the single-process step on the 8-sample batch; a single rank (5) that starts from other weights is caught
+    by every rank on the first step."""
+    from tecmollm.train import TrainStep
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_dp8_worker, args=(8, _free_port(), out, -1), nprocs=8, join=True)
+    assert all(out[r][0] == "ok" for r in range(8))
+    for r in range(1, 8):
+        assert torch.equal(out[r][1], out[0][1])
+    torch.manual_seed(0)
+    model = _Toy()
+    ts = TrainStep(model, world_size=1, fused_huber=False, optimizer="torch")
+    g = torch.Generator().manual_seed(100)
+    X, Y = torch.randn(8, 5, 9, 6, generator=g), torch.randn(8, 12, 9, 1, generator=g)
+    for _ in range(3):
+        ts.step(X, None, None, None, Y)
+    single = torch.cat([p.detach().flatten() for p in model.parameters()])
+    assert torch.allclose(out[0][1], single, rtol=1e-5, atol=1e-6)
+    out2 = mgr.dict()
+    mp.spawn(_dp8_worker, args=(8, _free_port(), out2, 5), nprocs=8, join=True)
+    assert all(out2[r][0] == "diverged" for r in range(8))
+
+
 def _sync_worker(rank, world, port, out, broadcast_init):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)

@@ -26,7 +26,7 @@ for ld_in, cin, Cout, L in blocks:
         out.backward(torch.randn_like(out))
     torch.cuda.synchronize()
     agg = collections.OrderedDict()
-    for name, flops, e0, e1 in rec:
+    for name, flops, e0, e1 in (r[:4] for r in rec):
         a = agg.setdefault(name, [0.0, 0.0])
         a[0] += e0.elapsed_time(e1) * 1e3
         a[1] += flops

@@ -331,8 +331,8 @@ def roofline_of(agg: dict, step_ms: float, steps: int, args, precision: str, bat
     shapes = []
     for key, r in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
         kern, f = _parse_detail(key)
-        if "M" not in f or r["flops"] / r["n"] < 2e10:
-            continue
+        if "M" not in f or r["flops"] / r["n"] < 2e10 or not f.get("K", "").isdigit() or "seq" in kern:
+            continue                                       # the sequence-tile conv kernels carry no operand byte count
         n_, k_ = int(f["N"]), int(f["K"])
         flags = {"res": f.get("res") == "1", "pre": f.get("pre") == "1", "dact": f.get("dact") == "1"}
         label = next((lab for lab, pred in _LAYER_SHAPES if int(f["M"]) == batch * 2911 * (L_in // 16) and pred(n_, k_, flags)), None)

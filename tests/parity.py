@@ -276,7 +276,7 @@ def assert_parity(res: dict, tol: Optional[float] = None, kink: bool = False, el
     if elem_scale:              # named tensors whose element-wise bar a test widens by a stated factor (and says why)
         for k, (_, ee, _) in res["per_param"].items():
             if not (k in KINK_TENSORS and not b16):
-                assert ee < elem_scale.get(k, 1.0), (k, ee, brief)
+                assert ee < elem_scale.get(k, elem_scale.get("*", 1.0)), (k, ee, brief)
     else:
         assert res["grad_elem_max"] < 1.0, brief
     if kink:

@@ -195,6 +195,11 @@ int tecm_spatial_bwd_blocks(const TecmSpatial* d);
 #define TECM_GN_OUT_BF16 2
 /* backward only, with TECM_GN_OUT_BF16: dact is a bf16 tensor (written by the bf16 GEMM of the strided 1x1 conv's d-input) */
 #define TECM_GN_DACT_BF16 4
+/* y itself is the bf16 tensor a bf16 Conv1d hands to the fp32 GroupNorm under autocast (train.py:68; tecm_conv_fwd_bf16 with
+ * y_bf16): forward with TECM_GN_OUT_BF16, backward with TECM_GN_OUT_BF16 | TECM_GN_DACT_BF16 -- every tensor bf16, statistics
+ * and arithmetic fp32.  Served for L * 3*Cout/8 <= 2560 (tecm_gn_y16_supported). */
+#define TECM_GN_Y_BF16 1
+int tecm_gn_y16_supported(int32_t L, int32_t N, int32_t Cout);
 /* act_stride s >= 1: only the time steps t % s == 0 are written, into a COMPACT (B, ceil(L / s), N, CT) tensor -- the
  * stride-s 1x1 conv behind the block (modules.py:36-41) reads nothing else; the statistics cover every step.  s > 1 is
  * served by the register-resident kernels only (TECM_E_ARG otherwise: callers ask tecm_gn_reg_ok first). */
@@ -302,8 +307,9 @@ typedef struct TecmConvFwd {
   const void* inp;
   const void* wpack;
   const float* bias;
-  float* y;
-  int32_t B, Lc, N, Cout, ld_in, _pad;
+  float* y;                    /* fp32; y_bf16 != 0 (tecm_conv_fwd_bf16 only): a bf16 (B, Lc, N, 3*Cout) tensor -- what a bf16
+                                  Conv1d returns under autocast (train.py:68), read by the TECM_GN_Y_BF16 norm kernels */
+  int32_t B, Lc, N, Cout, ld_in, y_bf16;
 } TecmConvFwd;
 int tecm_conv_fwd_pack(const float* w3, const float* w5, const float* w7, void* wpack, int32_t Cout, int32_t Cin,
                        int32_t ld_in, void* stream);

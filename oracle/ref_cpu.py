@@ -277,6 +277,18 @@ def conv1d(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, q: Rounding = F
     return _Conv1d.apply(x, w, stride, padding, q.fwd, q.bwd, q.bwd) + bias.view(1, -1, 1)
 
 
+def conv_y_bf16(L: int, Cout: int, ld_in: int) -> bool:
+    """Mirror of the device policy (ConvBlockFn: y16): in bf16 mode the conv output y is STORED as the bf16 tensor a bf16
+    Conv1d returns under autocast wherever the sequence-tile forward kernel writes it (tecm_conv_fwd_supported: L % 8 == 0,
+    Cout <= 128, ld_in % 8 == 0, (min(L, 48) + 7) * 4 rows of an odd number of 16-byte slots within 64 KiB) and the
+    all-bf16 norm kernels read it (tecm_gn_y16_supported: L * 3*Cout/8 <= 2560)."""
+    if not conv_acts_bf16(L, Cout) or L % 8 or Cout % 32 or Cout > 128 or ld_in % 8 or ld_in > 128:
+        return False
+    slots = ld_in * 2 // 16
+    slots += 1 - slots % 2
+    return (min(L, 48) + 7) * 4 * slots * 16 <= 65536 and L * (3 * Cout // 8) <= 2560
+
+
 # ------------------------------------------------------------------- stage a-4/a-5
 def conv_block(x: torch.Tensor, p: Params, idx: int, stride: int, q: Rounding = FP32) -> torch.Tensor:
     """Multi_Scale_Conv_Block.forward, modules.py:43-60: x (S, C_in, L).
@@ -286,6 +298,9 @@ def conv_block(x: torch.Tensor, p: Params, idx: int, stride: int, q: Rounding = 
     for j, k in enumerate((3, 5, 7)):
         pre = f"{P_CONV}{idx}.convs.{j}."
         y = conv1d(x, p[pre + "0.weight"], p[pre + "0.bias"], q, padding=(k - 1) // 2)
+        cin = x.shape[1]
+        if conv_y_bf16(x.shape[-1], y.shape[1], 24 if cin == 22 else cin):
+            y = stored(y, q)                                 # autocast's Conv1d output IS a bf16 tensor; the norm is fp32
         y = F.group_norm(y, 1, p[pre + "1.weight"], p[pre + "1.bias"], eps=1e-5)
         outs.append(F.gelu(y))
     cat = torch.cat(outs, dim=1)

@@ -446,7 +446,8 @@ struct FArgs {
   const void* inp;             // bf16 or fp32 (B, Lc, N, ld_in)
   const void* wpack;           // fragment-ordered weights, the element type of inp
   const float* bias;           // [3 * Cout]: b3 | b5 | b7
-  float* y;                    // fp32 (B, Lc, N, 3 * Cout)
+  float* y;                    // fp32 (B, Lc, N, 3 * Cout) -- or bf16 when y16 (the bf16 kernel only)
+  int y16;
   int B, Lc, N, Cout, ld_in, TC, nchunk, nblk, pitch;
   int nb32;                    // Cout / 32: unit u = (kernel size j = u / nb32, channel block u % nb32)
   unsigned long long assign;   // 4 waves x 3 unit ids of 4 bits (15 = none): no kernel-argument arrays -- indexing
@@ -556,8 +557,33 @@ __global__ __launch_bounds__(NTH, 2) void conv_fwd_seq_kernel(const FArgs a) {
     // ---- this unit's 32 channels of every row of the tile: accumulator register e of lane (co, h) is data row
     //      (e & 3) + 8 (e >> 2) + 4 h of its row tile, i.e. time step 8 i + 2 (e >> 2) + h, node e & 3
     const float bv = a.bias[col0 + r];
+    const int tstride = a.N * CT;                          // one time step, in elements (a tile spans < 2^31 of them)
+    if (a.y16) {
+      // y as the bf16 tensor a bf16 Conv1d produces under autocast (train.py:68): neighbouring lanes (channels c, c + 1)
+      // trade one value per register pair, so that the even lane stores (c, c + 1) of node e0 & 3 and the odd lane
+      // (c - 1, c) of the next node as ONE 4-byte word each -- half the store instructions of the fp32 form, half the bytes
+      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+      const bool odd = (lane & 1) != 0;
+      __bf16* yh = reinterpret_cast<__bf16*>(a.y) + (((int64_t)b * a.Lc + t0 + h) * a.N + n0) * CT + col0 + (r & ~1);
+#pragma unroll
+      for (int i = 0; i < MAXT; ++i) {
+        if (i < ntt) {
+#pragma unroll
+          for (int ep = 0; ep < 8; ++ep) {
+            const float v0 = acc[i][2 * ep] + bv, v1 = acc[i][2 * ep + 1] + bv;
+            const float send = odd ? v0 : v1;
+            const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, false));
+            bf16x2 pk;
+            pk[0] = (__bf16)(odd ? recv : v0);
+            pk[1] = (__bf16)(odd ? v1 : recv);
+            const int e = 2 * ep + (odd ? 1 : 0), n = e & 3;
+            if (n0 + n < a.N) *reinterpret_cast<bf16x2*>(yh + (8 * i + 2 * (e >> 2)) * tstride + n * CT) = pk;
+          }
+        }
+      }
+      continue;
+    }
     float* yb = a.y + (((int64_t)b * a.Lc + t0 + h) * a.N + n0) * CT + col0 + r;       // (time t0 + h, node n0)
-    const int tstride = a.N * CT;                          // one time step, in floats (a tile spans < 2^31 of them)
 #pragma unroll
     for (int i = 0; i < MAXT; ++i) {
       if (i < ntt) {
@@ -777,6 +803,9 @@ static int conv_fwd_launch(const TecmConvFwd* p, void* stream, bool f32, const c
   a.wpack = p->wpack;
   a.bias = p->bias;
   a.y = p->y;
+  a.y16 = p->y_bf16 != 0;
+  TECM_REQUIRE(!(a.y16 && f32), TECM_E_ARG, "%s: a bf16 y is written by the bf16 kernel only", who);
+  TECM_REQUIRE(!a.y16 || tecm_aligned(p->y, 4), TECM_E_ALIGN, "%s: y must be 4-byte aligned", who);
   a.B = p->B; a.Lc = p->Lc; a.N = p->N; a.Cout = p->Cout; a.ld_in = p->ld_in;
   const size_t lds = conv_fwd_lds(p->Lc, p->ld_in, f32, &a.pitch, &a.TC);
   a.nchunk = (p->Lc + a.TC - 1) / a.TC;

@@ -713,6 +713,301 @@ __global__ __launch_bounds__((GnGeom<CPB, WPS>::NTHR)) void gn_gelu_bwd_reg(cons
   for (int c = threadIdx.x; c < 3 * G::CT; c += G::NTHR) partials[(int64_t)blockIdx.x * 3 * G::CT + c] = red[c];
 }
 
+// ------------------------------------------------------------------------------ GroupNorm(1) + GELU on a bf16 y (round 4)
+// bf16 mode: the conv output y is the bf16 tensor a bf16 Conv1d hands to the fp32 GroupNorm under autocast (train.py:68;
+// conv_fwd_seq writes it as such), and every tensor these kernels touch is bf16 (y, act, dact, dy).  The register-resident
+// kernels above are bound by memory requests in flight, not bytes -- fed 8-byte quads they got slower, not faster -- so here
+// a lane's unit is an OCT (8 consecutive channels = one 16-byte load / store): the same number of requests per lane, twice
+// the elements, half the waves per sequence.  Oct o = l2 + LPS*k of lane l2 (k = 0..NG-1) is row t = o / OPR, oct o % OPR
+// (OPR = CT/8 octs per row); 3*LPS is a multiple of OPR for CT in {192, 384, 768}, so a lane meets three channel octs
+// (slot = k % 3).  The sequence need not fill the last round of lanes: L*OPR <= LPS*NG, octs past the end are skipped.
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8n __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x8 gn_ld8(const void* p, int64_t off) {
+  const bf16x8n v = *reinterpret_cast<const bf16x8n*>(reinterpret_cast<const __bf16*>(p) + off);
+  f32x8 r;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) r[e] = (float)v[e];
+  return r;
+}
+__device__ __forceinline__ void gn_st8(void* p, int64_t off, const f32x8& v) {
+  bf16x8n h;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) h[e] = (__bf16)v[e];
+  *reinterpret_cast<bf16x8n*>(reinterpret_cast<__bf16*>(p) + off) = h;
+}
+__device__ __forceinline__ f32x8 gn_ld8f(const float* p) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  f32x8 r = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  return r;
+}
+__device__ __forceinline__ float sum8(const f32x8& v) { return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])); }
+
+template <int CPB, int WPS>
+struct GnGeom8 {
+  static constexpr int CT = 192 * CPB;
+  static constexpr int OPR = CT / 8;        // octs per row
+  static constexpr int OPB = OPR / 3;       // octs per branch
+  static constexpr int LPS = 64 * WPS;      // lanes per sequence
+  static constexpr int NTHR = WPS > 4 ? 64 * WPS : 256;
+  static constexpr int SPB = NTHR / LPS;
+  static constexpr int DT = LPS / OPR, DQ = LPS % OPR;
+  static_assert((3 * LPS) % OPR == 0, "slot period");
+};
+
+constexpr int GN8_NG = 5;                    // octs per lane (40 values): L * OPR <= 64 * WPS * 5
+
+template <int CPB, int WPS>
+__global__ __launch_bounds__((GnGeom8<CPB, WPS>::NTHR)) void gn_gelu_fwd_reg16(const void* __restrict__ y, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, void* __restrict__ act,
+                                                          float* __restrict__ stats, int B, int L, int N, float eps,
+                                                          int astride) {
+  using G = GnGeom8<CPB, WPS>;
+  __shared__ float xch[G::NTHR / 64][3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sp = wave / WPS, half = wave % WPS, l2 = half * 64 + lane;
+  int64_t sidx = (int64_t)blockIdx.x * G::SPB + sp;
+  const bool live = sidx < (int64_t)B * N;
+  if (!live) sidx = (int64_t)B * N - 1;
+  const int b = (int)(sidx / N), n = (int)(sidx - (int64_t)b * N);
+  const int64_t tstride = (int64_t)N * G::CT;
+  const int64_t base = ((int64_t)b * L * N + n) * G::CT;
+  const int La = (L + astride - 1) / astride;
+  const int64_t abase = ((int64_t)b * La * N + n) * G::CT;
+  const float inv_cnt = 1.0f / (float)(L * CPB * 64);
+  int qs[3], brs[3];
+  {
+    int q = l2 % G::OPR;
+#pragma unroll
+    for (int s_ = 0; s_ < 3; ++s_) {
+      qs[s_] = q;
+      brs[s_] = q / G::OPB;
+      q += G::DQ;
+      if (q >= G::OPR) q -= G::OPR;
+    }
+  }
+  f32x8 v[GN8_NG];
+  int32_t aoff[GN8_NG];                                   // offset in the (compact) act tensor; -1: not written; -2: no such oct
+  {
+    int t = l2 / G::OPR, q = l2 % G::OPR;
+#pragma unroll
+    for (int k = 0; k < GN8_NG; ++k) {
+      const bool has = t < L;
+      aoff[k] = !has ? -2 : ((t % astride) == 0 ? (t / astride) * (int32_t)tstride + q * 8 : -1);
+      const int tc = has ? t : L - 1;                      // clamped: an unconditional load, the value is not used
+      v[k] = gn_ld8(y, base + tc * (int32_t)tstride + q * 8);
+      if (!has)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[k][e] = 0.f;
+      t += G::DT;
+      q += G::DQ;
+      if (q >= G::OPR) { q -= G::OPR; ++t; }
+    }
+  }
+  f32x8 gm[3], bt[3];
+#pragma unroll
+  for (int s_ = 0; s_ < 3; ++s_) {
+    gm[s_] = gn_ld8f(gamma + qs[s_] * 8);
+    bt[s_] = gn_ld8f(beta + qs[s_] * 8);
+  }
+  float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < GN8_NG; ++k) acc[k % 3] += sum8(v[k]);          // absent octs hold zeros
+  float mean[3];
+#pragma unroll
+  for (int bb = 0; bb < 3; ++bb)
+    mean[bb] = (brs[0] == bb ? acc[0] : 0.f) + (brs[1] == bb ? acc[1] : 0.f) + (brs[2] == bb ? acc[2] : 0.f);
+  seq_reduce3<WPS>(mean, xch, wave, lane);
+#pragma unroll
+  for (int bb = 0; bb < 3; ++bb) mean[bb] *= inv_cnt;
+  float ms[3];
+#pragma unroll
+  for (int s_ = 0; s_ < 3; ++s_) ms[s_] = sel3(brs[s_], mean[0], mean[1], mean[2]);
+  acc[0] = acc[1] = acc[2] = 0.f;
+#pragma unroll
+  for (int k = 0; k < GN8_NG; ++k)
+    if (aoff[k] != -2) {
+      const float m = ms[k % 3];
+      float q2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = v[k][e] - m;
+        q2 += d * d;
+      }
+      acc[k % 3] += q2;
+    }
+  float rstd[3];
+#pragma unroll
+  for (int bb = 0; bb < 3; ++bb)
+    rstd[bb] = (brs[0] == bb ? acc[0] : 0.f) + (brs[1] == bb ? acc[1] : 0.f) + (brs[2] == bb ? acc[2] : 0.f);
+  seq_reduce3<WPS>(rstd, xch, wave, lane);
+#pragma unroll
+  for (int bb = 0; bb < 3; ++bb) rstd[bb] = 1.0f / sqrtf(rstd[bb] * inv_cnt + eps);
+  float rs[3];
+#pragma unroll
+  for (int s_ = 0; s_ < 3; ++s_) rs[s_] = sel3(brs[s_], rstd[0], rstd[1], rstd[2]);
+  if (live) {
+#pragma unroll
+    for (int k = 0; k < GN8_NG; ++k)
+      if (aoff[k] >= 0) {
+        const int s_ = k % 3;
+        f32x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = gelu_erf_fast((v[k][e] - ms[s_]) * rs[s_] * gm[s_][e] + bt[s_][e]);
+        gn_st8(act, abase + aoff[k], o);
+      }
+    if (half == 0 && lane < 3) {
+      stats[(sidx * 3 + lane) * 2] = sel3(lane, mean[0], mean[1], mean[2]);
+      stats[(sidx * 3 + lane) * 2 + 1] = sel3(lane, rstd[0], rstd[1], rstd[2]);
+    }
+  }
+}
+
+template <int CPB, int WPS>
+__global__ __launch_bounds__((GnGeom8<CPB, WPS>::NTHR)) void gn_gelu_bwd_reg16(const void* __restrict__ dact, int dstride, int L2,
+                                                          const void* __restrict__ y, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ stats,
+                                                          void* __restrict__ dy, float* __restrict__ partials, int B,
+                                                          int L, int N) {
+  using G = GnGeom8<CPB, WPS>;
+  __shared__ float xch[G::NTHR / 64][3];
+  __shared__ float red[3 * G::CT];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sp = wave / WPS, half = wave % WPS, l2 = half * 64 + lane;
+  const int64_t tstride = (int64_t)N * G::CT;
+  const float inv_cnt = 1.0f / (float)(L * CPB * 64);
+  for (int c = threadIdx.x; c < 3 * G::CT; c += G::NTHR) red[c] = 0.f;
+  int qs[3], brs[3];
+  {
+    int q = l2 % G::OPR;
+#pragma unroll
+    for (int s_ = 0; s_ < 3; ++s_) {
+      qs[s_] = q;
+      brs[s_] = q / G::OPB;
+      q += G::DQ;
+      if (q >= G::OPR) q -= G::OPR;
+    }
+  }
+  f32x8 gm[3], bt[3], dgm[3], dbt[3], dys[3];
+#pragma unroll
+  for (int s_ = 0; s_ < 3; ++s_) {
+    gm[s_] = gn_ld8f(gamma + qs[s_] * 8);
+    bt[s_] = gn_ld8f(beta + qs[s_] * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dgm[s_][e] = dbt[s_][e] = dys[s_][e] = 0.f;
+  }
+  const int64_t S = (int64_t)B * N;
+  for (int64_t s0 = (int64_t)blockIdx.x * G::SPB; s0 < S; s0 += (int64_t)gridDim.x * G::SPB) {
+    int64_t sidx = s0 + sp;
+    const bool live = sidx < S;
+    if (!live) sidx = S - 1;
+    const int b = (int)(sidx / N), n = (int)(sidx - (int64_t)b * N);
+    const int64_t ybase = ((int64_t)b * L * N + n) * G::CT;
+    const int64_t dbase = ((int64_t)b * L2 * N + n) * G::CT;
+    float mean[3], rstd[3];
+#pragma unroll
+    for (int bb = 0; bb < 3; ++bb) {
+      mean[bb] = stats[(sidx * 3 + bb) * 2];
+      rstd[bb] = stats[(sidx * 3 + bb) * 2 + 1];
+    }
+    float ms[3], rs[3];
+#pragma unroll
+    for (int s_ = 0; s_ < 3; ++s_) {
+      ms[s_] = sel3(brs[s_], mean[0], mean[1], mean[2]);
+      rs[s_] = sel3(brs[s_], rstd[0], rstd[1], rstd[2]);
+    }
+    f32x8 yh[GN8_NG], gd[GN8_NG];
+    int32_t off[GN8_NG];                                   // -1: no such oct
+    {
+      int t = l2 / G::OPR, q = l2 % G::OPR;
+#pragma unroll
+      for (int k = 0; k < GN8_NG; ++k) {
+        const bool has = t < L;
+        const int tc = has ? t : L - 1;
+        off[k] = has ? tc * (int32_t)tstride + q * 8 : -1;
+        yh[k] = gn_ld8(y, ybase + tc * (int32_t)tstride + q * 8);
+        const bool hd = has && (tc % dstride) == 0;
+        gd[k] = gn_ld8(dact, dbase + (tc / dstride) * (int32_t)tstride + q * 8);   // unconditional (clamped), masked below
+        if (!hd)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) gd[k][e] = 0.f;
+        t += G::DT;
+        q += G::DQ;
+        if (q >= G::OPR) { q -= G::OPR; ++t; }
+      }
+    }
+    float a1[3] = {0.f, 0.f, 0.f}, a2[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < GN8_NG; ++k) {
+      const int s_ = k % 3;
+      const bool has = off[k] >= 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float h_ = (yh[k][e] - ms[s_]) * rs[s_];
+        const float g_ = gd[k][e] * dgelu_erf_fast(h_ * gm[s_][e] + bt[s_][e]);     // gd = 0 where there is no gradient
+        if (live && has) { dgm[s_][e] += g_ * h_; dbt[s_][e] += g_; }
+        const float d_ = has ? g_ * gm[s_][e] : 0.f;
+        a1[s_] += d_;
+        a2[s_] += d_ * h_;
+        yh[k][e] = h_;
+        gd[k][e] = d_;
+      }
+    }
+    float s1[3], s2[3];
+#pragma unroll
+    for (int bb = 0; bb < 3; ++bb) {
+      s1[bb] = (brs[0] == bb ? a1[0] : 0.f) + (brs[1] == bb ? a1[1] : 0.f) + (brs[2] == bb ? a1[2] : 0.f);
+      s2[bb] = (brs[0] == bb ? a2[0] : 0.f) + (brs[1] == bb ? a2[1] : 0.f) + (brs[2] == bb ? a2[2] : 0.f);
+    }
+    seq_reduce3<WPS>(s1, xch, wave, lane);
+    seq_reduce3<WPS>(s2, xch, wave, lane);
+    float m1[3], m2[3];
+#pragma unroll
+    for (int s_ = 0; s_ < 3; ++s_) {
+      m1[s_] = sel3(brs[s_], s1[0], s1[1], s1[2]) * inv_cnt;
+      m2[s_] = sel3(brs[s_], s2[0], s2[1], s2[2]) * inv_cnt;
+    }
+    if (live) {
+#pragma unroll
+      for (int k = 0; k < GN8_NG; ++k)
+        if (off[k] >= 0) {
+          const int s_ = k % 3;
+          f32x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            o[e] = rs[s_] * (gd[k][e] - m1[s_] - yh[k][e] * m2[s_]);
+            dys[s_][e] += o[e];                            // conv-bias gradient
+          }
+          gn_st8(dy, ybase + off[k], o);
+        }
+    }
+  }
+  // block reduction of the per-lane parameter gradients in a FIXED order (as gn_gelu_bwd_reg): for a given slot the holders
+  // of one oct are the lanes with the same l2 % OPR, ranked by (sequence of the block, l2 / OPR)
+  {
+    constexpr int RMAX = (G::LPS + G::OPR - 1) / G::OPR;
+    const int rank = sp * RMAX + l2 / G::OPR;
+#pragma unroll
+    for (int s_ = 0; s_ < 3; ++s_) {
+      const int c = qs[s_] * 8;
+      for (int r = 0; r < G::SPB * RMAX; ++r) {
+        __syncthreads();
+        if (r == rank) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            red[c + e] += dgm[s_][e];
+            red[G::CT + c + e] += dbt[s_][e];
+            red[2 * G::CT + c + e] += dys[s_][e];
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 3 * G::CT; c += G::NTHR) partials[(int64_t)blockIdx.x * 3 * G::CT + c] = red[c];
+}
+
 // ------------------------------------------------------------------------------ column sums
 // stage 1: grid (colblocks, RB, nseg).  Lane = column, the 4 waves stride the block's row chunk.
 __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ in, int64_t ld, int64_t outer,
@@ -858,12 +1153,25 @@ int gn_reg_pairs(int L, int N, int Cout, int wps, int npmax, const void* a, cons
   if (!tecm_aligned(a, 16) || !tecm_aligned(b, 16)) return 0;
   return (int)(quads / lps);
 }
+// waves per sequence of the bf16-y oct kernels (4 or 8), 0 when the sequence does not fit 5 octs per lane
+int gn16_wps(int L, int N, int Cout, const void* a, const void* b) {
+  if (Cout != 64 && Cout != 128 && Cout != 256) return 0;
+  const int64_t octs = (int64_t)L * (3 * Cout / 8);
+  if ((int64_t)L * N * 3 * Cout >= (1ll << 31)) return 0;
+  if ((a && !tecm_aligned(a, 16)) || (b && !tecm_aligned(b, 16))) return 0;
+  if (octs <= 256 * GN8_NG) return 4;
+  if (octs <= 512 * GN8_NG) return 8;
+  return 0;
+}
 int gn_blocks(int64_t S) {
   const int64_t want = (S + 3) / 4;
   return (int)(want < 1024 ? want : 1024);
 }
 
 }  // namespace
+
+// 1 when the all-bf16 GroupNorm kernels (TECM_GN_Y_BF16) serve sequences of L steps x 3*Cout channels, else 0
+extern "C" int tecm_gn_y16_supported(int32_t L, int32_t N, int32_t Cout) { return gn16_wps(L, N, Cout, nullptr, nullptr) > 0 ? 1 : 0; }
 
 extern "C" int tecm_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y,
                                   int64_t ldy, void* y16, int64_t ldy16, void* y16d, int64_t ldy16d, const TecmDrop* drop,
@@ -964,9 +1272,30 @@ extern "C" int tecm_groupnorm_gelu_fwd(const void* y_, const float* gamma, const
                                        int32_t io_bf16, int32_t act_stride, void* stream) {
   const float* y = reinterpret_cast<const float*>(y_);
   float* act = reinterpret_cast<float*>(act_);
-  TECM_REQUIRE(io_bf16 == 0 || io_bf16 == TECM_GN_OUT_BF16, TECM_E_ARG, "tecm_groupnorm_gelu_fwd: io_bf16 is 0 or TECM_GN_OUT_BF16");
+  TECM_REQUIRE(io_bf16 == 0 || io_bf16 == TECM_GN_OUT_BF16 || io_bf16 == (TECM_GN_OUT_BF16 | TECM_GN_Y_BF16), TECM_E_ARG,
+               "tecm_groupnorm_gelu_fwd: io_bf16 is 0, TECM_GN_OUT_BF16 or TECM_GN_OUT_BF16 | TECM_GN_Y_BF16");
   TECM_REQUIRE(act_stride >= 1, TECM_E_ARG, "tecm_groupnorm_gelu_fwd: act_stride must be at least 1");
-  const bool io16 = io_bf16 != 0;
+  const bool io16 = (io_bf16 & TECM_GN_OUT_BF16) != 0;
+  if (io_bf16 & TECM_GN_Y_BF16) {                        // every tensor bf16: the oct kernels
+    TECM_REQUIRE(y_ && gamma && beta && act_ && stats, TECM_E_ARG, "tecm_groupnorm_gelu_fwd: null pointer");
+    TECM_REQUIRE(B > 0 && L > 0 && N > 0, TECM_E_ARG, "tecm_groupnorm_gelu_fwd: bad shape");
+    const int wps = gn16_wps(L, N, Cout, y_, act_);
+    TECM_REQUIRE(wps > 0, TECM_E_ARG, "tecm_groupnorm_gelu_fwd: a bf16 y needs L * 3*Cout/8 <= 2560 and Cout in {64, 128, 256} "
+                 "(got L = %d, Cout = %d)", L, Cout);
+    const dim3 g1((unsigned)((int64_t)B * N));
+    hipStream_t st16 = (hipStream_t)stream;
+#define GN_FWD16(CPB, WPS) \
+  hipLaunchKernelGGL((gn_gelu_fwd_reg16<CPB, WPS>), g1, dim3(WPS > 4 ? 64 * WPS : 256), 0, st16, y_, gamma, beta, act_, stats, B, \
+                     L, N, eps, (int)act_stride)
+    if (wps == 4) {
+      if (Cout == 64) GN_FWD16(1, 4); else if (Cout == 128) GN_FWD16(2, 4); else GN_FWD16(4, 4);
+    } else {
+      if (Cout == 64) GN_FWD16(1, 8); else if (Cout == 128) GN_FWD16(2, 8); else GN_FWD16(4, 8);
+    }
+#undef GN_FWD16
+    TECM_CHECK_LAUNCH("tecm_groupnorm_gelu_fwd/reg16");
+    return TECM_OK;
+  }
   TECM_REQUIRE(y && gamma && beta && act && stats, TECM_E_ARG, "tecm_groupnorm_gelu_fwd: null pointer");
   TECM_REQUIRE(B > 0 && L > 0 && N > 0, TECM_E_ARG, "tecm_groupnorm_gelu_fwd: bad shape");
   TECM_REQUIRE(Cout == 64 || Cout == 128 || Cout == 256, TECM_E_ARG,
@@ -1031,9 +1360,10 @@ extern "C" int tecm_groupnorm_gelu_bwd(const void* dact_, int32_t dstride, const
                                        int32_t io_bf16, void* stream) {
   const float* y = reinterpret_cast<const float*>(y_);
   float* dy = reinterpret_cast<float*>(dy_);
-  TECM_REQUIRE((io_bf16 & ~(TECM_GN_OUT_BF16 | TECM_GN_DACT_BF16)) == 0 &&
-                   (!(io_bf16 & TECM_GN_DACT_BF16) || (io_bf16 & TECM_GN_OUT_BF16)),
-               TECM_E_ARG, "tecm_groupnorm_gelu_bwd: io_bf16 is 0, TECM_GN_OUT_BF16 or TECM_GN_OUT_BF16 | TECM_GN_DACT_BF16");
+  TECM_REQUIRE((io_bf16 & ~(TECM_GN_OUT_BF16 | TECM_GN_DACT_BF16 | TECM_GN_Y_BF16)) == 0 &&
+                   (!(io_bf16 & TECM_GN_DACT_BF16) || (io_bf16 & TECM_GN_OUT_BF16)) &&
+                   (!(io_bf16 & TECM_GN_Y_BF16) || (io_bf16 & (TECM_GN_OUT_BF16 | TECM_GN_DACT_BF16)) == (TECM_GN_OUT_BF16 | TECM_GN_DACT_BF16)),
+               TECM_E_ARG, "tecm_groupnorm_gelu_bwd: io_bf16 is 0, OUT_BF16, OUT_BF16 | DACT_BF16 or all three with Y_BF16");
   const bool io16 = (io_bf16 & TECM_GN_OUT_BF16) != 0, d16 = (io_bf16 & TECM_GN_DACT_BF16) != 0;
   const float* dact = reinterpret_cast<const float*>(dact_);
   TECM_REQUIRE(B > 0 && L > 0 && N > 0 && dstride > 0, TECM_E_ARG, "tecm_groupnorm_gelu_bwd: bad shape");
@@ -1045,6 +1375,22 @@ extern "C" int tecm_groupnorm_gelu_bwd(const void* dact_, int32_t dstride, const
   TECM_REQUIRE(dact && y && gamma && beta && stats && dgb_partials, TECM_E_ARG, "tecm_groupnorm_gelu_bwd: null pointer");
   const int L2 = (L + dstride - 1) / dstride;
   hipStream_t st = (hipStream_t)stream;
+  if (io_bf16 & TECM_GN_Y_BF16) {                        // every tensor bf16: the oct kernel
+    const int wps = gn16_wps(L, N, Cout, y_, dy_);
+    TECM_REQUIRE(wps > 0 && tecm_aligned(dact_, 16), TECM_E_ARG,
+                 "tecm_groupnorm_gelu_bwd: a bf16 y needs L * 3*Cout/8 <= 2560, Cout in {64, 128, 256}, 16-byte aligned tensors");
+#define GN_BWD16(CPB, WPS) \
+  hipLaunchKernelGGL((gn_gelu_bwd_reg16<CPB, WPS>), dim3(nb), dim3(WPS > 4 ? 64 * WPS : 256), 0, st, dact_, dstride, L2, y_, gamma, \
+                     beta, stats, dy_, dgb_partials, B, L, N)
+    if (wps == 4) {
+      if (Cout == 64) GN_BWD16(1, 4); else if (Cout == 128) GN_BWD16(2, 4); else GN_BWD16(4, 4);
+    } else {
+      if (Cout == 64) GN_BWD16(1, 8); else if (Cout == 128) GN_BWD16(2, 8); else GN_BWD16(4, 8);
+    }
+#undef GN_BWD16
+    TECM_CHECK_LAUNCH("tecm_groupnorm_gelu_bwd/reg16");
+    return TECM_OK;
+  }
 #define GN_BWD_REG(CPB, WPS, NT, NPV)                                                                              \
   do {                                                                                                            \
     if (io16 && d16)                                                                                              \

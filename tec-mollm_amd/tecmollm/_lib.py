@@ -128,7 +128,7 @@ class TecmConvDw(C.Structure):
 class TecmConvFwd(C.Structure):
     _fields_ = [("inp", C.c_void_p), ("wpack", C.c_void_p), ("bias", c_f32p), ("y", c_f32p),
                 ("B", C.c_int32), ("Lc", C.c_int32), ("N", C.c_int32), ("Cout", C.c_int32), ("ld_in", C.c_int32),
-                ("_pad", C.c_int32)]
+                ("y_bf16", C.c_int32)]
 
 
 TECM_NORM_BLOCKS = 512
@@ -147,6 +147,7 @@ EXPORTS = {
     "tecm_spatial_bwd_blocks": (C.c_int, [C.POINTER(TecmSpatial)]),
     "tecm_groupnorm_gelu_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32,
                                           C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_void_p]),
+    "tecm_gn_y16_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "tecm_groupnorm_gelu_bwd": (C.c_int, [c_f32p, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                           C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                           C.c_int32, C.c_void_p]),

@@ -299,13 +299,18 @@ class ConvBlockFn(torch.autograd.Function):
         r16 = int(bf16) == ops.PREC_BF16 and Cout >= 64 and ops.gn_reg_ok(Lc, N, Cout)
         adt = torch.bfloat16 if r16 else torch.float32
         side16 = r16
-        y = _empty(B, Lc, N, CT, like=inp)
         packs = []
         # the three kernel sizes in ONE launch that stages the input rows once and writes whole rows of y
         # (csrc/conv_seq.hip): exact fp32 from the fp32 input, the bf16 mode's arithmetic from the bf16 copy of the input;
         # otherwise (bf16x3 / bf16x6 modes, odd shapes) three window GEMMs, one 64- / 128-column slice each
         seq_in = inp16 if (side16 and inp16 is not None) else (inp if int(bf16) == ops.PREC_FP32 else None)
         fwd_seq = seq_in is not None and ops.conv_fwd_seq_ok(Lc, Cout, ld_in, f32=seq_in.dtype == torch.float32)
+        # bf16 mode: y itself is the bf16 tensor a bf16 Conv1d returns under autocast (train.py:68) -- written as such by the
+        # sequence-tile kernel, read by the all-bf16 norm kernels forward and backward (half the bytes, three times over) --
+        # wherever those kernels serve the sequence and the 1x1 conv's d-input GEMM returns the bf16 gradient they take
+        y16 = r16 and fwd_seq and seq_in.dtype == torch.bfloat16 and ops.gn_y16_ok(Lc, N, Cout) \
+            and ops.uses_bf16(CT, Cout, Cout, CT, b_layout=B_KN)
+        y = torch.empty(B, Lc, N, CT, device=inp.device, dtype=torch.bfloat16 if y16 else torch.float32)
         # bias | gamma | beta of the three branches as the 3*Cout vectors the kernels read: one launch, not three cats
         bgb = ops.pack_vectors([b3, b5, b7, g3, g5, g7, be3, be5, be7])
         bias3, gamma, beta = bgb[:CT], bgb[CT:2 * CT], bgb[2 * CT:]
@@ -328,9 +333,10 @@ class ConvBlockFn(torch.autograd.Function):
             gemm(M, Cout, k * ld_in, a_in, ld_in, fp, k * ld_in, y, CT, c_off=j * Cout,
                  a_win=win(N, Lc, Lc, 1, k, ld_in, (k - 1) // 2), bias=b, bf16=bf16)
         Lo = (Lc - 1) // stride + 1
-        # bf16 mode: the activation is only kept at the time steps the stride-s 1x1 conv reads (a COMPACT (B, Lo, N, CT)
-        # tensor: half the bytes at stride 2, and that conv and its weight gradient become plain GEMMs, no window view)
-        compact = r16 and stride > 1
+        # the activation is only kept at the time steps the stride-s 1x1 conv reads (a COMPACT (B, Lo, N, CT) tensor: half
+        # the bytes at stride 2, and that conv and its weight gradient become plain GEMMs, no window view) wherever the
+        # register-resident norm kernels -- the ones that can skip rows -- serve the sequence
+        compact = stride > 1 and ops.gn_reg_ok(Lc, N, Cout) and int(bf16) in (ops.PREC_FP32, ops.PREC_BF16)
         La = Lo if compact else Lc
         act = torch.empty(B, La, N, CT, device=inp.device, dtype=adt)
         stats = _empty(B * N, 3, 2, like=inp)

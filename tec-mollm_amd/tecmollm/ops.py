@@ -339,7 +339,7 @@ def layernorm_bwd(dy: torch.Tensor, lddy: int, x: torch.Tensor, ldx: int, gamma:
     return dgb[0, :D], dgb[0, D:]
 
 
-GN_OUT_BF16, GN_DACT_BF16 = 2, 4
+GN_Y_BF16, GN_OUT_BF16, GN_DACT_BF16 = 1, 2, 4
 
 
 def gn_reg_ok(L: int, N: int, Cout: int) -> bool:
@@ -354,9 +354,18 @@ def gn_reg_ok(L: int, N: int, Cout: int) -> bool:
 
 
 def _gn_io(y: torch.Tensor, out: torch.Tensor) -> int:
+    if y.dtype == torch.bfloat16:
+        if out.dtype != torch.bfloat16:
+            raise _lib.TecmError("groupnorm_gelu: a bf16 y comes with bf16 act / dact / dy")
+        return GN_Y_BF16 | GN_OUT_BF16
     if y.dtype != torch.float32:
-        raise _lib.TecmError("groupnorm_gelu: y is fp32 (only act / dy may be bf16)")
+        raise _lib.TecmError("groupnorm_gelu: y is fp32 or bf16")
     return GN_OUT_BF16 if out.dtype == torch.bfloat16 else 0
+
+
+def gn_y16_ok(L: int, N: int, Cout: int) -> bool:
+    """True when the all-bf16 GroupNorm + GELU kernels serve the sequence (the conv block then writes y as bf16)."""
+    return os.environ.get("TECM_Y16", "1")[:1] != "0" and lib().tecm_gn_y16_supported(L, N, Cout) == 1
 
 
 def groupnorm_gelu_fwd(y: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, act: torch.Tensor,
@@ -386,6 +395,8 @@ def groupnorm_gelu_bwd(dact: torch.Tensor, dstride: int, y: torch.Tensor, gamma:
         if not io:
             raise _lib.TecmError("groupnorm_gelu_bwd: a bf16 dact comes with a bf16 dy")
         io |= GN_DACT_BF16
+    elif io & GN_Y_BF16:
+        raise _lib.TecmError("groupnorm_gelu_bwd: a bf16 y comes with a bf16 dact")
     check(lib().tecm_groupnorm_gelu_bwd(dact.data_ptr(), dstride, y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                         stats.data_ptr(), dy.data_ptr(), partials.data_ptr(), C.byref(nb), B, L, N,
                                         Cout, io, stream_ptr()), "tecm_groupnorm_gelu_bwd")
@@ -607,8 +618,9 @@ def conv_fwd(inp: torch.Tensor, w3: torch.Tensor, w5: torch.Tensor, w7: torch.Te
     """y (B, Lc, N, 3*Cout) fp32 = the three parallel Conv1d (k = 3, 5, 7) of a Multi_Scale_Conv_Block (modules.py:43-60)
     of inp (B, Lc, N, ld_in), bias (3*Cout) included, in one launch (csrc/conv_seq.hip).  inp bf16: the bf16 mode's
     arithmetic; inp fp32: exact fp32."""
-    if inp.dtype not in (torch.bfloat16, torch.float32) or y.dtype != torch.float32:
-        raise _lib.TecmError("conv_fwd: inp is bf16 or fp32, y fp32")
+    if inp.dtype not in (torch.bfloat16, torch.float32) or y.dtype not in (torch.bfloat16, torch.float32) or \
+            (y.dtype == torch.bfloat16 and inp.dtype != torch.bfloat16):
+        raise _lib.TecmError("conv_fwd: inp is bf16 or fp32, y fp32 (or bf16 next to a bf16 inp)")
     f32 = inp.dtype == torch.float32
     if f32:
         nval = sum(((3 + 2 * j) * ld_in // 8) * (Cout // 32) for j in range(3)) * 256
@@ -619,7 +631,7 @@ def conv_fwd(inp: torch.Tensor, w3: torch.Tensor, w5: torch.Tensor, w7: torch.Te
     wpack = torch.empty(nval, device=y.device, dtype=inp.dtype)
     check(pack(w3.data_ptr(), w5.data_ptr(), w7.data_ptr(), wpack.data_ptr(), Cout, cin, ld_in, stream_ptr()), what + "/pack")
     d = _lib.TecmConvFwd(inp=inp.data_ptr(), wpack=wpack.data_ptr(), bias=bias.data_ptr(), y=y.data_ptr(), B=B, Lc=Lc,
-                         N=N, Cout=Cout, ld_in=ld_in)
+                         N=N, Cout=Cout, ld_in=ld_in, y_bf16=1 if y.dtype == torch.bfloat16 else 0)
     if _timing is None:
         check(run(C.byref(d), stream_ptr()), what)
         return

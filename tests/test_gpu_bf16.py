@@ -487,3 +487,8 @@ def test_conv_fwd_sequence_tile_kernel(dev, Bn, Lc, N, cin, ld_in, Cout, f32):
         ops.gemm(M, Cout, k * ld_in, xd, ld_in, fp, k * ld_in, old, CT, c_off=j * Cout,
                  a_win=ops.win(N, Lc, Lc, 1, k, ld_in, (k - 1) // 2), bias=bias[j * Cout:(j + 1) * Cout].contiguous(), bf16=not f32)
     assert _rel(y, old) < 1e-5
+    if not f32:
+        # y as the bf16 tensor a bf16 Conv1d returns under autocast (TecmConvFwd.y_bf16): the same accumulators, rounded once
+        y16 = torch.full((Bn, Lc, N, CT), float("nan"), device=dev, dtype=torch.bfloat16)
+        ops.conv_fwd(xd, wd[0], wd[1], wd[2], bias, y16, Bn, Lc, N, Cout, cin, ld_in)
+        assert torch.equal(y16, y.bfloat16())

@@ -356,6 +356,54 @@ def test_groupnorm_gelu_compact_strided_act_and_bf16_dact(dev, Bn, L, N, Cout, s
         ops.groupnorm_gelu_bwd(d16, stride, y, g, b, st, torch.empty(Bn, L, N, CT, device=dev), Bn, L, N, Cout)   # bf16 dact, fp32 dy
 
 
+@pytest.mark.parametrize("Bn,L,N,Cout,stride", [(2, 48, 5, 64, 2), (1, 24, 9, 128, 2), (1, 96, 3, 64, 2), (1, 48, 3, 128, 2),
+                                                (2, 16, 7, 64, 1), (1, 12, 3, 256, 2), (1, 40, 3, 64, 2)])
+def test_groupnorm_gelu_all_bf16_kernels(dev, Bn, L, N, Cout, stride):
+    """TECM_GN_Y_BF16: y, act, dact and dy all bf16 (a lane's unit is 8 channels = one 16-byte access), statistics and
+    arithmetic fp32 -- against the fp32-y kernels fed the same rounded y (outputs one bf16 ulp, statistics and parameter
+    gradients 1e-5: other lanes sum other elements) and against fp64 GroupNorm(1) + GELU (modules.py:28-29) of that y.
+    Sequences that fill the last round of lanes only partly (L = 48 x 24 octs over 256 lanes: 4.5 per lane; L = 40)."""
+    from tecmollm import ops
+    CT = 3 * Cout
+    assert ops.gn_y16_ok(L, N, Cout)
+    y16 = _rand(Bn, L, N, CT, dev=dev, seed=1).bfloat16()
+    y = y16.float()
+    g, b = 1 + 0.1 * _rand(CT, dev=dev, seed=2), 0.1 * _rand(CT, dev=dev, seed=3)
+    La = (L + stride - 1) // stride
+    a16, st16 = torch.full((Bn, La, N, CT), float("nan"), device=dev, dtype=torch.bfloat16), torch.empty(Bn * N, 3, 2, device=dev)
+    a32, st32 = torch.empty(Bn, La, N, CT, device=dev, dtype=torch.bfloat16), torch.empty(Bn * N, 3, 2, device=dev)
+    ops.groupnorm_gelu_fwd(y16, g, b, a16, st16, Bn, L, N, Cout, act_stride=stride)
+    full = torch.empty(Bn, L, N, CT, device=dev, dtype=torch.bfloat16)
+    ops.groupnorm_gelu_fwd(y, g, b, full, st32, Bn, L, N, Cout)
+    a32 = full[:, ::stride]
+    assert _rel(st16, st32) < 1e-5
+    d = (a16.float() - a32.float()).abs()
+    assert bool((d <= a32.float().abs() * 2.0 ** -7 + 1e-6).all())
+    yd = y.double().requires_grad_(True)
+    gd, bd = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    ys = yd.permute(0, 2, 3, 1).reshape(Bn * N, CT, L)
+    outs = [torch.nn.functional.gelu(torch.nn.functional.group_norm(ys[:, j * Cout:(j + 1) * Cout], 1, gd[j * Cout:(j + 1) * Cout],
+                                                                    bd[j * Cout:(j + 1) * Cout], 1e-5)) for j in range(3)]
+    ref = torch.cat(outs, 1).view(Bn, N, CT, L).permute(0, 3, 1, 2)
+    assert _rel(a16, ref[:, ::stride]) < 5e-3                     # bf16 output
+    dact16 = _rand(Bn, La, N, CT, dev=dev, seed=4).bfloat16()
+    dy16 = torch.full((Bn, L, N, CT), float("nan"), device=dev, dtype=torch.bfloat16)
+    dyq = torch.empty_like(dy16)
+    r16 = ops.groupnorm_gelu_bwd(dact16, stride, y16, g, b, st16, dy16, Bn, L, N, Cout)
+    rq = ops.groupnorm_gelu_bwd(dact16, stride, y, g, b, st16, dyq, Bn, L, N, Cout)
+    assert torch.isfinite(dy16.float()).all()
+    d = (dy16.float() - dyq.float()).abs()
+    assert bool((d <= dyq.float().abs() * 2.0 ** -7 + 1e-5 * float(dyq.float().abs().max())).all())
+    for a_, b_ in zip(r16, rq):
+        assert _rel(a_, b_) < 2e-5
+    fullg = torch.zeros(Bn, L, N, CT, dtype=torch.float64, device=dev)
+    fullg[:, ::stride] = dact16.double()
+    gy, gg, gb = torch.autograd.grad(ref, (yd, gd, bd), fullg)
+    assert _rel(dy16, gy) < 5e-3 and _rel(r16[0], gg) < TOL and _rel(r16[1], gb) < TOL
+    with pytest.raises(Exception):
+        ops.groupnorm_gelu_bwd(dact16.float(), stride, y16, g, b, st16, dy16, Bn, L, N, Cout)      # bf16 y, fp32 dact
+
+
 def test_colsum_segments_and_dropout(dev):
     from tecmollm import ops, rng
     Bn, P, N, Cn = 3, 4, 50, 70

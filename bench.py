@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--L_in", type=int, default=48)
     ap.add_argument("--L_out", type=int, default=12)
     ap.add_argument("--c_in", type=int, default=10, help="raw feature width F (BASELINE: 10 -> d_emb 12)")
+    ap.add_argument("--llm_layers", type=int, default=3, help="GPT-2 blocks (train.py:196; the reference's 4-GPU script uses 6)")
     ap.add_argument("--gat", choices=["per_timestep", "reference"], default="per_timestep")
     ap.add_argument("--precision", choices=["fp32", "bf16", "bf16x3", "bf16x6"], default="fp32",
                     help="fp32 = BASELINE configs[1] (exact-f32 MFMA); bf16 = configs[2] (bf16 MFMA, fp32 accumulate)")
@@ -150,7 +151,7 @@ def make_config(args):
     return {
         "num_nodes": 2911, "d_emb": 22 - args.c_in, "spatial_in_channels_base": args.c_in,
         "spatial_out_channels": 11, "spatial_heads": 2, "temporal_channel_list": [64, 128],
-        "temporal_strides": [2, 2], "patch_len": patch_len, "d_llm": 768, "llm_layers": 3,
+        "temporal_strides": [2, 2], "patch_len": patch_len, "d_llm": 768, "llm_layers": getattr(args, "llm_layers", 3),
         "prediction_horizon": args.L_out, "temporal_seq_len": args.L_in, "num_years": 13,
     }
 
@@ -344,7 +345,7 @@ def roofline_of(agg: dict, step_ms: float, steps: int, args, precision: str, bat
                        "algorithmic_mb": round(by / 1e6, 1), "t_mfma_us": round(t_mfma, 1), "t_hbm_us": round(t_hbm, 1),
                        "bound": "mfma" if t_mfma >= t_hbm else "hbm", "frac_of_bound": round(max(t_mfma, t_hbm) / us, 3),
                        "tflops": round(fl / us / 1e6, 1), "gbs": round(by / us / 1e3, 1)})
-    gf = ALG_GFLOP_PER_SAMPLE.get(L_in)
+    gf = ALG_GFLOP_PER_SAMPLE.get(L_in) if getattr(args, "llm_layers", 3) == 3 else None
     step = None
     if gf is not None:
         tf = gf * batch / step_ms / 1e3
@@ -588,7 +589,7 @@ def main():
             "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16", "bf16x3": "bf16x3", "bf16x6": "bf16x6"}[args.precision], "data": "synthetic",
             "config": {"workload": f"BASELINE configs[{2 if args.precision == 'bf16' else 1}]: B={B}/GPU, "
                                    f"L_in={args.L_in}, L_out={args.L_out}, N=2911, "
-                                   f"F={args.c_in} (d_emb={22 - args.c_in}), full fwd+bwd+AdamW, "
+                                   f"F={args.c_in} (d_emb={22 - args.c_in}), {args.llm_layers} GPT-2 blocks, full fwd+bwd+AdamW, "
                                    f"{PRECISION_TEXT[args.precision]}, "
                                    f"GATv2 {args.gat}, dropout {'off' if args.eval_mode else 'on (p=0.1)'}",
                        "global_batch": B * world, "parallelism": f"dp{world}", "final_loss": round(float(loss), 5),

@@ -367,8 +367,10 @@ int tecm_cast_bf16(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, 
 /* dst[r][c] = src[r][c] * keep(seed, r*drop.ld + c) / (1 - p): the counter-based dropout mask every kernel of this
  * library recomputes (F.dropout of tec_mollm.py:115, GPT-2's embd dropout), materialised once where the masked
  * tensor is consumed several times.  cols, ld_src, ld_dst multiples of 4; 16-byte aligned. */
-int tecm_dropout_apply(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t rows, int32_t cols,
-                       const TecmDrop* drop, void* stream);
+/* dst_bf16 != 0: dst is a bf16 tensor -- the cast autocast applies to the dropped value in front of a bf16 Linear
+ * (train.py:68), done once where the masked tensor is only ever read by bf16 contractions. */
+int tecm_dropout_apply(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int32_t dst_bf16, int64_t rows,
+                       int32_t cols, const TecmDrop* drop, void* stream);
 
 /* dst[r*ldd + c] = scale * src[c*lds + r]  (r < rows, c < cols): builds the K-extended c_attn weight
  * [W ; (alpha/r) * B^T] (modules.py:177-183) and other small transposes. */

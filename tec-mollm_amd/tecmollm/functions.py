@@ -766,7 +766,10 @@ class HeadFn(torch.autograd.Function):
         hid = hid.contiguous()
         # F.dropout(hid) is read by the forward GEMM (once per 128-column tile) and again by the W1 gradient: mask it
         # once (one streaming pass) instead of hashing every element in both GEMM loaders
-        hd = ops.dropout_apply(hid, B * T * N, D, pspec) if pspec is not None else hid
+        # (bf16 mode: as the bf16 tensor autocast casts the dropped value to -- both readers are bf16 contractions)
+        h16 = int(plan.bf16) == ops.PREC_BF16 and D % 8 == 0 and ops.uses_bf16(Hd, K1, D, K1) and \
+            ops.uses_bf16(K1, S, Hd, D, a_layout=A_KM, b_layout=B_KN)
+        hd = ops.dropout_apply(hid, B * T * N, D, pspec, out_bf16=h16) if pspec is not None else hid
         gemm(S, Hd, K1, hd, D, W1, K1, h1, Hd, a_win=w, bias=b1, preact=(pre, Hd), act=ACT_GELU_ERF,
              out_drop=hspec, bf16=plan.bf16)
         pred = _empty(B, N, Lo, like=hid)

@@ -443,12 +443,14 @@ def cast_bf16(src: torch.Tensor, lds: int, dst: torch.Tensor, ldd: int, rows: in
                                stream_ptr()), "tecm_cast_bf16")
 
 
-def dropout_apply(src: torch.Tensor, rows: int, cols: int, spec: TecmDrop, ld: Optional[int] = None) -> torch.Tensor:
-    """dropout(src) with the library's counter-based mask (index = row*spec.ld + col) as a new contiguous tensor."""
-    dst = torch.empty_like(src)
+def dropout_apply(src: torch.Tensor, rows: int, cols: int, spec: TecmDrop, ld: Optional[int] = None,
+                  out_bf16: bool = False) -> torch.Tensor:
+    """dropout(src) with the library's counter-based mask (index = row*spec.ld + col) as a new contiguous tensor; out_bf16:
+    a bf16 one (the masked value rounded once, for a tensor only bf16 contractions read)."""
+    dst = torch.empty_like(src, dtype=torch.bfloat16 if out_bf16 else torch.float32)
     ld = cols if ld is None else ld
-    check(lib().tecm_dropout_apply(src.data_ptr(), ld, dst.data_ptr(), ld, rows, cols, C.byref(spec), stream_ptr()),
-          "tecm_dropout_apply")
+    check(lib().tecm_dropout_apply(src.data_ptr(), ld, dst.data_ptr(), ld, 1 if out_bf16 else 0, rows, cols, C.byref(spec),
+                                   stream_ptr()), "tecm_dropout_apply")
     return dst
 
 

@@ -197,7 +197,7 @@ int tecm_spatial_bwd_blocks(const TecmSpatial* d);
 #define TECM_GN_DACT_BF16 4
 /* y itself is the bf16 tensor a bf16 Conv1d hands to the fp32 GroupNorm under autocast (train.py:68; tecm_conv_fwd_bf16 with
  * y_bf16): forward with TECM_GN_OUT_BF16, backward with TECM_GN_OUT_BF16 | TECM_GN_DACT_BF16 -- every tensor bf16, statistics
- * and arithmetic fp32.  Served for L * 3*Cout/8 <= 2560 (tecm_gn_y16_supported). */
+ * and arithmetic fp32.  Served for L * 3*Cout/8 <= 2304 (tecm_gn_y16_supported). */
 #define TECM_GN_Y_BF16 1
 int tecm_gn_y16_supported(int32_t L, int32_t N, int32_t Cout);
 /* act_stride s >= 1: only the time steps t % s == 0 are written, into a COMPACT (B, ceil(L / s), N, CT) tensor -- the

@@ -281,12 +281,12 @@ def conv_y_bf16(L: int, Cout: int, ld_in: int) -> bool:
     """Mirror of the device policy (ConvBlockFn: y16): in bf16 mode the conv output y is STORED as the bf16 tensor a bf16
     Conv1d returns under autocast wherever the sequence-tile forward kernel writes it (tecm_conv_fwd_supported: L % 8 == 0,
     Cout <= 128, ld_in % 8 == 0, (min(L, 48) + 7) * 4 rows of an odd number of 16-byte slots within 64 KiB) and the
-    all-bf16 norm kernels read it (tecm_gn_y16_supported: L * 3*Cout/8 <= 2560)."""
+    all-bf16 norm kernels read it (tecm_gn_y16_supported: L * 3*Cout/8 <= 2304)."""
     if not conv_acts_bf16(L, Cout) or L % 8 or Cout % 32 or Cout > 128 or ld_in % 8 or ld_in > 128:
         return False
     slots = ld_in * 2 // 16
     slots += 1 - slots % 2
-    return (min(L, 48) + 7) * 4 * slots * 16 <= 65536 and L * (3 * Cout // 8) <= 2560
+    return (min(L, 48) + 7) * 4 * slots * 16 <= 65536 and L * (3 * Cout // 8) <= 2304
 
 
 # ------------------------------------------------------------------- stage a-4/a-5

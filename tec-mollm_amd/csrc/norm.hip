@@ -145,8 +145,9 @@ __global__ __launch_bounds__(64 * NW) void layernorm_bwd_kernel(const float* __r
       float4 acc[NCH];
 #pragma unroll
       for (int i = 0; i < NCH; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int j = 0; j < lb.r; ++j) {
-        const float sj = __shfl(dzl, j);
+      // dz[row][j] is wave-uniform: v_readlane of lane j (a compile-time lane in the unrolled r = 32 form -- a run-time
+      // lane would be a ds_bpermute, an LDS operation per term, beside the three LDS reads of A's row)
+      auto term = [&](int j, float sj) {
         const float* Aj = lds_ln + j * D;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
@@ -157,6 +158,12 @@ __global__ __launch_bounds__(64 * NW) void layernorm_bwd_kernel(const float* __r
             acc[i].z = fmaf(sj, a.z, acc[i].z); acc[i].w = fmaf(sj, a.w, acc[i].w);
           }
         }
+      };
+      if (lb.r == 32) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) term(j, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dzl), j)));
+      } else {
+        for (int j = 0; j < lb.r; ++j) term(j, __shfl(dzl, j));
       }
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
@@ -718,9 +725,7 @@ __global__ __launch_bounds__((GnGeom<CPB, WPS>::NTHR)) void gn_gelu_bwd_reg(cons
 // conv_fwd_seq writes it as such), and every tensor these kernels touch is bf16 (y, act, dact, dy).  The register-resident
 // kernels above are bound by memory requests in flight, not bytes -- fed 8-byte quads they got slower, not faster -- so here
 // a lane's unit is an OCT (8 consecutive channels = one 16-byte load / store): the same number of requests per lane, twice
-// the elements, half the waves per sequence.  Oct o = l2 + LPS*k of lane l2 (k = 0..NG-1) is row t = o / OPR, oct o % OPR
-// (OPR = CT/8 octs per row); 3*LPS is a multiple of OPR for CT in {192, 384, 768}, so a lane meets three channel octs
-// (slot = k % 3).  The sequence need not fill the last round of lanes: L*OPR <= LPS*NG, octs past the end are skipped.
+// the elements.  (Geometry: GnGeom8 below.)  The sequence need not fill the last round of lanes: rows past L are skipped.
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8n __attribute__((ext_vector_type(8)));
 
@@ -744,268 +749,188 @@ __device__ __forceinline__ f32x8 gn_ld8f(const float* p) {
 }
 __device__ __forceinline__ float sum8(const f32x8& v) { return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])); }
 
-template <int CPB, int WPS>
+// Geometry: SIX waves (384 lanes) own one sequence and a lane keeps ONE channel oct for the whole kernel (384 is a multiple
+// of OPR = 24, 48, 96): lane l2 holds oct l2 % OPR of the rows t = l2 / OPR + k * (384 / OPR), k < NG.  One gamma / beta oct
+// and one set of parameter-gradient accumulators per lane (the three-slot form of the fp32-y kernels needs 72 + 48
+// registers for them at 8 channels per unit and ran at one wave per SIMD).
+template <int CPB>
 struct GnGeom8 {
   static constexpr int CT = 192 * CPB;
   static constexpr int OPR = CT / 8;        // octs per row
   static constexpr int OPB = OPR / 3;       // octs per branch
-  static constexpr int LPS = 64 * WPS;      // lanes per sequence
-  static constexpr int NTHR = WPS > 4 ? 64 * WPS : 256;
-  static constexpr int SPB = NTHR / LPS;
-  static constexpr int DT = LPS / OPR, DQ = LPS % OPR;
-  static_assert((3 * LPS) % OPR == 0, "slot period");
+  static constexpr int LPS = 384;           // lanes per sequence = threads per block
+  static constexpr int DT = LPS / OPR;      // rows between a lane's consecutive octs
+  static_assert(LPS % OPR == 0, "a lane keeps its channel oct");
 };
 
-constexpr int GN8_NG = 5;                    // octs per lane (40 values): L * OPR <= 64 * WPS * 5
+// sums over the six waves of the block; branch br of this lane's contribution goes to slot br
+__device__ __forceinline__ void seq_reduce3x6(float (&v)[3], float (*xch)[3], int wave, int lane) {
+#pragma unroll
+  for (int b = 0; b < 3; ++b) v[b] = wave_sum(v[b]);
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int b = 0; b < 3; ++b) xch[wave][b] = v[b];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int b = 0; b < 3; ++b) v[b] = ((xch[0][b] + xch[1][b]) + (xch[2][b] + xch[3][b])) + (xch[4][b] + xch[5][b]);
+}
 
-template <int CPB, int WPS>
-__global__ __launch_bounds__((GnGeom8<CPB, WPS>::NTHR)) void gn_gelu_fwd_reg16(const void* __restrict__ y, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, void* __restrict__ act,
-                                                          float* __restrict__ stats, int B, int L, int N, float eps,
-                                                          int astride) {
-  using G = GnGeom8<CPB, WPS>;
-  __shared__ float xch[G::NTHR / 64][3];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int sp = wave / WPS, half = wave % WPS, l2 = half * 64 + lane;
-  int64_t sidx = (int64_t)blockIdx.x * G::SPB + sp;
-  const bool live = sidx < (int64_t)B * N;
-  if (!live) sidx = (int64_t)B * N - 1;
+template <int CPB, int NG>
+__global__ __launch_bounds__(384) void gn_gelu_fwd_reg16(const void* __restrict__ y, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, void* __restrict__ act,
+                                                         float* __restrict__ stats, int B, int L, int N, float eps,
+                                                         int astride) {
+  using G = GnGeom8<CPB>;
+  __shared__ float xch[6][3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l2 = threadIdx.x;
+  const int64_t sidx = blockIdx.x;                        // one sequence per block
   const int b = (int)(sidx / N), n = (int)(sidx - (int64_t)b * N);
   const int64_t tstride = (int64_t)N * G::CT;
   const int64_t base = ((int64_t)b * L * N + n) * G::CT;
   const int La = (L + astride - 1) / astride;
   const int64_t abase = ((int64_t)b * La * N + n) * G::CT;
   const float inv_cnt = 1.0f / (float)(L * CPB * 64);
-  int qs[3], brs[3];
-  {
-    int q = l2 % G::OPR;
+  const int q = l2 % G::OPR, t0 = l2 / G::OPR, br = q / G::OPB;
+  f32x8 v[NG];
 #pragma unroll
-    for (int s_ = 0; s_ < 3; ++s_) {
-      qs[s_] = q;
-      brs[s_] = q / G::OPB;
-      q += G::DQ;
-      if (q >= G::OPR) q -= G::OPR;
-    }
+  for (int k = 0; k < NG; ++k) {
+    const int t = t0 + k * G::DT;
+    const int tc = t < L ? t : L - 1;                      // clamped: an unconditional load, the value is not used
+    v[k] = gn_ld8(y, base + tc * (int32_t)tstride + q * 8);
+    if (t >= L)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[k][e] = 0.f;
   }
-  f32x8 v[GN8_NG];
-  int32_t aoff[GN8_NG];                                   // offset in the (compact) act tensor; -1: not written; -2: no such oct
-  {
-    int t = l2 / G::OPR, q = l2 % G::OPR;
+  const f32x8 gm = gn_ld8f(gamma + q * 8), bt = gn_ld8f(beta + q * 8);
+  float acc = 0.f;
 #pragma unroll
-    for (int k = 0; k < GN8_NG; ++k) {
-      const bool has = t < L;
-      aoff[k] = !has ? -2 : ((t % astride) == 0 ? (t / astride) * (int32_t)tstride + q * 8 : -1);
-      const int tc = has ? t : L - 1;                      // clamped: an unconditional load, the value is not used
-      v[k] = gn_ld8(y, base + tc * (int32_t)tstride + q * 8);
-      if (!has)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[k][e] = 0.f;
-      t += G::DT;
-      q += G::DQ;
-      if (q >= G::OPR) { q -= G::OPR; ++t; }
-    }
-  }
-  f32x8 gm[3], bt[3];
-#pragma unroll
-  for (int s_ = 0; s_ < 3; ++s_) {
-    gm[s_] = gn_ld8f(gamma + qs[s_] * 8);
-    bt[s_] = gn_ld8f(beta + qs[s_] * 8);
-  }
-  float acc[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-  for (int k = 0; k < GN8_NG; ++k) acc[k % 3] += sum8(v[k]);          // absent octs hold zeros
-  float mean[3];
-#pragma unroll
-  for (int bb = 0; bb < 3; ++bb)
-    mean[bb] = (brs[0] == bb ? acc[0] : 0.f) + (brs[1] == bb ? acc[1] : 0.f) + (brs[2] == bb ? acc[2] : 0.f);
-  seq_reduce3<WPS>(mean, xch, wave, lane);
+  for (int k = 0; k < NG; ++k) acc += sum8(v[k]);          // absent octs hold zeros
+  float mean[3] = {br == 0 ? acc : 0.f, br == 1 ? acc : 0.f, br == 2 ? acc : 0.f};
+  seq_reduce3x6(mean, xch, wave, lane);
 #pragma unroll
   for (int bb = 0; bb < 3; ++bb) mean[bb] *= inv_cnt;
-  float ms[3];
+  const float m = sel3(br, mean[0], mean[1], mean[2]);
+  acc = 0.f;
 #pragma unroll
-  for (int s_ = 0; s_ < 3; ++s_) ms[s_] = sel3(brs[s_], mean[0], mean[1], mean[2]);
-  acc[0] = acc[1] = acc[2] = 0.f;
-#pragma unroll
-  for (int k = 0; k < GN8_NG; ++k)
-    if (aoff[k] != -2) {
-      const float m = ms[k % 3];
-      float q2 = 0.f;
+  for (int k = 0; k < NG; ++k)
+    if (t0 + k * G::DT < L) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float d = v[k][e] - m;
-        q2 += d * d;
+        acc += d * d;
       }
-      acc[k % 3] += q2;
     }
-  float rstd[3];
-#pragma unroll
-  for (int bb = 0; bb < 3; ++bb)
-    rstd[bb] = (brs[0] == bb ? acc[0] : 0.f) + (brs[1] == bb ? acc[1] : 0.f) + (brs[2] == bb ? acc[2] : 0.f);
-  seq_reduce3<WPS>(rstd, xch, wave, lane);
+  float rstd[3] = {br == 0 ? acc : 0.f, br == 1 ? acc : 0.f, br == 2 ? acc : 0.f};
+  seq_reduce3x6(rstd, xch, wave, lane);
 #pragma unroll
   for (int bb = 0; bb < 3; ++bb) rstd[bb] = 1.0f / sqrtf(rstd[bb] * inv_cnt + eps);
-  float rs[3];
+  const float rs = sel3(br, rstd[0], rstd[1], rstd[2]);
 #pragma unroll
-  for (int s_ = 0; s_ < 3; ++s_) rs[s_] = sel3(brs[s_], rstd[0], rstd[1], rstd[2]);
-  if (live) {
+  for (int k = 0; k < NG; ++k) {
+    const int t = t0 + k * G::DT;
+    if (t < L && (t % astride) == 0) {
+      f32x8 o;
 #pragma unroll
-    for (int k = 0; k < GN8_NG; ++k)
-      if (aoff[k] >= 0) {
-        const int s_ = k % 3;
-        f32x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = gelu_erf_fast((v[k][e] - ms[s_]) * rs[s_] * gm[s_][e] + bt[s_][e]);
-        gn_st8(act, abase + aoff[k], o);
-      }
-    if (half == 0 && lane < 3) {
-      stats[(sidx * 3 + lane) * 2] = sel3(lane, mean[0], mean[1], mean[2]);
-      stats[(sidx * 3 + lane) * 2 + 1] = sel3(lane, rstd[0], rstd[1], rstd[2]);
+      for (int e = 0; e < 8; ++e) o[e] = gelu_erf_fast((v[k][e] - m) * rs * gm[e] + bt[e]);
+      gn_st8(act, abase + (t / astride) * (int32_t)tstride + q * 8, o);
     }
+  }
+  if (l2 < 3) {
+    stats[(sidx * 3 + l2) * 2] = sel3(l2, mean[0], mean[1], mean[2]);
+    stats[(sidx * 3 + l2) * 2 + 1] = sel3(l2, rstd[0], rstd[1], rstd[2]);
   }
 }
 
-template <int CPB, int WPS>
-__global__ __launch_bounds__((GnGeom8<CPB, WPS>::NTHR)) void gn_gelu_bwd_reg16(const void* __restrict__ dact, int dstride, int L2,
-                                                          const void* __restrict__ y, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, const float* __restrict__ stats,
-                                                          void* __restrict__ dy, float* __restrict__ partials, int B,
-                                                          int L, int N) {
-  using G = GnGeom8<CPB, WPS>;
-  __shared__ float xch[G::NTHR / 64][3];
+template <int CPB, int NG>
+#ifndef GN16_OCC
+#define GN16_OCC 3       // waves per SIMD the 3-oct backward is compiled for (168 registers, ~8 spilled; 2 = 176, none)
+#endif
+__global__ __launch_bounds__(384, (NG == 3 ? GN16_OCC : 2)) void gn_gelu_bwd_reg16(const void* __restrict__ dact, int dstride, int L2,
+                                                         const void* __restrict__ y, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const float* __restrict__ stats,
+                                                         void* __restrict__ dy, float* __restrict__ partials, int B,
+                                                         int L, int N) {
+  using G = GnGeom8<CPB>;
+  __shared__ float xch[6][3];
   __shared__ float red[3 * G::CT];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int sp = wave / WPS, half = wave % WPS, l2 = half * 64 + lane;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l2 = threadIdx.x;
   const int64_t tstride = (int64_t)N * G::CT;
   const float inv_cnt = 1.0f / (float)(L * CPB * 64);
-  for (int c = threadIdx.x; c < 3 * G::CT; c += G::NTHR) red[c] = 0.f;
-  int qs[3], brs[3];
-  {
-    int q = l2 % G::OPR;
+  const int q = l2 % G::OPR, t0 = l2 / G::OPR, br = q / G::OPB;
+  const f32x8 gm = gn_ld8f(gamma + q * 8), bt = gn_ld8f(beta + q * 8);
+  f32x8 dgm, dbt, dys;
 #pragma unroll
-    for (int s_ = 0; s_ < 3; ++s_) {
-      qs[s_] = q;
-      brs[s_] = q / G::OPB;
-      q += G::DQ;
-      if (q >= G::OPR) q -= G::OPR;
-    }
-  }
-  f32x8 gm[3], bt[3], dgm[3], dbt[3], dys[3];
-#pragma unroll
-  for (int s_ = 0; s_ < 3; ++s_) {
-    gm[s_] = gn_ld8f(gamma + qs[s_] * 8);
-    bt[s_] = gn_ld8f(beta + qs[s_] * 8);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) dgm[s_][e] = dbt[s_][e] = dys[s_][e] = 0.f;
-  }
+  for (int e = 0; e < 8; ++e) dgm[e] = dbt[e] = dys[e] = 0.f;
   const int64_t S = (int64_t)B * N;
-  for (int64_t s0 = (int64_t)blockIdx.x * G::SPB; s0 < S; s0 += (int64_t)gridDim.x * G::SPB) {
-    int64_t sidx = s0 + sp;
-    const bool live = sidx < S;
-    if (!live) sidx = S - 1;
+  for (int64_t sidx = blockIdx.x; sidx < S; sidx += gridDim.x) {
     const int b = (int)(sidx / N), n = (int)(sidx - (int64_t)b * N);
     const int64_t ybase = ((int64_t)b * L * N + n) * G::CT;
     const int64_t dbase = ((int64_t)b * L2 * N + n) * G::CT;
-    float mean[3], rstd[3];
+    const float m = stats[(sidx * 3 + br) * 2], rs = stats[(sidx * 3 + br) * 2 + 1];
+    f32x8 yh[NG], gd[NG];
 #pragma unroll
-    for (int bb = 0; bb < 3; ++bb) {
-      mean[bb] = stats[(sidx * 3 + bb) * 2];
-      rstd[bb] = stats[(sidx * 3 + bb) * 2 + 1];
+    for (int k = 0; k < NG; ++k) {
+      const int t = t0 + k * G::DT;
+      const int tc = t < L ? t : L - 1;
+      yh[k] = gn_ld8(y, ybase + tc * (int32_t)tstride + q * 8);
+      gd[k] = gn_ld8(dact, dbase + (tc / dstride) * (int32_t)tstride + q * 8);     // unconditional (clamped), masked below
+      if (t >= L || (tc % dstride) != 0)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gd[k][e] = 0.f;
     }
-    float ms[3], rs[3];
+    float a1 = 0.f, a2 = 0.f;
 #pragma unroll
-    for (int s_ = 0; s_ < 3; ++s_) {
-      ms[s_] = sel3(brs[s_], mean[0], mean[1], mean[2]);
-      rs[s_] = sel3(brs[s_], rstd[0], rstd[1], rstd[2]);
-    }
-    f32x8 yh[GN8_NG], gd[GN8_NG];
-    int32_t off[GN8_NG];                                   // -1: no such oct
-    {
-      int t = l2 / G::OPR, q = l2 % G::OPR;
-#pragma unroll
-      for (int k = 0; k < GN8_NG; ++k) {
-        const bool has = t < L;
-        const int tc = has ? t : L - 1;
-        off[k] = has ? tc * (int32_t)tstride + q * 8 : -1;
-        yh[k] = gn_ld8(y, ybase + tc * (int32_t)tstride + q * 8);
-        const bool hd = has && (tc % dstride) == 0;
-        gd[k] = gn_ld8(dact, dbase + (tc / dstride) * (int32_t)tstride + q * 8);   // unconditional (clamped), masked below
-        if (!hd)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) gd[k][e] = 0.f;
-        t += G::DT;
-        q += G::DQ;
-        if (q >= G::OPR) { q -= G::OPR; ++t; }
-      }
-    }
-    float a1[3] = {0.f, 0.f, 0.f}, a2[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < GN8_NG; ++k) {
-      const int s_ = k % 3;
-      const bool has = off[k] >= 0;
+    for (int k = 0; k < NG; ++k) {
+      const bool has = t0 + k * G::DT < L;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float h_ = (yh[k][e] - ms[s_]) * rs[s_];
-        const float g_ = gd[k][e] * dgelu_erf_fast(h_ * gm[s_][e] + bt[s_][e]);     // gd = 0 where there is no gradient
-        if (live && has) { dgm[s_][e] += g_ * h_; dbt[s_][e] += g_; }
-        const float d_ = has ? g_ * gm[s_][e] : 0.f;
-        a1[s_] += d_;
-        a2[s_] += d_ * h_;
-        yh[k][e] = h_;
+        const float h_ = (yh[k][e] - m) * rs;
+        const float g_ = gd[k][e] * dgelu_erf_fast(h_ * gm[e] + bt[e]);            // gd = 0 where there is no gradient
+        dgm[e] += g_ * h_;
+        dbt[e] += g_;
+        const float d_ = g_ * gm[e];
+        a1 += d_;
+        a2 += d_ * h_;
+        yh[k][e] = has ? h_ : 0.f;
         gd[k][e] = d_;
       }
     }
-    float s1[3], s2[3];
+    float s1[3] = {br == 0 ? a1 : 0.f, br == 1 ? a1 : 0.f, br == 2 ? a1 : 0.f};
+    float s2[3] = {br == 0 ? a2 : 0.f, br == 1 ? a2 : 0.f, br == 2 ? a2 : 0.f};
+    seq_reduce3x6(s1, xch, wave, lane);
+    seq_reduce3x6(s2, xch, wave, lane);
+    const float m1 = sel3(br, s1[0], s1[1], s1[2]) * inv_cnt, m2 = sel3(br, s2[0], s2[1], s2[2]) * inv_cnt;
 #pragma unroll
-    for (int bb = 0; bb < 3; ++bb) {
-      s1[bb] = (brs[0] == bb ? a1[0] : 0.f) + (brs[1] == bb ? a1[1] : 0.f) + (brs[2] == bb ? a1[2] : 0.f);
-      s2[bb] = (brs[0] == bb ? a2[0] : 0.f) + (brs[1] == bb ? a2[1] : 0.f) + (brs[2] == bb ? a2[2] : 0.f);
-    }
-    seq_reduce3<WPS>(s1, xch, wave, lane);
-    seq_reduce3<WPS>(s2, xch, wave, lane);
-    float m1[3], m2[3];
+    for (int k = 0; k < NG; ++k) {
+      const int t = t0 + k * G::DT;
+      if (t < L) {
+        f32x8 o;
 #pragma unroll
-    for (int s_ = 0; s_ < 3; ++s_) {
-      m1[s_] = sel3(brs[s_], s1[0], s1[1], s1[2]) * inv_cnt;
-      m2[s_] = sel3(brs[s_], s2[0], s2[1], s2[2]) * inv_cnt;
-    }
-    if (live) {
-#pragma unroll
-      for (int k = 0; k < GN8_NG; ++k)
-        if (off[k] >= 0) {
-          const int s_ = k % 3;
-          f32x8 o;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            o[e] = rs[s_] * (gd[k][e] - m1[s_] - yh[k][e] * m2[s_]);
-            dys[s_][e] += o[e];                            // conv-bias gradient
-          }
-          gn_st8(dy, ybase + off[k], o);
+        for (int e = 0; e < 8; ++e) {
+          o[e] = rs * (gd[k][e] - m1 - yh[k][e] * m2);
+          dys[e] += o[e];                                  // conv-bias gradient
         }
+        gn_st8(dy, ybase + t * (int32_t)tstride + q * 8, o);
+      }
     }
   }
-  // block reduction of the per-lane parameter gradients in a FIXED order (as gn_gelu_bwd_reg): for a given slot the holders
-  // of one oct are the lanes with the same l2 % OPR, ranked by (sequence of the block, l2 / OPR)
-  {
-    constexpr int RMAX = (G::LPS + G::OPR - 1) / G::OPR;
-    const int rank = sp * RMAX + l2 / G::OPR;
+  // block reduction in a FIXED order: the holders of one oct are the lanes l2 = q + OPR * j, j = 0 .. DT-1, taken in turn
+  for (int c = threadIdx.x; c < 3 * G::CT; c += 384) red[c] = 0.f;
+  for (int j = 0; j < G::DT; ++j) {
+    __syncthreads();
+    if (t0 == j) {
 #pragma unroll
-    for (int s_ = 0; s_ < 3; ++s_) {
-      const int c = qs[s_] * 8;
-      for (int r = 0; r < G::SPB * RMAX; ++r) {
-        __syncthreads();
-        if (r == rank) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            red[c + e] += dgm[s_][e];
-            red[G::CT + c + e] += dbt[s_][e];
-            red[2 * G::CT + c + e] += dys[s_][e];
-          }
-        }
+      for (int e = 0; e < 8; ++e) {
+        red[q * 8 + e] += dgm[e];
+        red[G::CT + q * 8 + e] += dbt[e];
+        red[2 * G::CT + q * 8 + e] += dys[e];
       }
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < 3 * G::CT; c += G::NTHR) partials[(int64_t)blockIdx.x * 3 * G::CT + c] = red[c];
+  for (int c = threadIdx.x; c < 3 * G::CT; c += 384) partials[(int64_t)blockIdx.x * 3 * G::CT + c] = red[c];
 }
 
 // ------------------------------------------------------------------------------ column sums
@@ -1153,14 +1078,14 @@ int gn_reg_pairs(int L, int N, int Cout, int wps, int npmax, const void* a, cons
   if (!tecm_aligned(a, 16) || !tecm_aligned(b, 16)) return 0;
   return (int)(quads / lps);
 }
-// waves per sequence of the bf16-y oct kernels (4 or 8), 0 when the sequence does not fit 5 octs per lane
-int gn16_wps(int L, int N, int Cout, const void* a, const void* b) {
+// octs per lane of the all-bf16 kernels (3 or 6; 384 lanes per sequence), 0 when the sequence does not fit
+int gn16_ng(int L, int N, int Cout, const void* a, const void* b) {
   if (Cout != 64 && Cout != 128 && Cout != 256) return 0;
   const int64_t octs = (int64_t)L * (3 * Cout / 8);
   if ((int64_t)L * N * 3 * Cout >= (1ll << 31)) return 0;
   if ((a && !tecm_aligned(a, 16)) || (b && !tecm_aligned(b, 16))) return 0;
-  if (octs <= 256 * GN8_NG) return 4;
-  if (octs <= 512 * GN8_NG) return 8;
+  if (octs <= 384 * 3) return 3;
+  if (octs <= 384 * 6) return 6;
   return 0;
 }
 int gn_blocks(int64_t S) {
@@ -1171,7 +1096,7 @@ int gn_blocks(int64_t S) {
 }  // namespace
 
 // 1 when the all-bf16 GroupNorm kernels (TECM_GN_Y_BF16) serve sequences of L steps x 3*Cout channels, else 0
-extern "C" int tecm_gn_y16_supported(int32_t L, int32_t N, int32_t Cout) { return gn16_wps(L, N, Cout, nullptr, nullptr) > 0 ? 1 : 0; }
+extern "C" int tecm_gn_y16_supported(int32_t L, int32_t N, int32_t Cout) { return gn16_ng(L, N, Cout, nullptr, nullptr) > 0 ? 1 : 0; }
 
 extern "C" int tecm_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y,
                                   int64_t ldy, void* y16, int64_t ldy16, void* y16d, int64_t ldy16d, const TecmDrop* drop,
@@ -1279,18 +1204,17 @@ extern "C" int tecm_groupnorm_gelu_fwd(const void* y_, const float* gamma, const
   if (io_bf16 & TECM_GN_Y_BF16) {                        // every tensor bf16: the oct kernels
     TECM_REQUIRE(y_ && gamma && beta && act_ && stats, TECM_E_ARG, "tecm_groupnorm_gelu_fwd: null pointer");
     TECM_REQUIRE(B > 0 && L > 0 && N > 0, TECM_E_ARG, "tecm_groupnorm_gelu_fwd: bad shape");
-    const int wps = gn16_wps(L, N, Cout, y_, act_);
-    TECM_REQUIRE(wps > 0, TECM_E_ARG, "tecm_groupnorm_gelu_fwd: a bf16 y needs L * 3*Cout/8 <= 2560 and Cout in {64, 128, 256} "
+    const int ng = gn16_ng(L, N, Cout, y_, act_);
+    TECM_REQUIRE(ng > 0, TECM_E_ARG, "tecm_groupnorm_gelu_fwd: a bf16 y needs L * 3*Cout/8 <= 2304 and Cout in {64, 128, 256} "
                  "(got L = %d, Cout = %d)", L, Cout);
     const dim3 g1((unsigned)((int64_t)B * N));
     hipStream_t st16 = (hipStream_t)stream;
-#define GN_FWD16(CPB, WPS) \
-  hipLaunchKernelGGL((gn_gelu_fwd_reg16<CPB, WPS>), g1, dim3(WPS > 4 ? 64 * WPS : 256), 0, st16, y_, gamma, beta, act_, stats, B, \
-                     L, N, eps, (int)act_stride)
-    if (wps == 4) {
-      if (Cout == 64) GN_FWD16(1, 4); else if (Cout == 128) GN_FWD16(2, 4); else GN_FWD16(4, 4);
+#define GN_FWD16(CPB, NG) \
+  hipLaunchKernelGGL((gn_gelu_fwd_reg16<CPB, NG>), g1, dim3(384), 0, st16, y_, gamma, beta, act_, stats, B, L, N, eps, (int)act_stride)
+    if (ng == 3) {
+      if (Cout == 64) GN_FWD16(1, 3); else if (Cout == 128) GN_FWD16(2, 3); else GN_FWD16(4, 3);
     } else {
-      if (Cout == 64) GN_FWD16(1, 8); else if (Cout == 128) GN_FWD16(2, 8); else GN_FWD16(4, 8);
+      if (Cout == 64) GN_FWD16(1, 6); else if (Cout == 128) GN_FWD16(2, 6); else GN_FWD16(4, 6);
     }
 #undef GN_FWD16
     TECM_CHECK_LAUNCH("tecm_groupnorm_gelu_fwd/reg16");
@@ -1376,16 +1300,16 @@ extern "C" int tecm_groupnorm_gelu_bwd(const void* dact_, int32_t dstride, const
   const int L2 = (L + dstride - 1) / dstride;
   hipStream_t st = (hipStream_t)stream;
   if (io_bf16 & TECM_GN_Y_BF16) {                        // every tensor bf16: the oct kernel
-    const int wps = gn16_wps(L, N, Cout, y_, dy_);
-    TECM_REQUIRE(wps > 0 && tecm_aligned(dact_, 16), TECM_E_ARG,
-                 "tecm_groupnorm_gelu_bwd: a bf16 y needs L * 3*Cout/8 <= 2560, Cout in {64, 128, 256}, 16-byte aligned tensors");
-#define GN_BWD16(CPB, WPS) \
-  hipLaunchKernelGGL((gn_gelu_bwd_reg16<CPB, WPS>), dim3(nb), dim3(WPS > 4 ? 64 * WPS : 256), 0, st, dact_, dstride, L2, y_, gamma, \
-                     beta, stats, dy_, dgb_partials, B, L, N)
-    if (wps == 4) {
-      if (Cout == 64) GN_BWD16(1, 4); else if (Cout == 128) GN_BWD16(2, 4); else GN_BWD16(4, 4);
+    const int ng = gn16_ng(L, N, Cout, y_, dy_);
+    TECM_REQUIRE(ng > 0 && tecm_aligned(dact_, 16), TECM_E_ARG,
+                 "tecm_groupnorm_gelu_bwd: a bf16 y needs L * 3*Cout/8 <= 2304, Cout in {64, 128, 256}, 16-byte aligned tensors");
+#define GN_BWD16(CPB, NG) \
+  hipLaunchKernelGGL((gn_gelu_bwd_reg16<CPB, NG>), dim3(nb), dim3(384), 0, st, dact_, dstride, L2, y_, gamma, beta, stats, dy_, \
+                     dgb_partials, B, L, N)
+    if (ng == 3) {
+      if (Cout == 64) GN_BWD16(1, 3); else if (Cout == 128) GN_BWD16(2, 3); else GN_BWD16(4, 3);
     } else {
-      if (Cout == 64) GN_BWD16(1, 8); else if (Cout == 128) GN_BWD16(2, 8); else GN_BWD16(4, 8);
+      if (Cout == 64) GN_BWD16(1, 6); else if (Cout == 128) GN_BWD16(2, 6); else GN_BWD16(4, 6);
     }
 #undef GN_BWD16
     TECM_CHECK_LAUNCH("tecm_groupnorm_gelu_bwd/reg16");

@@ -244,7 +244,10 @@ typedef struct TecmLoraBack {
 int tecm_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                        const float* stats, const float* dres, float* dx, void* dx_masked, int32_t masked_bf16,
                        const TecmDrop* mask_drop, float* dgb_partials, int32_t* num_blocks, int64_t M, int32_t D,
-                       const TecmLoraBack* lora /* NULL: none */, void* stream);
+                       const TecmLoraBack* lora /* NULL: none */,
+                       int32_t dy_bf16 /* != 0: dy (and lora->dz, columns of the same matrix) are bf16 -- the gradient a bf16
+                                          Linear returns for its input under autocast (train.py:68) */,
+                       void* stream);
 
 /* Causal multi-head self-attention over T tokens per sequence (GPT2Attention, modeling_gpt2.py:54-73,
  * :144-226; all-ones attention_mask tec_mollm.py:111 => pure causal).  qkv: (B,T,N,3*D) time-major
@@ -254,10 +257,11 @@ int tecm_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ld
  * what a Linear's output is under torch.autocast, train.py:68; scores, softmax and the weighted sum stay fp32). */
 #define TECM_ATT_OUT_BF16 1
 #define TECM_ATT_QKV_BF16 2
+#define TECM_ATT_DCTX_BF16 4     /* backward only, with TECM_ATT_QKV_BF16: dctx is the bf16 tensor attn.c_proj's d-input GEMM wrote */
 int tecm_attention_fwd(const float* qkv, void* ctx, int32_t io_bf16, int32_t B, int32_t T, int32_t N, int32_t heads,
                        int32_t D, const TecmDrop* prob_drop, void* stream);
 /* io_bf16: TECM_ATT_OUT_BF16 -- dqkv is a bf16 (B,T,N,3*D) tensor (its readers, the c_attn dX and the LoRA-B dW GEMMs, are
- * bf16 GEMMs); TECM_ATT_QKV_BF16 -- qkv is the bf16 tensor the forward read.  dctx is fp32. */
+ * bf16 GEMMs); TECM_ATT_QKV_BF16 -- qkv is the bf16 tensor the forward read; TECM_ATT_DCTX_BF16 -- dctx is bf16 (else fp32). */
 int tecm_attention_bwd(const float* qkv, const float* dctx, void* dqkv, int32_t io_bf16, int32_t B, int32_t T, int32_t N,
                        int32_t heads, int32_t D, const TecmDrop* prob_drop, void* stream);
 

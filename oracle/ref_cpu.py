@@ -361,7 +361,9 @@ def gpt2_lora(h: torch.Tensor, p: Params, n_layers: int, q: Rounding = FP32, mas
         Bm = p[pre + "attn.c_attn.lora_B.default.weight"]    # (2304, r)
         z = mm(_mul(u, masks, f"lora{i}"), A.t(), q)
         wcat = torch.cat([p[pre + "attn.c_attn.base_layer.weight"], LORA_SCALE * Bm.t()], 0)     # (768 + r, 2304)
-        qkv = stored(mm(torch.cat([u, z], -1), wcat, q) + p[pre + "attn.c_attn.base_layer.bias"], q)   # a bf16 tensor under autocast
+        # (grad_stored: the gradient a bf16 Linear returns for its input is a bf16 tensor under autocast -- d [LN1-out | z],
+        #  d ctx and d LN2-out are stored as such by the device's d-input GEMMs and read by fp32 kernels)
+        qkv = stored(mm(grad_stored(torch.cat([u, z], -1), q), wcat, q) + p[pre + "attn.c_attn.base_layer.bias"], q)   # a bf16 tensor under autocast
         qq, k, v = qkv.split(D, dim=-1)
         qq = qq.view(S, T, GPT2_HEADS, hd).transpose(1, 2)
         k = k.view(S, T, GPT2_HEADS, hd).transpose(1, 2)
@@ -369,10 +371,10 @@ def gpt2_lora(h: torch.Tensor, p: Params, n_layers: int, q: Rounding = FP32, mas
         w = (qq @ k.transpose(-1, -2)) / math.sqrt(hd)
         w = _mul(w.masked_fill(~causal, float("-inf")).softmax(-1), masks, f"attn{i}")
         ctx = (w @ v).transpose(1, 2).reshape(S, T, D)
-        h = h + _mul(mm(ctx, p[pre + "attn.c_proj.weight"], q) + p[pre + "attn.c_proj.bias"], masks, f"res1_{i}")
+        h = h + _mul(mm(grad_stored(ctx, q), p[pre + "attn.c_proj.weight"], q) + p[pre + "attn.c_proj.bias"], masks, f"res1_{i}")
         u = F.layer_norm(h, (D,), p[pre + "ln_2.weight"], p[pre + "ln_2.bias"], LN_EPS)
         # autocast's c_fc output IS a bf16 tensor (train.py:68): GELU and its derivative see the rounded value
-        f = gelu_new(stored(mm(u, p[pre + "mlp.c_fc.weight"], q) + p[pre + "mlp.c_fc.bias"], q))
+        f = gelu_new(stored(mm(grad_stored(u, q), p[pre + "mlp.c_fc.weight"], q) + p[pre + "mlp.c_fc.bias"], q))
         h = h + _mul(mm(f, p[pre + "mlp.c_proj.weight"], q) + p[pre + "mlp.c_proj.bias"], masks, f"res2_{i}")
     return F.layer_norm(h, (D,), p[P_GPT + "ln_f.weight"], p[P_GPT + "ln_f.bias"], LN_EPS)
 

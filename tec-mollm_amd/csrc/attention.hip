@@ -183,7 +183,8 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel_kv(const float* __re
 // Backward: recompute the probabilities, then
 //   dP~_ij = <dctx_i, v_j>;  dV_j += P~_ij dctx_i;  dP_ij = dP~_ij * keep/(1-p);
 //   dS_ij = P_ij (dP_ij - sum_k P_ik dP_ik);  dQ_i += dS_ij K_j / 8;  dK_j += dS_ij Q_i / 8.
-template <int TT, bool Q16>
+// D16: dctx is the bf16 tensor the attn.c_proj d-input GEMM wrote (bf16 mode: the gradient of a bf16 Linear's input)
+template <int TT, bool Q16, bool D16 = false>
 __device__ __forceinline__ void attention_bwd_body(const float* __restrict__ qkv, const float* __restrict__ dctx,
                                                    float* __restrict__ dqkv, int dqkv_bf16, int B, int Trt, int N, int H,
                                                    int D, DropA dr) {
@@ -214,7 +215,7 @@ __device__ __forceinline__ void attention_bwd_body(const float* __restrict__ qkv
   }
 #pragma unroll
   for (int i = 0; i < T; ++i) {
-    const float4 go = *reinterpret_cast<const float4*>(dctx + (row0 + (int64_t)i * N) * D + col);
+    const float4 go = ldq<D16>(dctx, (row0 + (int64_t)i * N) * D + col);
     float pr[TM], dp[TM];
     float mx = -INFINITY;
 #pragma unroll
@@ -262,7 +263,7 @@ __device__ __forceinline__ void attention_bwd_body(const float* __restrict__ qkv
 // arrays with runtime bounds, i.e. scratch: 6.0 ms per launch at B = 2, L_in = 336 against 1.2 ms for the forward), and
 // the guards keep the scheduler from interleaving query rows (a guard-free T = 21 instance hoisted the loads of all
 // rows and spilled 856 VGPRs).
-template <int TM, bool Q16>
+template <int TM, bool Q16, bool D16 = false>
 __global__ __launch_bounds__(256, 1) void attention_bwd_kernel_qstream(const float* __restrict__ qkv,
                                                                        const float* __restrict__ dctx,
                                                                        float* __restrict__ dqkv, int dqkv_bf16, int B, int T,
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel_qstream(const flo
     if (i < T) {
       const int64_t roff = row0 + (int64_t)i * N;
       const float4 qi = ldq<Q16>(qkv, roff * ld + col);
-      const float4 go = *reinterpret_cast<const float4*>(dctx + roff * D + col);
+      const float4 go = ldq<D16>(dctx, roff * D + col);
       float4 dqi = make_float4(0.f, 0.f, 0.f, 0.f);
       float pr[TM], dp[TM];
       float mx = -INFINITY;
@@ -340,19 +341,19 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel_qstream(const flo
   }
 }
 
-template <int TT, bool Q16>
+template <int TT, bool Q16, bool D16 = false>
 __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restrict__ qkv,
                                                             const float* __restrict__ dctx, float* __restrict__ dqkv,
                                                             int dqkv_bf16, int B, int Trt, int N, int H, int D, DropA dr) {
-  attention_bwd_body<TT, Q16>(qkv, dctx, dqkv, dqkv_bf16, B, Trt, N, H, D, dr);
+  attention_bwd_body<TT, Q16, D16>(qkv, dctx, dqkv, dqkv_bf16, B, Trt, N, H, D, dr);
 }
 // T = 8, 12: six float4[T] register arrays need more than 256 VGPRs -- one wave per SIMD, the whole 512-entry file
-template <int TT, bool Q16>
+template <int TT, bool Q16, bool D16 = false>
 __global__ __launch_bounds__(256, 1) void attention_bwd_kernel_wide(const float* __restrict__ qkv,
                                                                     const float* __restrict__ dctx,
                                                                     float* __restrict__ dqkv, int dqkv_bf16, int B, int Trt,
                                                                     int N, int H, int D, DropA dr) {
-  attention_bwd_body<TT, Q16>(qkv, dctx, dqkv, dqkv_bf16, B, Trt, N, H, D, dr);
+  attention_bwd_body<TT, Q16, D16>(qkv, dctx, dqkv, dqkv_bf16, B, Trt, N, H, D, dr);
 }
 
 int check(const char* who, const void* a, const void* b, const void* c, int B, int T, int N, int heads, int D) {
@@ -418,16 +419,19 @@ extern "C" int tecm_attention_bwd(const float* qkv, const float* dctx, void* dqk
   float* dqkv = reinterpret_cast<float*>(dqkv_);
   const int rc = check("tecm_attention_bwd", qkv, dctx, dqkv, B, T, N, heads, D);
   if (rc) return rc;
-  TECM_REQUIRE((io_bf16 & ~3) == 0, TECM_E_ARG, "tecm_attention_bwd: io_bf16 is a mask of TECM_ATT_OUT_BF16 | TECM_ATT_QKV_BF16");
+  TECM_REQUIRE((io_bf16 & ~7) == 0 && (!(io_bf16 & TECM_ATT_DCTX_BF16) || (io_bf16 & TECM_ATT_QKV_BF16)), TECM_E_ARG,
+               "tecm_attention_bwd: io_bf16 is a mask of TECM_ATT_OUT_BF16 | TECM_ATT_QKV_BF16 | TECM_ATT_DCTX_BF16 (the last "
+               "only with a bf16 qkv)");
   const int dqkv_bf16 = io_bf16 & TECM_ATT_OUT_BF16;
-  const bool q16 = (io_bf16 & TECM_ATT_QKV_BF16) != 0;
+  const bool q16 = (io_bf16 & TECM_ATT_QKV_BF16) != 0, d16 = (io_bf16 & TECM_ATT_DCTX_BF16) != 0;
   const int64_t items = (int64_t)B * N * heads;
   const dim3 grid((unsigned)((items + 15) / 16));
   const DropA dr = make_dropa(prob_drop);
   hipStream_t st = (hipStream_t)stream;
 #define ATT_LAUNCH(KERNEL, TT)                                                                                             \
   do {                                                                                                                     \
-    if (q16) hipLaunchKernelGGL((KERNEL<TT, true>), grid, dim3(256), 0, st, qkv, dctx, dqkv, dqkv_bf16, B, T, N, heads, D, dr); \
+    if (q16 && d16) hipLaunchKernelGGL((KERNEL<TT, true, true>), grid, dim3(256), 0, st, qkv, dctx, dqkv, dqkv_bf16, B, T, N, heads, D, dr); \
+    else if (q16) hipLaunchKernelGGL((KERNEL<TT, true>), grid, dim3(256), 0, st, qkv, dctx, dqkv, dqkv_bf16, B, T, N, heads, D, dr); \
     else hipLaunchKernelGGL((KERNEL<TT, false>), grid, dim3(256), 0, st, qkv, dctx, dqkv, dqkv_bf16, B, T, N, heads, D, dr);    \
   } while (0)
   switch (T) {

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 // rounded to bf16 first when `lora_bf16`: the bf16 mode's contraction with bf16 operands and fp32 accumulation); the
 // per-wave reduction rows of the parameter gradients alias the same LDS once the row loop is over.
 struct LoraBack {
-  const float* dz;      // (M, r) with leading dimension lddz
+  const float* dz;      // (M, r) with leading dimension lddz; bf16 when the kernel's dy is (they are columns of one matrix)
   int64_t lddz;
   const float* A;       // (r, D)
   int32_t r, bf16;
@@ -105,7 +105,8 @@ struct LoraBack {
 
 __device__ __forceinline__ float ln_round_bf16(float v) { return (float)(__bf16)v; }
 
-template <int NCH, int NW, bool LORA>
+// DY16: dy is a bf16 matrix (bf16 mode: the gradient a bf16 Linear hands back for its input, train.py:68)
+template <int NCH, int NW, bool LORA, bool DY16 = false>
 __global__ __launch_bounds__(64 * NW) void layernorm_bwd_kernel(const float* __restrict__ dy, int64_t lddy,
                                                             const float* __restrict__ x, int64_t ldx,
                                                             const float* __restrict__ gamma,
@@ -137,33 +138,65 @@ __global__ __launch_bounds__(64 * NW) void layernorm_bwd_kernel(const float* __r
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = 4 * (lane + 64 * i);
-      dv[i] = c < D ? *reinterpret_cast<const float4*>(dy + row * lddy + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < D) {
+        if constexpr (DY16) {
+          const tecm_bf16x4 h = *reinterpret_cast<const tecm_bf16x4*>(reinterpret_cast<const __bf16*>(dy) + row * lddy + c);
+          dv[i] = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+        } else {
+          dv[i] = *reinterpret_cast<const float4*>(dy + row * lddy + c);
+        }
+      } else {
+        dv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
     if constexpr (LORA) {
-      float dzl = lane < lb.r ? lb.dz[row * lb.lddz + lane] : 0.f;
+      float dzl = 0.f;
+      if (lane < lb.r) dzl = DY16 ? (float)reinterpret_cast<const __bf16*>(lb.dz)[row * lb.lddz + lane] : lb.dz[row * lb.lddz + lane];
       if (lb.bf16) dzl = ln_round_bf16(dzl);
       float4 acc[NCH];
 #pragma unroll
       for (int i = 0; i < NCH; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       // dz[row][j] is wave-uniform: v_readlane of lane j (a compile-time lane in the unrolled r = 32 form -- a run-time
-      // lane would be a ds_bpermute, an LDS operation per term, beside the three LDS reads of A's row)
-      auto term = [&](int j, float sj) {
-        const float* Aj = lds_ln + j * D;
+      // lane would be a ds_bpermute, an LDS operation per term, beside the three LDS reads of A's row).  The rows of A are
+      // read LJ j at a time into registers before their FMAs: one LDS round trip per group, not one per read (the straight
+      // loop compiled to read -> lgkmcnt(0) -> two packed FMAs, 96 exposed LDS latencies per row; a 1024-thread block has
+      // 128 registers per lane, which is what bounds LJ).
+      if (lb.r == 32) {
+        constexpr int LJ = 4;
+#pragma unroll 1                                        // rolled: fully unrolled the scheduler hoists every read and spills
+        for (int jb = 0; jb < 32; jb += LJ) {
+          float4 a[LJ][NCH];
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-          const int c = 4 * (lane + 64 * i);
-          if (c < D) {
-            const float4 a = *reinterpret_cast<const float4*>(Aj + c);
-            acc[i].x = fmaf(sj, a.x, acc[i].x); acc[i].y = fmaf(sj, a.y, acc[i].y);
-            acc[i].z = fmaf(sj, a.z, acc[i].z); acc[i].w = fmaf(sj, a.w, acc[i].w);
+          for (int jj = 0; jj < LJ; ++jj)
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+              const int c = 4 * (lane + 64 * i);
+              a[jj][i] = c < D ? *reinterpret_cast<const float4*>(lds_ln + (jb + jj) * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+          for (int jj = 0; jj < LJ; ++jj) {
+            const float sj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dzl), jb + jj));
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+              acc[i].x = fmaf(sj, a[jj][i].x, acc[i].x); acc[i].y = fmaf(sj, a[jj][i].y, acc[i].y);
+              acc[i].z = fmaf(sj, a[jj][i].z, acc[i].z); acc[i].w = fmaf(sj, a[jj][i].w, acc[i].w);
+            }
           }
         }
-      };
-      if (lb.r == 32) {
-#pragma unroll
-        for (int j = 0; j < 32; ++j) term(j, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dzl), j)));
       } else {
-        for (int j = 0; j < lb.r; ++j) term(j, __shfl(dzl, j));
+        for (int j = 0; j < lb.r; ++j) {
+          const float sj = __shfl(dzl, j);
+          const float* Aj = lds_ln + j * D;
+#pragma unroll
+          for (int i = 0; i < NCH; ++i) {
+            const int c = 4 * (lane + 64 * i);
+            if (c < D) {
+              const float4 av = *reinterpret_cast<const float4*>(Aj + c);
+              acc[i].x = fmaf(sj, av.x, acc[i].x); acc[i].y = fmaf(sj, av.y, acc[i].y);
+              acc[i].z = fmaf(sj, av.z, acc[i].z); acc[i].w = fmaf(sj, av.w, acc[i].w);
+            }
+          }
+        }
       }
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
@@ -573,7 +606,9 @@ __global__ __launch_bounds__((GnGeom<CPB, WPS>::NTHR)) void gn_gelu_fwd_reg(cons
   }
 }
 
-template <int CPB, int WPS, int GN_NPMAX, bool IO16, bool D16 = false>
+// Y16: y itself is bf16 (round 4; 8-byte loads: the same number of requests as the fp32 form, half the bytes -- the
+// 8-channel kernels below issue a third of the requests per lane and run slower in this direction)
+template <int CPB, int WPS, int GN_NPMAX, bool IO16, bool D16 = false, bool Y16 = false>
 __global__ __launch_bounds__((GnGeom<CPB, WPS>::NTHR)) void gn_gelu_bwd_reg(const void* __restrict__ dact, int dstride, int L2,
                                                        const void* __restrict__ y, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const float* __restrict__ stats,
@@ -634,7 +669,7 @@ __global__ __launch_bounds__((GnGeom<CPB, WPS>::NTHR)) void gn_gelu_bwd_reg(cons
       for (int i = 0; i < GN_NPMAX; ++i) {
         off[i] = t * (int32_t)tstride + q * 4;
         if (i < NP) {
-          yh[i] = gn_ld4<false>(y, ybase + off[i]);
+          yh[i] = gn_ld4<Y16>(y, ybase + off[i]);
           const bool has = (t % dstride) == 0;
           // (D16: the gradient of the strided 1x1 conv's input arrives as the bf16 tensor its bf16 GEMM wrote)
           gd[i] = has ? gn_ld4<D16>(dact, dbase + (t / dstride) * (int32_t)tstride + q * 4)
@@ -1133,7 +1168,8 @@ extern "C" int tecm_layernorm_fwd(const float* x, int64_t ldx, const float* gamm
 extern "C" int tecm_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                                   const float* stats, const float* dres, float* dx, void* dx_masked,
                                   int32_t masked_bf16, const TecmDrop* mask_drop, float* dgb_partials,
-                                  int32_t* num_blocks, int64_t M, int32_t D, const TecmLoraBack* lora, void* stream) {
+                                  int32_t* num_blocks, int64_t M, int32_t D, const TecmLoraBack* lora, int32_t dy_bf16,
+                                  void* stream) {
   TECM_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAXCH, TECM_E_ARG, "tecm_layernorm_bwd: bad M/D");
   const bool has_lora = lora != nullptr && lora->dz != nullptr;
   // the LoRA variant keeps lora_A (r x D floats) in LDS: one 1024-thread block per CU, 16 rows in flight per block
@@ -1141,7 +1177,7 @@ extern "C" int tecm_layernorm_bwd(const float* dy, int64_t lddy, const float* x,
   if (num_blocks) *num_blocks = nb;
   if (dx == nullptr) return TECM_OK;   // query mode
   TECM_REQUIRE(dy && x && gamma && stats && dgb_partials, TECM_E_ARG, "tecm_layernorm_bwd: null pointer");
-  TECM_REQUIRE(lddy % 4 == 0 && ldx % 4 == 0 && tecm_aligned(dy, 16) && tecm_aligned(x, 16) &&
+  TECM_REQUIRE(lddy % 4 == 0 && ldx % 4 == 0 && tecm_aligned(dy, dy_bf16 ? 8 : 16) && tecm_aligned(x, 16) &&
                    tecm_aligned(dx, 16) && (!dres || tecm_aligned(dres, 16)) &&
                    (!dx_masked || tecm_aligned(dx_masked, 16)),
                TECM_E_ALIGN, "tecm_layernorm_bwd: 16-byte alignment required");
@@ -1161,11 +1197,16 @@ extern "C" int tecm_layernorm_bwd(const float* dy, int64_t lddy, const float* x,
     TECM_REQUIRE(lds <= 160 * 1024, TECM_E_LDS, "tecm_layernorm_bwd: lora_A (%d x %d) does not fit the LDS", lora->r, D);
 #define LN_BWD_L(NCH)                                                                                                   \
   {                                                                                                                     \
-    const void* fn = reinterpret_cast<const void*>(&layernorm_bwd_kernel<NCH, NW, true>);                               \
+    const void* fn = dy_bf16 ? reinterpret_cast<const void*>(&layernorm_bwd_kernel<NCH, NW, true, true>)                \
+                             : reinterpret_cast<const void*>(&layernorm_bwd_kernel<NCH, NW, true>);                     \
     TECM_REQUIRE(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,          \
                  TECM_E_LAUNCH, "tecm_layernorm_bwd: hipFuncSetAttribute failed");                                       \
-    hipLaunchKernelGGL((layernorm_bwd_kernel<NCH, NW, true>), dim3(nb), dim3(64 * NW), lds, st, dy, lddy, x, ldx, gamma, \
-                       stats, dres, dx, static_cast<float*>(dx_masked), (int)masked_bf16, odc, dgb_partials, M, D, lb);  \
+    if (dy_bf16)                                                                                                        \
+      hipLaunchKernelGGL((layernorm_bwd_kernel<NCH, NW, true, true>), dim3(nb), dim3(64 * NW), lds, st, dy, lddy, x, ldx,   \
+                         gamma, stats, dres, dx, static_cast<float*>(dx_masked), (int)masked_bf16, odc, dgb_partials, M, D, lb); \
+    else                                                                                                                \
+      hipLaunchKernelGGL((layernorm_bwd_kernel<NCH, NW, true>), dim3(nb), dim3(64 * NW), lds, st, dy, lddy, x, ldx, gamma, \
+                         stats, dres, dx, static_cast<float*>(dx_masked), (int)masked_bf16, odc, dgb_partials, M, D, lb); \
   }
     switch (nch) {
       case 1: LN_BWD_L(1); break;
@@ -1178,9 +1219,16 @@ extern "C" int tecm_layernorm_bwd(const float* dy, int64_t lddy, const float* x,
     return TECM_OK;
   }
 #define LN_BWD(NCH)                                                                                                    \
-  hipLaunchKernelGGL((layernorm_bwd_kernel<NCH, 4, false>), dim3(nb), dim3(256), (size_t)4 * 2 * 4 * 64 * NCH * sizeof(float), \
-                     st, dy, lddy, x, ldx, gamma, stats, dres, dx, static_cast<float*>(dx_masked), (int)masked_bf16, odc,   \
-                     dgb_partials, M, D, lb)
+  do {                                                                                                                 \
+    if (dy_bf16)                                                                                                       \
+      hipLaunchKernelGGL((layernorm_bwd_kernel<NCH, 4, false, true>), dim3(nb), dim3(256),                              \
+                         (size_t)4 * 2 * 4 * 64 * NCH * sizeof(float), st, dy, lddy, x, ldx, gamma, stats, dres, dx,    \
+                         static_cast<float*>(dx_masked), (int)masked_bf16, odc, dgb_partials, M, D, lb);               \
+    else                                                                                                               \
+      hipLaunchKernelGGL((layernorm_bwd_kernel<NCH, 4, false>), dim3(nb), dim3(256),                                    \
+                         (size_t)4 * 2 * 4 * 64 * NCH * sizeof(float), st, dy, lddy, x, ldx, gamma, stats, dres, dx,    \
+                         static_cast<float*>(dx_masked), (int)masked_bf16, odc, dgb_partials, M, D, lb);               \
+  } while (0)
   switch (nch) {
     case 1: LN_BWD(1); break;
     case 2: LN_BWD(2); break;
@@ -1299,7 +1347,29 @@ extern "C" int tecm_groupnorm_gelu_bwd(const void* dact_, int32_t dstride, const
   TECM_REQUIRE(dact && y && gamma && beta && stats && dgb_partials, TECM_E_ARG, "tecm_groupnorm_gelu_bwd: null pointer");
   const int L2 = (L + dstride - 1) / dstride;
   hipStream_t st = (hipStream_t)stream;
-  if (io_bf16 & TECM_GN_Y_BF16) {                        // every tensor bf16: the oct kernel
+  if (io_bf16 & TECM_GN_Y_BF16) {                        // every tensor bf16
+    // the four-channel register kernel with 8-byte y / dact loads where its geometry serves the sequence (measured at B = 8:
+    // 1.3x faster than the 8-channel kernel in this direction: more requests in flight per lane), else the 8-channel one
+    const int npq = tecm_aligned(dact_, 8) ? gn_reg_pairs(L, N, Cout, 4, 9, y_, dy_) : 0;
+    if (npq > 0) {
+#define GN_BWD_Q16(CPB) \
+  hipLaunchKernelGGL((gn_gelu_bwd_reg<CPB, 4, 9, true, true, true>), dim3(nb), dim3(256), 0, st, dact_, dstride, L2, y_, gamma, \
+                     beta, stats, dy_, dgb_partials, B, L, N, npq)
+      if (Cout == 64) GN_BWD_Q16(1); else if (Cout == 128) GN_BWD_Q16(2); else GN_BWD_Q16(4);
+#undef GN_BWD_Q16
+      TECM_CHECK_LAUNCH("tecm_groupnorm_gelu_bwd/reg-y16");
+      return TECM_OK;
+    }
+    const int npq8 = tecm_aligned(dact_, 8) ? gn_reg_pairs(L, N, Cout, 8, 9, y_, dy_) : 0;
+    if (npq8 > 0) {
+#define GN_BWD_Q16(CPB) \
+  hipLaunchKernelGGL((gn_gelu_bwd_reg<CPB, 8, 9, true, true, true>), dim3(nb), dim3(512), 0, st, dact_, dstride, L2, y_, gamma, \
+                     beta, stats, dy_, dgb_partials, B, L, N, npq8)
+      if (Cout == 64) GN_BWD_Q16(1); else if (Cout == 128) GN_BWD_Q16(2); else GN_BWD_Q16(4);
+#undef GN_BWD_Q16
+      TECM_CHECK_LAUNCH("tecm_groupnorm_gelu_bwd/reg8-y16");
+      return TECM_OK;
+    }
     const int ng = gn16_ng(L, N, Cout, y_, dy_);
     TECM_REQUIRE(ng > 0 && tecm_aligned(dact_, 16), TECM_E_ARG,
                  "tecm_groupnorm_gelu_bwd: a bf16 y needs L * 3*Cout/8 <= 2304, Cout in {64, 128, 256}, 16-byte aligned tensors");

@@ -156,7 +156,7 @@ EXPORTS = {
                                      c_f32p, C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
     "tecm_layernorm_bwd": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p,
                                      C.c_int32, C.POINTER(TecmDrop), c_f32p, C.POINTER(C.c_int32), C.c_int64, C.c_int32,
-                                     C.POINTER(TecmLoraBack), C.c_void_p]),
+                                     C.POINTER(TecmLoraBack), C.c_int32, C.c_void_p]),
     "tecm_attention_fwd": (C.c_int, [c_f32p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                      C.c_int32, C.POINTER(TecmDrop), C.c_void_p]),
     "tecm_cast_bf16": (C.c_int, [c_f32p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),

@@ -22,6 +22,7 @@ from .graph import GraphMeta
 from .ops import (A_KM, A_MK, ACT_GELU_ERF, ACT_GELU_TANH, B_KN, B_NK, colsum, drop, gemm, pick_split_k, win)
 
 PRE16 = os.environ.get("TECM_PRE16", "1")[:1] != "0"     # diagnostics: "0" keeps the GPT-2 MLP pre-activation fp32
+GRAD16 = os.environ.get("TECM_GRAD16", "1")[:1] != "0"   # diagnostics: "0" keeps d LN-out / d ctx fp32 in bf16 mode
 QKV16 = os.environ.get("TECM_QKV16", "1")[:1] != "0"   # diagnostics: "0" keeps qkv fp32 in bf16 mode
 
 import ctypes as C
@@ -697,7 +698,10 @@ class GPT2StackFn(torch.autograd.Function):
             da16 = Wpr_b.dtype == torch.bfloat16 and Wfc_b.dtype == torch.bfloat16
             da = torch.empty(M, F4, device=dh.device, dtype=torch.bfloat16 if da16 else torch.float32)
             gemm(M, F4, D, dhm, D, Wpr_b, D, da, F4, act=ACT_GELU_TANH, dact_src=(a, F4), bf16=plan.bf16)
-            du2 = _empty(M, D, like=dh)
+            # the gradients the frozen bf16 Linears hand back for their inputs (d LN2-out here, d ctx and d [LN1-out | z]
+            # below) are bf16 tensors under autocast: written as such by their GEMMs, read once by fp32 kernels
+            g16 = b16 and da16 and GRAD16
+            du2 = torch.empty(M, D, device=dh.device, dtype=torch.bfloat16 if g16 else torch.float32)
             gemm(M, D, F4, da, F4, Wfc_b, F4, du2, D, bf16=plan.bf16)
             del da
             dh2 = _empty(M, D, like=dh)
@@ -708,14 +712,18 @@ class GPT2StackFn(torch.autograd.Function):
                                          dx_masked=dh2m if sp is not None else None, mask_drop=sp,
                                          need_dgb=nig[pb + 8] or nig[pb + 9])
             # attention: h2 = h + drop(ctx Wo + b)
-            dcx = du2                                         # reuse buffer
-            gemm(M, D, D, dh2m, D, _bwd_weight(Wo, plan.bf16), D, dcx, D, bf16=plan.bf16)
+            Wo_b = _bwd_weight(Wo, plan.bf16)
+            c16 = g16 and Wo_b.dtype == torch.bfloat16 and dh2m.dtype == torch.bfloat16 and qkv.dtype == torch.bfloat16
+            dcx = torch.empty(M, D, device=dh.device, dtype=torch.bfloat16) if c16 else \
+                (du2 if du2.dtype == torch.float32 else _empty(M, D, like=dh))            # fp32: reuse the buffer
+            gemm(M, D, D, dh2m, D, Wo_b, D, dcx, D, bf16=plan.bf16)
             # dqkv is read by the c_attn dX GEMM ([row][k] A) and the LoRA-B dW GEMM ([k][m] A): bf16 when both run on the
             # bf16 matrix cores against a bf16 copy of [W ; (alpha/r) B^T]
             q16 = b16 and wcat.dtype == torch.bfloat16
             dqkv = torch.empty(M, F3, device=dh.device, dtype=torch.bfloat16 if q16 else torch.float32)
             ops.attention_bwd(qkv, dcx, dqkv, B, T, N, GPT_HEADS, D, plan.spec(site_attn(i), 1))
-            du = _empty(M, KE, like=dh)                       # [ d LN1-out (base path) | dz ]
+            u16g = g16 and q16 and u.dtype == torch.bfloat16
+            du = torch.empty(M, KE, device=dh.device, dtype=torch.bfloat16 if u16g else torch.float32)   # [ d LN1-out | dz ]
             gemm(M, KE, F3, dqkv, F3, wcat, F3, du, KE, bf16=plan.bf16)
             lspec = plan.spec(site_lora(i), KE)
             dlB = _empty(F3, LORA_R, like=dh)

@@ -300,8 +300,8 @@ def _lora_back(lora) -> Optional["_lib.TecmLoraBack"]:
     if lora is None:
         return None
     du, ld, off, A, dspec, b16 = lora
-    if A.dtype != torch.float32 or not A.is_contiguous() or du.dtype != torch.float32:
-        raise _lib.TecmError("layernorm_bwd: the LoRA back-path takes fp32 dz and a contiguous fp32 lora_A")
+    if A.dtype != torch.float32 or not A.is_contiguous() or du.dtype not in (torch.float32, torch.bfloat16):
+        raise _lib.TecmError("layernorm_bwd: the LoRA back-path takes fp32 / bf16 dz and a contiguous fp32 lora_A")
     return _lib.TecmLoraBack(dz=_off(du, off), ld_dz=ld, A=A.data_ptr(), r=A.shape[0], bf16_operands=1 if b16 else 0,
                              drop=dspec if dspec is not None else NO_DROP)
 
@@ -310,7 +310,7 @@ def layernorm_bwd_blocks(M: int, D: int, lora=None) -> int:
     nb = C.c_int32(0)
     lb = _lora_back(lora)
     check(lib().tecm_layernorm_bwd(None, 0, None, 0, None, None, None, None, None, 0, None, None, C.byref(nb), M, D,
-                                   C.byref(lb) if lb is not None else None, None), "tecm_layernorm_bwd(query)")
+                                   C.byref(lb) if lb is not None else None, 0, None), "tecm_layernorm_bwd(query)")
     return nb.value
 
 
@@ -325,13 +325,16 @@ def layernorm_bwd(dy: torch.Tensor, lddy: int, x: torch.Tensor, ldx: int, gamma:
     LayerNorm: the per-block partials are not reduced)."""
     m16 = 1 if (dx_masked is not None and dx_masked.dtype == torch.bfloat16) else 0
     lb = _lora_back(lora)
+    dy16 = 1 if dy.dtype == torch.bfloat16 else 0        # bf16 mode: the gradient a bf16 GEMM returned for its input
+    if lora is not None and lora[0].dtype != dy.dtype:
+        raise _lib.TecmError("layernorm_bwd: dz and dy are columns of one matrix: one dtype")
     nb = layernorm_bwd_blocks(M, D, lora)
     partials = torch.empty(nb, 2 * D, device=dx.device, dtype=torch.float32)
     nbc = C.c_int32(0)
     od = mask_drop if mask_drop is not None else NO_DROP
     check(lib().tecm_layernorm_bwd(dy.data_ptr(), lddy, x.data_ptr(), ldx, gamma.data_ptr(), stats.data_ptr(),
                                    ptr(dres), dx.data_ptr(), ptr(dx_masked), m16, C.byref(od), partials.data_ptr(),
-                                   C.byref(nbc), M, D, C.byref(lb) if lb is not None else None, stream_ptr()),
+                                   C.byref(nbc), M, D, C.byref(lb) if lb is not None else None, dy16, stream_ptr()),
           "tecm_layernorm_bwd")
     if not need_dgb:
         return None, None
@@ -404,7 +407,7 @@ def groupnorm_gelu_bwd(dact: torch.Tensor, dstride: int, y: torch.Tensor, gamma:
     return dgb[0, :CT], dgb[0, CT:2 * CT], dgb[0, 2 * CT:]
 
 
-ATT_OUT_BF16, ATT_QKV_BF16 = 1, 2      # io_bf16 of tecm_attention_fwd / _bwd
+ATT_OUT_BF16, ATT_QKV_BF16, ATT_DCTX_BF16 = 1, 2, 4      # io_bf16 of tecm_attention_fwd / _bwd
 
 
 def attention_fwd(qkv: torch.Tensor, ctx: torch.Tensor, B: int, T: int, N: int, heads: int, D: int,
@@ -418,7 +421,8 @@ def attention_fwd(qkv: torch.Tensor, ctx: torch.Tensor, B: int, T: int, N: int, 
 def attention_bwd(qkv: torch.Tensor, dctx: torch.Tensor, dqkv: torch.Tensor, B: int, T: int, N: int, heads: int,
                   D: int, prob_drop: Optional[TecmDrop] = None) -> None:
     pd = prob_drop if prob_drop is not None else NO_DROP
-    io = (ATT_OUT_BF16 if dqkv.dtype == torch.bfloat16 else 0) | (ATT_QKV_BF16 if qkv.dtype == torch.bfloat16 else 0)
+    io = (ATT_OUT_BF16 if dqkv.dtype == torch.bfloat16 else 0) | (ATT_QKV_BF16 if qkv.dtype == torch.bfloat16 else 0) | \
+        (ATT_DCTX_BF16 if dctx.dtype == torch.bfloat16 else 0)
     check(lib().tecm_attention_bwd(qkv.data_ptr(), dctx.data_ptr(), dqkv.data_ptr(), io, B, T, N, heads, D, C.byref(pd),
                                    stream_ptr()), "tecm_attention_bwd")
 

@@ -231,22 +231,22 @@ int tecm_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const fl
  * store instead of one hash per element per GEMM column tile.  dgb_partials (num_blocks, 2*D);
  * dx == NULL only queries *num_blocks. */
 /* masked_bf16 != 0: dx_masked is a bf16 (M, D) matrix (its only reader is a bf16 GEMM). */
-/* Optional LoRA back-path folded into dy before the LayerNorm backward (peft Linear on c_attn, modules.py:177-186):
- *   dy[row][c] += keep(row*drop.ld + c) / (1 - p) * sum_j dz[row][j] * A[j][c],   dz (M, r) fp32, A = lora_A (r, D) fp32;
- * bf16_operands != 0: dz and A are rounded to bf16 first (the bf16 mode's contraction), accumulation is fp32 either way. */
-typedef struct TecmLoraBack {
-  const float* dz;
-  int64_t ld_dz;
-  const float* A;
-  int32_t r, bf16_operands;
+/* Optional second gradient stream of the same tensor, added before the LayerNorm backward:
+ *   dy[row][c] += keep(row*drop.ld + c) / (1 - p) * dy2[row][c]        (drop.p == 0: no mask)
+ * -- the gradient peft's LoRA branch returns for its input (lora_A's d-input GEMM, modules.py:177-186) reaching the
+ * LayerNorm output through lora_dropout's backward (modules.py:181).  dy2: (M, D) fp32 or bf16 with leading dimension ld. */
+typedef struct TecmLnAdd {
+  const void* dy2;
+  int64_t ld;
+  int32_t bf16, _pad;
   TecmDrop drop;
-} TecmLoraBack;
+} TecmLnAdd;
 int tecm_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                        const float* stats, const float* dres, float* dx, void* dx_masked, int32_t masked_bf16,
                        const TecmDrop* mask_drop, float* dgb_partials, int32_t* num_blocks, int64_t M, int32_t D,
-                       const TecmLoraBack* lora /* NULL: none */,
-                       int32_t dy_bf16 /* != 0: dy (and lora->dz, columns of the same matrix) are bf16 -- the gradient a bf16
-                                          Linear returns for its input under autocast (train.py:68) */,
+                       const TecmLnAdd* add /* NULL: none */,
+                       int32_t dy_bf16 /* != 0: dy is bf16 -- the gradient a bf16 Linear returns for its input under
+                                          autocast (train.py:68) */,
                        void* stream);
 
 /* Causal multi-head self-attention over T tokens per sequence (GPT2Attention, modeling_gpt2.py:54-73,

@@ -359,7 +359,7 @@ def gpt2_lora(h: torch.Tensor, p: Params, n_layers: int, q: Rounding = FP32, mas
         u = F.layer_norm(h, (D,), p[pre + "ln_1.weight"], p[pre + "ln_1.bias"], LN_EPS)
         A = p[pre + "attn.c_attn.lora_A.default.weight"]     # (r, 768)
         Bm = p[pre + "attn.c_attn.lora_B.default.weight"]    # (2304, r)
-        z = mm(_mul(u, masks, f"lora{i}"), A.t(), q)
+        z = mm(grad_stored(_mul(u, masks, f"lora{i}"), q), A.t(), q)      # lora_A's input gradient: a bf16 tensor too
         wcat = torch.cat([p[pre + "attn.c_attn.base_layer.weight"], LORA_SCALE * Bm.t()], 0)     # (768 + r, 2304)
         # (grad_stored: the gradient a bf16 Linear returns for its input is a bf16 tensor under autocast -- d [LN1-out | z],
         #  d ctx and d LN2-out are stored as such by the device's d-input GEMMs and read by fp32 kernels)

@@ -89,40 +89,30 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   }
 }
 
-// NW waves per block.  LORA: the rank-r LoRA back-path of peft's c_attn (modules.py:177-186) is folded into the row's dy
-// before anything else is done with it:   dy[row][c] += keep(row, c) / (1 - p) * sum_j dz[row][j] * A[j][c]
-// (dz = d z of the LoRA-A product, A = lora_A (r, D), the mask = lora_dropout's) -- the separate K = r GEMM that used to
-// read-modify-write the whole M x D gradient (430 MB per layer at B = 8) is gone.  A sits in LDS as fp32 (r * D floats,
-// rounded to bf16 first when `lora_bf16`: the bf16 mode's contraction with bf16 operands and fp32 accumulation); the
-// per-wave reduction rows of the parameter gradients alias the same LDS once the row loop is over.
-struct LoraBack {
-  const float* dz;      // (M, r) with leading dimension lddz; bf16 when the kernel's dy is (they are columns of one matrix)
-  int64_t lddz;
-  const float* A;       // (r, D)
-  int32_t r, bf16;
+// Optional SECOND gradient stream of the same tensor: dy2 (M, D), fp32 or bf16, times an optional dropout mask -- the gradient
+// the LoRA branch of peft's c_attn returns for ITS input (lora_A's d-input GEMM, modules.py:177-186), which reaches the
+// LayerNorm output through lora_dropout's backward (modules.py:181):     dy[row][c] += keep(row, c) / (1 - p) * dy2[row][c].
+// (Round 4 first folded the rank-32 product itself into this kernel -- lora_A in LDS, one 1024-thread block per CU -- and
+// measured 370 us per launch against 148 + 129 for this kernel plus the K = 32 GEMM: the LDS image costs the occupancy a
+// bandwidth kernel lives on.  The product stays a GEMM, its read-modify-write of the M x D gradient is what went away.)
+struct LnAdd {
+  const void* dy2;
+  int64_t ld;
+  int32_t bf16, _pad;
   DropCtxN drop;
 };
 
-__device__ __forceinline__ float ln_round_bf16(float v) { return (float)(__bf16)v; }
-
 // DY16: dy is a bf16 matrix (bf16 mode: the gradient a bf16 Linear hands back for its input, train.py:68)
-template <int NCH, int NW, bool LORA, bool DY16 = false>
-__global__ __launch_bounds__(64 * NW) void layernorm_bwd_kernel(const float* __restrict__ dy, int64_t lddy,
+template <int NCH, bool ADD, bool DY16 = false>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, int64_t lddy,
                                                             const float* __restrict__ x, int64_t ldx,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ stats,
                                                             const float* __restrict__ dres, float* __restrict__ dx,
                                                             float* __restrict__ dxm, int dxm_bf16, DropCtxN odc,
-                                                            float* __restrict__ partials, int64_t M, int D, LoraBack lb) {
-  constexpr int RED = 2 * 4 * 64 * NCH;                      // floats per wave in the final reduction
-  extern __shared__ __attribute__((aligned(16))) float lds_ln[];   // max(NW * RED, r * D) floats
-  float* red = lds_ln;
+                                                            float* __restrict__ partials, int64_t M, int D, LnAdd ad) {
+  __shared__ float red[4][2 * 4 * 64 * NCH];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if constexpr (LORA) {
-    const int tot = lb.r * D;
-    for (int i = threadIdx.x; i < tot; i += 64 * NW) lds_ln[i] = lb.bf16 ? ln_round_bf16(lb.A[i]) : lb.A[i];
-    __syncthreads();
-  }
   float4 dg[NCH], db[NCH], gm[NCH];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
@@ -132,94 +122,39 @@ __global__ __launch_bounds__(64 * NW) void layernorm_bwd_kernel(const float* __r
     gm[i] = c < D ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const float invD = 1.0f / (float)D;
-  for (int64_t row = (int64_t)blockIdx.x * NW + wave; row < M; row += (int64_t)gridDim.x * NW) {
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
     const float mean = stats[2 * row], rstd = stats[2 * row + 1];
-    float4 xh[NCH], g[NCH], dv[NCH];
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = 4 * (lane + 64 * i);
-      if (c < D) {
-        if constexpr (DY16) {
-          const tecm_bf16x4 h = *reinterpret_cast<const tecm_bf16x4*>(reinterpret_cast<const __bf16*>(dy) + row * lddy + c);
-          dv[i] = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
-        } else {
-          dv[i] = *reinterpret_cast<const float4*>(dy + row * lddy + c);
-        }
-      } else {
-        dv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-    if constexpr (LORA) {
-      float dzl = 0.f;
-      if (lane < lb.r) dzl = DY16 ? (float)reinterpret_cast<const __bf16*>(lb.dz)[row * lb.lddz + lane] : lb.dz[row * lb.lddz + lane];
-      if (lb.bf16) dzl = ln_round_bf16(dzl);
-      float4 acc[NCH];
-#pragma unroll
-      for (int i = 0; i < NCH; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      // dz[row][j] is wave-uniform: v_readlane of lane j (a compile-time lane in the unrolled r = 32 form -- a run-time
-      // lane would be a ds_bpermute, an LDS operation per term, beside the three LDS reads of A's row).  The rows of A are
-      // read LJ j at a time into registers before their FMAs: one LDS round trip per group, not one per read (the straight
-      // loop compiled to read -> lgkmcnt(0) -> two packed FMAs, 96 exposed LDS latencies per row; a 1024-thread block has
-      // 128 registers per lane, which is what bounds LJ).
-      if (lb.r == 32) {
-        constexpr int LJ = 4;
-#pragma unroll 1                                        // rolled: fully unrolled the scheduler hoists every read and spills
-        for (int jb = 0; jb < 32; jb += LJ) {
-          float4 a[LJ][NCH];
-#pragma unroll
-          for (int jj = 0; jj < LJ; ++jj)
-#pragma unroll
-            for (int i = 0; i < NCH; ++i) {
-              const int c = 4 * (lane + 64 * i);
-              a[jj][i] = c < D ? *reinterpret_cast<const float4*>(lds_ln + (jb + jj) * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-          for (int jj = 0; jj < LJ; ++jj) {
-            const float sj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dzl), jb + jj));
-#pragma unroll
-            for (int i = 0; i < NCH; ++i) {
-              acc[i].x = fmaf(sj, a[jj][i].x, acc[i].x); acc[i].y = fmaf(sj, a[jj][i].y, acc[i].y);
-              acc[i].z = fmaf(sj, a[jj][i].z, acc[i].z); acc[i].w = fmaf(sj, a[jj][i].w, acc[i].w);
-            }
-          }
-        }
-      } else {
-        for (int j = 0; j < lb.r; ++j) {
-          const float sj = __shfl(dzl, j);
-          const float* Aj = lds_ln + j * D;
-#pragma unroll
-          for (int i = 0; i < NCH; ++i) {
-            const int c = 4 * (lane + 64 * i);
-            if (c < D) {
-              const float4 av = *reinterpret_cast<const float4*>(Aj + c);
-              acc[i].x = fmaf(sj, av.x, acc[i].x); acc[i].y = fmaf(sj, av.y, acc[i].y);
-              acc[i].z = fmaf(sj, av.z, acc[i].z); acc[i].w = fmaf(sj, av.w, acc[i].w);
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < NCH; ++i) {
-        const int c = 4 * (lane + 64 * i);
-        if (c < D) {
-          if (lb.drop.thresh) {
-            const uint64_t di = (uint64_t)(row * lb.drop.ld + c);
-            acc[i].x *= tecm_drop_mult(lb.drop.seed, di, lb.drop.thresh, lb.drop.inv);
-            acc[i].y *= tecm_drop_mult(lb.drop.seed, di + 1, lb.drop.thresh, lb.drop.inv);
-            acc[i].z *= tecm_drop_mult(lb.drop.seed, di + 2, lb.drop.thresh, lb.drop.inv);
-            acc[i].w *= tecm_drop_mult(lb.drop.seed, di + 3, lb.drop.thresh, lb.drop.inv);
-          }
-          dv[i].x += acc[i].x; dv[i].y += acc[i].y; dv[i].z += acc[i].z; dv[i].w += acc[i].w;
-        }
-      }
-    }
+    float4 xh[NCH], g[NCH];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = 4 * (lane + 64 * i);
       if (c < D) {
         const float4 xv = *reinterpret_cast<const float4*>(x + row * ldx + c);
-        const float4 d = dv[i];
+        float4 d;
+        if constexpr (DY16) {
+          const tecm_bf16x4 h = *reinterpret_cast<const tecm_bf16x4*>(reinterpret_cast<const __bf16*>(dy) + row * lddy + c);
+          d = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+        } else {
+          d = *reinterpret_cast<const float4*>(dy + row * lddy + c);
+        }
+        if constexpr (ADD) {
+          float4 e;
+          if (ad.bf16) {
+            const tecm_bf16x4 h = *reinterpret_cast<const tecm_bf16x4*>(reinterpret_cast<const __bf16*>(ad.dy2) + row * ad.ld + c);
+            e = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+          } else {
+            e = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(ad.dy2) + row * ad.ld + c);
+          }
+          if (ad.drop.thresh) {
+            const uint64_t di = (uint64_t)(row * ad.drop.ld + c);
+            e.x *= tecm_drop_mult(ad.drop.seed, di, ad.drop.thresh, ad.drop.inv);
+            e.y *= tecm_drop_mult(ad.drop.seed, di + 1, ad.drop.thresh, ad.drop.inv);
+            e.z *= tecm_drop_mult(ad.drop.seed, di + 2, ad.drop.thresh, ad.drop.inv);
+            e.w *= tecm_drop_mult(ad.drop.seed, di + 3, ad.drop.thresh, ad.drop.inv);
+          }
+          d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w;
+        }
         xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
         g[i] = make_float4(d.x * gm[i].x, d.y * gm[i].y, d.z * gm[i].z, d.w * gm[i].w);
         dg[i].x += d.x * xh[i].x; dg[i].y += d.y * xh[i].y; dg[i].z += d.z * xh[i].z; dg[i].w += d.w * xh[i].w;
@@ -258,23 +193,19 @@ __global__ __launch_bounds__(64 * NW) void layernorm_bwd_kernel(const float* __r
       }
     }
   }
-  // block reduction of the per-lane parameter gradients -> one partial row per block (the LDS image of A is dead)
-  if constexpr (LORA) __syncthreads();
+  // block reduction of the per-lane parameter gradients -> one partial row per block
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = 4 * (lane + 64 * i);
-    float* r0 = &red[wave * RED + c];
-    float* r1 = &red[wave * RED + 4 * 64 * NCH + c];
+    float* r0 = &red[wave][c];
+    float* r1 = &red[wave][4 * 64 * NCH + c];
     r0[0] = dg[i].x; r0[1] = dg[i].y; r0[2] = dg[i].z; r0[3] = dg[i].w;
     r1[0] = db[i].x; r1[1] = db[i].y; r1[2] = db[i].z; r1[3] = db[i].w;
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < 2 * D; c += 64 * NW) {
+  for (int c = threadIdx.x; c < 2 * D; c += 256) {
     const int src = c < D ? c : (4 * 64 * NCH + (c - D));
-    float t = red[src];                                     // waves in a fixed order: bit-reproducible
-#pragma unroll
-    for (int w = 1; w < NW; ++w) t += red[w * RED + src];
-    partials[(int64_t)blockIdx.x * 2 * D + c] = t;
+    partials[(int64_t)blockIdx.x * 2 * D + c] = (red[0][src] + red[1][src]) + (red[2][src] + red[3][src]);
   }
 }
 
@@ -608,6 +539,11 @@ __global__ __launch_bounds__((GnGeom<CPB, WPS>::NTHR)) void gn_gelu_fwd_reg(cons
 
 // Y16: y itself is bf16 (round 4; 8-byte loads: the same number of requests as the fp32 form, half the bytes -- the
 // 8-channel kernels below issue a third of the requests per lane and run slower in this direction)
+#ifdef GN_ABLATE_DGELU                                    // diagnostics (tools/build_variant.py): no transcendental in the backward
+#define GN_DGELU(v) (0.5f + 0.1f * (v))
+#else
+#define GN_DGELU(v) dgelu_erf_fast(v)
+#endif
 template <int CPB, int WPS, int GN_NPMAX, bool IO16, bool D16 = false, bool Y16 = false>
 __global__ __launch_bounds__((GnGeom<CPB, WPS>::NTHR)) void gn_gelu_bwd_reg(const void* __restrict__ dact, int dstride, int L2,
                                                        const void* __restrict__ y, const float* __restrict__ gamma,
@@ -688,7 +624,7 @@ __global__ __launch_bounds__((GnGeom<CPB, WPS>::NTHR)) void gn_gelu_bwd_reg(cons
 #define GN_ELEM(c)                                                               \
   {                                                                              \
     const float h_ = (yh[i].c - ms[s_]) * rs[s_];                                \
-    const float g_ = gd[i].c * dgelu_erf_fast(h_ * gm[s_].c + bt[s_].c);              \
+    const float g_ = gd[i].c * GN_DGELU(h_ * gm[s_].c + bt[s_].c);                    \
     if (live) { dgm[s_].c += g_ * h_; dbt[s_].c += g_; }                         \
     const float d_ = g_ * gm[s_].c;                                              \
     a1[s_] += d_;                                                                \
@@ -1168,12 +1104,10 @@ extern "C" int tecm_layernorm_fwd(const float* x, int64_t ldx, const float* gamm
 extern "C" int tecm_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                                   const float* stats, const float* dres, float* dx, void* dx_masked,
                                   int32_t masked_bf16, const TecmDrop* mask_drop, float* dgb_partials,
-                                  int32_t* num_blocks, int64_t M, int32_t D, const TecmLoraBack* lora, int32_t dy_bf16,
+                                  int32_t* num_blocks, int64_t M, int32_t D, const TecmLnAdd* add, int32_t dy_bf16,
                                   void* stream) {
   TECM_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAXCH, TECM_E_ARG, "tecm_layernorm_bwd: bad M/D");
-  const bool has_lora = lora != nullptr && lora->dz != nullptr;
-  // the LoRA variant keeps lora_A (r x D floats) in LDS: one 1024-thread block per CU, 16 rows in flight per block
-  const int nb = has_lora ? (int)((M + 15) / 16 < 256 ? (M + 15) / 16 : 256) : ln_blocks(M);
+  const int nb = ln_blocks(M);
   if (num_blocks) *num_blocks = nb;
   if (dx == nullptr) return TECM_OK;   // query mode
   TECM_REQUIRE(dy && x && gamma && stats && dgb_partials, TECM_E_ARG, "tecm_layernorm_bwd: null pointer");
@@ -1184,50 +1118,27 @@ extern "C" int tecm_layernorm_bwd(const float* dy, int64_t lddy, const float* x,
   const DropCtxN odc = make_dropn(mask_drop);
   const int nch = (D + 255) / 256;
   hipStream_t st = (hipStream_t)stream;
-  LoraBack lb{};
-  if (has_lora) {
-    TECM_REQUIRE(lora->A && lora->r > 0 && lora->r <= 64 && lora->ld_dz >= lora->r, TECM_E_ARG,
-                 "tecm_layernorm_bwd: the LoRA back-path needs lora_A and 1 <= r <= 64");
-    TECM_REQUIRE(tecm_aligned(lora->A, 16), TECM_E_ALIGN, "tecm_layernorm_bwd: lora_A must be 16-byte aligned");
-    lb.dz = lora->dz; lb.lddz = lora->ld_dz; lb.A = lora->A; lb.r = lora->r; lb.bf16 = lora->bf16_operands;
-    lb.drop = make_dropn(&lora->drop);
-    constexpr int NW = 16;
-    const size_t red = (size_t)NW * 2 * 4 * 64 * nch * sizeof(float), img = (size_t)lora->r * D * sizeof(float);
-    const size_t lds = red > img ? red : img;
-    TECM_REQUIRE(lds <= 160 * 1024, TECM_E_LDS, "tecm_layernorm_bwd: lora_A (%d x %d) does not fit the LDS", lora->r, D);
-#define LN_BWD_L(NCH)                                                                                                   \
-  {                                                                                                                     \
-    const void* fn = dy_bf16 ? reinterpret_cast<const void*>(&layernorm_bwd_kernel<NCH, NW, true, true>)                \
-                             : reinterpret_cast<const void*>(&layernorm_bwd_kernel<NCH, NW, true>);                     \
-    TECM_REQUIRE(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,          \
-                 TECM_E_LAUNCH, "tecm_layernorm_bwd: hipFuncSetAttribute failed");                                       \
-    if (dy_bf16)                                                                                                        \
-      hipLaunchKernelGGL((layernorm_bwd_kernel<NCH, NW, true, true>), dim3(nb), dim3(64 * NW), lds, st, dy, lddy, x, ldx,   \
-                         gamma, stats, dres, dx, static_cast<float*>(dx_masked), (int)masked_bf16, odc, dgb_partials, M, D, lb); \
-    else                                                                                                                \
-      hipLaunchKernelGGL((layernorm_bwd_kernel<NCH, NW, true>), dim3(nb), dim3(64 * NW), lds, st, dy, lddy, x, ldx, gamma, \
-                         stats, dres, dx, static_cast<float*>(dx_masked), (int)masked_bf16, odc, dgb_partials, M, D, lb); \
+  LnAdd ad{};
+  const bool has_add = add != nullptr && add->dy2 != nullptr;
+  if (has_add) {
+    TECM_REQUIRE(add->ld % 4 == 0 && add->ld >= D && tecm_aligned(add->dy2, add->bf16 ? 8 : 16), TECM_E_ALIGN,
+                 "tecm_layernorm_bwd: dy2 must be 16-byte (fp32) / 8-byte (bf16) friendly");
+    ad.dy2 = add->dy2; ad.ld = add->ld; ad.bf16 = add->bf16; ad.drop = make_dropn(&add->drop);
   }
-    switch (nch) {
-      case 1: LN_BWD_L(1); break;
-      case 2: LN_BWD_L(2); break;
-      case 3: LN_BWD_L(3); break;
-      default: LN_BWD_L(4); break;
-    }
-#undef LN_BWD_L
-    TECM_CHECK_LAUNCH("tecm_layernorm_bwd/lora");
-    return TECM_OK;
-  }
-#define LN_BWD(NCH)                                                                                                    \
-  do {                                                                                                                 \
-    if (dy_bf16)                                                                                                       \
-      hipLaunchKernelGGL((layernorm_bwd_kernel<NCH, 4, false, true>), dim3(nb), dim3(256),                              \
-                         (size_t)4 * 2 * 4 * 64 * NCH * sizeof(float), st, dy, lddy, x, ldx, gamma, stats, dres, dx,    \
-                         static_cast<float*>(dx_masked), (int)masked_bf16, odc, dgb_partials, M, D, lb);               \
-    else                                                                                                               \
-      hipLaunchKernelGGL((layernorm_bwd_kernel<NCH, 4, false>), dim3(nb), dim3(256),                                    \
-                         (size_t)4 * 2 * 4 * 64 * NCH * sizeof(float), st, dy, lddy, x, ldx, gamma, stats, dres, dx,    \
-                         static_cast<float*>(dx_masked), (int)masked_bf16, odc, dgb_partials, M, D, lb);               \
+#define LN_BWD(NCH)                                                                                                       \
+  do {                                                                                                                    \
+    if (has_add && dy_bf16)                                                                                               \
+      hipLaunchKernelGGL((layernorm_bwd_kernel<NCH, true, true>), dim3(nb), dim3(256), 0, st, dy, lddy, x, ldx, gamma, stats, \
+                         dres, dx, static_cast<float*>(dx_masked), (int)masked_bf16, odc, dgb_partials, M, D, ad);        \
+    else if (has_add)                                                                                                     \
+      hipLaunchKernelGGL((layernorm_bwd_kernel<NCH, true, false>), dim3(nb), dim3(256), 0, st, dy, lddy, x, ldx, gamma, stats, \
+                         dres, dx, static_cast<float*>(dx_masked), (int)masked_bf16, odc, dgb_partials, M, D, ad);        \
+    else if (dy_bf16)                                                                                                     \
+      hipLaunchKernelGGL((layernorm_bwd_kernel<NCH, false, true>), dim3(nb), dim3(256), 0, st, dy, lddy, x, ldx, gamma, stats, \
+                         dres, dx, static_cast<float*>(dx_masked), (int)masked_bf16, odc, dgb_partials, M, D, ad);        \
+    else                                                                                                                  \
+      hipLaunchKernelGGL((layernorm_bwd_kernel<NCH, false, false>), dim3(nb), dim3(256), 0, st, dy, lddy, x, ldx, gamma, stats, \
+                         dres, dx, static_cast<float*>(dx_masked), (int)masked_bf16, odc, dgb_partials, M, D, ad);        \
   } while (0)
   switch (nch) {
     case 1: LN_BWD(1); break;

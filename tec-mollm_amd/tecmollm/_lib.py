@@ -76,9 +76,8 @@ class TecmSpatialGrads(C.Structure):
     ]
 
 
-class TecmLoraBack(C.Structure):
-    _fields_ = [("dz", c_f32p), ("ld_dz", C.c_int64), ("A", c_f32p), ("r", C.c_int32), ("bf16_operands", C.c_int32),
-                ("drop", TecmDrop)]
+class TecmLnAdd(C.Structure):
+    _fields_ = [("dy2", C.c_void_p), ("ld", C.c_int64), ("bf16", C.c_int32), ("_pad", C.c_int32), ("drop", TecmDrop)]
 
 
 class TecmAdamW(C.Structure):
@@ -156,7 +155,7 @@ EXPORTS = {
                                      c_f32p, C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
     "tecm_layernorm_bwd": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p,
                                      C.c_int32, C.POINTER(TecmDrop), c_f32p, C.POINTER(C.c_int32), C.c_int64, C.c_int32,
-                                     C.POINTER(TecmLoraBack), C.c_int32, C.c_void_p]),
+                                     C.POINTER(TecmLnAdd), C.c_int32, C.c_void_p]),
     "tecm_attention_fwd": (C.c_int, [c_f32p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                      C.c_int32, C.POINTER(TecmDrop), C.c_void_p]),
     "tecm_cast_bf16": (C.c_int, [c_f32p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),

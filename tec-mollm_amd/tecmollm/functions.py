@@ -737,15 +737,18 @@ class GPT2StackFn(torch.autograd.Function):
             else:
                 gemm(LORA_R, D, M, du, KE, u, KE, dlA, D, a_layout=A_KM, b_layout=B_KN, a_off=D, b_drop=lspec,
                      split_k=pick_split_k(LORA_R, D, M, prec=plan.bf16), bf16=plan.bf16)
-            # LoRA path back to LN1's output, du[:, :D] += mask * (dz A): folded into the LayerNorm backward's read of du
-            # (it used to be a K = 32 GEMM that read and re-wrote the whole M x 768 gradient)
+            # LoRA path back to LN1's output: the branch's input gradient dz A (lora_A's d-input GEMM, K = 32: a bf16 tensor in
+            # bf16 mode, as under autocast) is a SECOND stream the LayerNorm backward adds through lora_dropout's mask -- it
+            # used to be accumulated into du by that GEMM, a read-modify-write of the whole M x 768 gradient
+            dzA = torch.empty(M, D, device=dh.device, dtype=torch.bfloat16 if (b16 and GRAD16) else torch.float32)
+            gemm(M, D, LORA_R, du, KE, lA, D, dzA, D, b_layout=B_KN, a_off=D, bf16=plan.bf16)
             dhn = _empty(M, D, like=dh)
             sp = plan.spec(site_res2(i - 1), D) if i > 0 else None
             dhm = masked_buf(sp, params[(i - 1) * GPT2StackFn.PER_LAYER + 12]) if sp is not None else dhn
             dg1, db1 = ops.layernorm_bwd(du, KE, h, D, ln1w, st1, dh2, dhn, M, D,
                                          dx_masked=dhm if sp is not None else None, mask_drop=sp,
                                          need_dgb=nig[pb + 0] or nig[pb + 1],
-                                         lora=(du, KE, D, lA.detach().contiguous(), lspec, b16))
+                                         add=(dzA, D, lspec))
             dh = dhn
             base = i * GPT2StackFn.PER_LAYER
             pgrads[base + 0], pgrads[base + 1] = dg1, db1

@@ -295,46 +295,42 @@ def layernorm_fwd(x: torch.Tensor, ldx: int, gamma: torch.Tensor, beta: torch.Te
                                    stats.data_ptr(), M, D, eps, stream_ptr()), "tecm_layernorm_fwd")
 
 
-def _lora_back(lora) -> Optional["_lib.TecmLoraBack"]:
-    """lora = (du, ld, col_off, lora_A (r, D), drop spec or None, bf16_operands): dz = du[:, col_off:col_off + r]."""
-    if lora is None:
+def _ln_add(add) -> Optional["_lib.TecmLnAdd"]:
+    """add = (dy2 (M, D) fp32 / bf16, ld, drop spec or None)."""
+    if add is None:
         return None
-    du, ld, off, A, dspec, b16 = lora
-    if A.dtype != torch.float32 or not A.is_contiguous() or du.dtype not in (torch.float32, torch.bfloat16):
-        raise _lib.TecmError("layernorm_bwd: the LoRA back-path takes fp32 / bf16 dz and a contiguous fp32 lora_A")
-    return _lib.TecmLoraBack(dz=_off(du, off), ld_dz=ld, A=A.data_ptr(), r=A.shape[0], bf16_operands=1 if b16 else 0,
-                             drop=dspec if dspec is not None else NO_DROP)
+    dy2, ld, dspec = add
+    if dy2.dtype not in (torch.float32, torch.bfloat16):
+        raise _lib.TecmError("layernorm_bwd: dy2 is fp32 or bf16")
+    return _lib.TecmLnAdd(dy2=dy2.data_ptr(), ld=ld, bf16=1 if dy2.dtype == torch.bfloat16 else 0,
+                          drop=dspec if dspec is not None else NO_DROP)
 
 
-def layernorm_bwd_blocks(M: int, D: int, lora=None) -> int:
+def layernorm_bwd_blocks(M: int, D: int) -> int:
     nb = C.c_int32(0)
-    lb = _lora_back(lora)
     check(lib().tecm_layernorm_bwd(None, 0, None, 0, None, None, None, None, None, 0, None, None, C.byref(nb), M, D,
-                                   C.byref(lb) if lb is not None else None, 0, None), "tecm_layernorm_bwd(query)")
+                                   None, 0, None), "tecm_layernorm_bwd(query)")
     return nb.value
 
 
 def layernorm_bwd(dy: torch.Tensor, lddy: int, x: torch.Tensor, ldx: int, gamma: torch.Tensor, stats: torch.Tensor,
                   dres: Optional[torch.Tensor], dx: torch.Tensor, M: int, D: int,
                   dx_masked: Optional[torch.Tensor] = None,
-                  mask_drop: Optional[TecmDrop] = None, need_dgb: bool = True, lora=None):
+                  mask_drop: Optional[TecmDrop] = None, need_dgb: bool = True, add=None):
     """dx = dres + LN'(dy); optional dx_masked = dropout(dx, mask_drop) -- fp32, or bf16 when its only reader is a bf16
-    GEMM.  lora = (du, ld, col_off, lora_A, drop, bf16_operands): the rank-r LoRA back-path
-    dy += dropmask * (du[:, col_off:col_off + r] @ lora_A) is folded into the row before the LayerNorm backward (no separate
-    K = r GEMM over the M x D gradient).  Returns (dgamma, dbeta), or (None, None) when need_dgb is False (frozen
-    LayerNorm: the per-block partials are not reduced)."""
+    GEMM.  dy: fp32 or bf16.  add = (dy2, ld, drop): a second gradient stream of the same tensor, dy += dropmask * dy2 before
+    the LayerNorm backward (the LoRA branch's input gradient through lora_dropout's backward).  Returns (dgamma, dbeta), or
+    (None, None) when need_dgb is False (frozen LayerNorm: the per-block partials are not reduced)."""
     m16 = 1 if (dx_masked is not None and dx_masked.dtype == torch.bfloat16) else 0
-    lb = _lora_back(lora)
+    ad = _ln_add(add)
     dy16 = 1 if dy.dtype == torch.bfloat16 else 0        # bf16 mode: the gradient a bf16 GEMM returned for its input
-    if lora is not None and lora[0].dtype != dy.dtype:
-        raise _lib.TecmError("layernorm_bwd: dz and dy are columns of one matrix: one dtype")
-    nb = layernorm_bwd_blocks(M, D, lora)
+    nb = layernorm_bwd_blocks(M, D)
     partials = torch.empty(nb, 2 * D, device=dx.device, dtype=torch.float32)
     nbc = C.c_int32(0)
     od = mask_drop if mask_drop is not None else NO_DROP
     check(lib().tecm_layernorm_bwd(dy.data_ptr(), lddy, x.data_ptr(), ldx, gamma.data_ptr(), stats.data_ptr(),
                                    ptr(dres), dx.data_ptr(), ptr(dx_masked), m16, C.byref(od), partials.data_ptr(),
-                                   C.byref(nbc), M, D, C.byref(lb) if lb is not None else None, dy16, stream_ptr()),
+                                   C.byref(nbc), M, D, C.byref(ad) if ad is not None else None, dy16, stream_ptr()),
           "tecm_layernorm_bwd")
     if not need_dgb:
         return None, None

@@ -360,8 +360,10 @@ def test_groupnorm_gelu_bf16_outputs(dev, Bn, L, N, Cout, stride):
     assert torch.equal(dy16, dy32.bfloat16())
     for a_, b_ in zip(r16, r32):                          # block partials are combined with LDS atomics: order varies
         assert _rel(a_, b_) < 1e-5
+    # (a bf16 y used to be refused; round 4 serves it with its own kernels: tests/test_gpu_ops.py,
+    #  test_groupnorm_gelu_all_bf16_kernels)
     with pytest.raises(Exception):
-        ops.groupnorm_gelu_fwd(y.bfloat16(), g, b, act16, st16, Bn, L, N, Cout)
+        ops.groupnorm_gelu_fwd(y.bfloat16(), g, b, act32, st16, Bn, L, N, Cout)     # a bf16 y with an fp32 activation
 
 
 @pytest.mark.parametrize("f32", [False, True], ids=["bf16", "fp32"])

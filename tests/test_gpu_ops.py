@@ -250,48 +250,46 @@ def test_layernorm_fwd_dropped_bf16_output_is_the_lora_branch_input(dev, M):
     assert torch.equal(y16b[:, :D], y16[:, :D]) and torch.equal(y16db, y16d)
 
 
-@pytest.mark.parametrize("M,bf16", [(1000, False), (1000, True), (37, False), (4099, True)])
-def test_layernorm_bwd_folds_the_lora_back_path(dev, M, bf16):
-    """tecm_layernorm_bwd with TecmLoraBack: dy[:, :D] += mask * (dz @ lora_A) before the LayerNorm backward (peft Linear
-    on c_attn, modules.py:177-186) equals the separate K = 32 accumulate GEMM followed by the plain kernel -- in exact
-    fp32, and in the bf16 mode's arithmetic (dz and lora_A rounded to bf16, fp32 accumulation)."""
+@pytest.mark.parametrize("M,dt", [(1000, torch.float32), (1000, torch.bfloat16), (37, torch.float32), (4099, torch.bfloat16)])
+def test_layernorm_bwd_adds_a_masked_second_gradient_stream(dev, M, dt):
+    """tecm_layernorm_bwd with TecmLnAdd: dy += dropmask * dy2 before the LayerNorm backward -- the gradient peft's LoRA
+    branch returns for its input (lora_A's d-input GEMM, modules.py:177-186) reaching LN1's output through lora_dropout's
+    backward (modules.py:181) -- with dy and dy2 fp32 or bf16, against fp64 from first principles (the mask from the NumPy
+    mirror of the device hash), and bit for bit against the plain kernel fed the pre-added gradient."""
     from tecmollm import ops, rng
-    D, R, KE = 768, 32, 800
+    D, KE = 768, 800
     x = _rand(M, D, dev=dev, seed=1)
     g = 1 + 0.1 * _rand(D, dev=dev, seed=2)
     st = torch.empty(M, 2, device=dev)
     ops.layernorm_fwd(x, D, g, torch.zeros(D, device=dev), torch.empty(M, D, device=dev), D, st, M, D)
-    du = _rand(M, KE, dev=dev, seed=4)
-    lA = _rand(R, D, dev=dev, seed=5, scale=0.05)
+    du = _rand(M, KE, dev=dev, seed=4).to(dt)
+    dy2 = _rand(M, D, dev=dev, seed=5, scale=0.3).to(dt)
     dres = _rand(M, D, dev=dev, seed=6)
     spec = ops.drop(0.1, 4321, KE)
-    # reference composition: the GEMM the fused form replaces, then the plain LayerNorm backward
-    du_ref = du.clone()
-    ops.gemm(M, D, R, du_ref, KE, lA, D, du_ref, KE, b_layout=ops.B_KN, a_off=D, out_drop=spec, accumulate=True, bf16=bf16)
-    dx_ref, dxm_ref = torch.empty(M, D, device=dev), torch.empty(M, D, device=dev)
-    dg_ref, db_ref = ops.layernorm_bwd(du_ref, KE, x, D, g, st, dres, dx_ref, M, D, dx_masked=dxm_ref, mask_drop=ops.drop(0.1, 7, D))
+    idx = (np.arange(M, dtype=np.uint64)[:, None] * np.uint64(KE) + np.arange(D, dtype=np.uint64)[None, :])
+    mult = torch.from_numpy(rng.keep_mult(4321, idx, 0.1)).to(dev)
     dx, dxm = torch.empty(M, D, device=dev), torch.empty(M, D, device=dev)
     dg, db = ops.layernorm_bwd(du, KE, x, D, g, st, dres, dx, M, D, dx_masked=dxm, mask_drop=ops.drop(0.1, 7, D),
-                               lora=(du, KE, D, lA, spec, bf16))
-    tol = 2e-5
-    assert _rel(dx, dx_ref) < tol and _rel(dxm, dxm_ref) < tol and _rel(dg, dg_ref) < tol and _rel(db, db_ref) < tol
-    # and against fp64 from first principles (the mask from the NumPy mirror of the device hash)
-    idx = (np.arange(M, dtype=np.uint64)[:, None] * np.uint64(KE) + np.arange(D, dtype=np.uint64)[None, :])
-    mult = torch.from_numpy(rng.keep_mult(4321, idx, 0.1)).to(dev).double()
-    dz, A = du[:, D:].double(), lA.double()
-    if bf16:
-        dz, A = du[:, D:].bfloat16().double(), lA.bfloat16().double()
-    dy_tot = du[:, :D].double() + mult * (dz @ A)
+                               add=(dy2, D, spec))
+    pre = du[:, :D].float() + mult * dy2.float()                       # what the kernel forms in registers (fp32)
+    dx_r, dxm_r = torch.empty(M, D, device=dev), torch.empty(M, D, device=dev)
+    dg_r, db_r = ops.layernorm_bwd(pre.contiguous(), D, x, D, g, st, dres, dx_r, M, D, dx_masked=dxm_r, mask_drop=ops.drop(0.1, 7, D))
+    assert torch.equal(dx, dx_r) and torch.equal(dxm, dxm_r) and torch.equal(dg, dg_r) and torch.equal(db, db_r)
+    dy_tot = du[:, :D].double() + mult.double() * dy2.double()
     xd = x.double().requires_grad_(True)
     gd = g.double().requires_grad_(True)
     ref = torch.nn.functional.layer_norm(xd, (D,), gd, None, 1e-5)
     gx, gg = torch.autograd.grad(ref, (xd, gd), dy_tot)
     assert _rel(dx, gx + dres.double()) < TOL and _rel(dg, gg) < TOL and _rel(db, dy_tot.sum(0)) < TOL
-    # eval mode: no mask
+    # eval mode: no mask; and a bf16 dy alone (the LN2 / ln_f form of the bf16 mode)
     dx0 = torch.empty(M, D, device=dev)
-    ops.layernorm_bwd(du, KE, x, D, g, st, None, dx0, M, D, lora=(du, KE, D, lA, None, bf16))
-    gx0, = torch.autograd.grad(torch.nn.functional.layer_norm(xd, (D,), gd, None, 1e-5), (xd,), du[:, :D].double() + dz @ A)
+    ops.layernorm_bwd(du, KE, x, D, g, st, None, dx0, M, D, add=(dy2, D, None))
+    gx0, = torch.autograd.grad(torch.nn.functional.layer_norm(xd, (D,), gd, None, 1e-5), (xd,), du[:, :D].double() + dy2.double())
     assert _rel(dx0, gx0) < TOL
+    dx1 = torch.empty(M, D, device=dev)
+    ops.layernorm_bwd(du, KE, x, D, g, st, None, dx1, M, D)
+    gx1, = torch.autograd.grad(torch.nn.functional.layer_norm(xd, (D,), gd, None, 1e-5), (xd,), du[:, :D].double())
+    assert _rel(dx1, gx1) < TOL
 
 
 # register-resident kernels: 4 waves/sequence (2304 quads), 8 waves (4608 quads: L_in = 96), forward-only 2 waves

@@ -79,6 +79,11 @@ class Multi_Scale_Conv_Block(nn.Module):
         args = []
         for seq in self.convs:
             args += [seq[0].weight, seq[0].bias, seq[1].weight, seq[1].bias]
+        if inp16 is None and int(bf16) == ops_.PREC_BF16 and inp.shape[-1] % 8 == 0 and os.environ.get("TECM_XS16", "1")[:1] != "0":
+            # a block called on its own in bf16 mode (the embedder hands its blocks the bf16 copy): round the input once here,
+            # so that the sequence-tile kernels -- and with them the bf16 storage of y -- serve this call as they serve the model
+            inp16 = torch.empty(inp.shape, device=inp.device, dtype=torch.bfloat16)
+            ops_.cast_bf16(inp.detach(), inp.shape[-1], inp16, inp.shape[-1], inp.numel() // inp.shape[-1], inp.shape[-1])
         return F_.ConvBlockFn.apply(inp, inp16, cin, self.stride, need_dinp, bf16, *args, self.final_conv.weight,
                                     self.final_conv.bias)
 

@@ -180,7 +180,14 @@ def test_bf16_full_step_against_bf16_emulating_oracle(dev, grid, thr, B, train):
     cfg = R.default_config(L_in=48, L_out=12, num_nodes=grid[0] * grid[1])
     res = compare_forward_backward(cfg, B=B, grid=grid, threshold_km=thr, gat_graphs="per_timestep", seed=31,
                                    train=train, precision="bf16")
-    assert_parity(res)
+    # N = 20 is a 40-sequence / 120-token problem: a weight gradient there sums 120 rows, and the rounding-flip noise of the
+    # bf16 tensors in front of it does not average out.  Round 4 stores five more tensors as bf16 (the conv output, the
+    # gradients a bf16 Linear / Conv1d returns for its input); tools/diag_n20.py over five seeds in train mode: worst
+    # element 1.02-1.33x the standard bar (lora_B of one of the layers four times -- the one trainable tensor that
+    # contracts dqkv over only 120 rows -- conv weights 1.0-1.1x, the worst tensor and its runner-up change with the seed),
+    # max-norm 1.3e-2 ... 2.0e-2.  The 40-sequence case gets 1.5x the element-wise bar (as L_in = 336 below); N = 135 and
+    # N = 2911 keep the standard one, and the self-calibrated test at the end of this file is the noise-independent check.
+    assert_parity(res, elem_scale={"*": 1.5} if grid == (4, 5) else None)
     assert res["n_grads"] == sum(R.is_trainable(k) for k in R.init_params(cfg, 0))
 
 

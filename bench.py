@@ -348,7 +348,7 @@ def roofline_of(agg: dict, step_ms: float, steps: int, args, precision: str, bat
     gf = ALG_GFLOP_PER_SAMPLE.get(L_in) if getattr(args, "llm_layers", 3) == 3 else None
     step = None
     if gf is not None:
-        tf = gf * batch / step_ms / 1e3
+        tf = gf * batch / step_ms                      # GFLOP / ms = TFLOP/s
         step_peak = BF16_MFMA_PEAK_TFLOPS if precision in ("bf16", "bf16x3", "bf16x6") else F32_MFMA_PEAK_TFLOPS
         step = {"algorithmic_tflops": round(tf, 1), "peak": step_peak, "frac_of_peak": round(tf / step_peak, 4),
                 "gflop_per_sample": gf, "note": "SURVEY 8d algorithmic flops (fwd + bwd, no recompute) x samples / step time"}
@@ -359,7 +359,7 @@ def roofline_of(agg: dict, step_ms: float, steps: int, args, precision: str, bat
             "all_gemm_share_of_step": round(all_ms / step_ms, 4),
             "timing": f"events on the launch stream around every GEMM in a separate pass of {steps} steps after the timed "
                       "region (the timed steps carry no event bracketing)",
-            "step": step, "shapes": shapes[:14], "non_gemm": non_gemm_block(args, precision)}
+            "step": step, "shapes": shapes[:24], "non_gemm": non_gemm_block(args, precision)}
 
 
 def shape_pass(ts, batch_fn, ei, ew, steps: int = 3):

@@ -33,7 +33,7 @@ extern "C" {
 #define TECM_E_LAUNCH (-3)     /* hipGetLastError() != hipSuccess after the launch       */
 #define TECM_E_LDS (-4)        /* problem does not fit the 160 KiB LDS budget            */
 
-#define TECM_ABI_VERSION 15
+#define TECM_ABI_VERSION 16
 int tecm_abi_version(void);
 /* Human-readable text for the last error on this thread (host pointer, never NULL). */
 const char* tecm_last_error(void);
@@ -122,6 +122,14 @@ int tecm_gemm_bf16x3(const TecmGemm* g, void* stream);
  * hi.mid + mid.hi + hi.hi: only terms below 2^-24 of a product are dropped -- fp32-grade accuracy at 6/16 of the exact
  * matrix time.  Same scope and return convention as tecm_gemm_bf16x3. */
 int tecm_gemm_bf16x6(const TecmGemm* g, void* stream);
+
+/* Weight gradients in bf16 mode (a_layout KM x b_layout KN, both operands bf16 tensors, split_k >= 2: the backward of
+ * every trainable nn.Linear / Conv1d(k=1) / LoRA matrix of the path, reference train.py:85) are served inside
+ * tecm_gemm_bf16 by a natural-orientation LDS-DMA kernel (csrc/gemm_bf16_tn.hip) for the output shapes it is built for.
+ * This returns the split count that kernel wants for an M x N output contracted over K rows (one or two rounds of
+ * blocks on 256 CUs, slabs kept under a tenth of the operand bytes), or 0 when the shape is not served -- the caller
+ * sizes split_k / the workspace with it; any split_k >= 2 is accepted.  Pure host function. */
+int32_t tecm_gemm_tn_splits(int64_t M, int64_t N, int64_t K);
 
 /* ------------------------------------------------------------------ stage a-1..a-3 (fused)
  * SpatioTemporalEmbedding.forward (modules.py:230-266) + GATv2Conv (modules.py:329-336,:356)

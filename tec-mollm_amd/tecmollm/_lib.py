@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TECM_LIB", os.path.join(_HERE, "libtecmollm_hip.so"))   # override for experiments
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 c_f32p = C.c_void_p
 
@@ -184,6 +184,7 @@ EXPORTS = {
     "tecm_conv_dx_pack_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "tecm_conv_dx_f32": (C.c_int, [C.POINTER(TecmConvDx), C.c_void_p]),
     "tecm_conv_fwd_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "tecm_gemm_tn_splits": (C.c_int32, [C.c_int64, C.c_int64, C.c_int64]),
     "tecm_conv_dx_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "tecm_transpose_scale": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_float,
                                        C.c_void_p]),

@@ -728,7 +728,7 @@ class GPT2StackFn(torch.autograd.Function):
             lspec = plan.spec(site_lora(i), KE)
             dlB = _empty(F3, LORA_R, like=dh)
             gemm(F3, LORA_R, M, dqkv, F3, u, KE, dlB, LORA_R, a_layout=A_KM, b_layout=B_KN, b_off=D,
-                 alpha=LORA_SCALE, split_k=pick_split_k(F3, LORA_R, M), bf16=plan.bf16)
+                 alpha=LORA_SCALE, split_k=pick_split_k(F3, LORA_R, M, prec=plan.bf16), bf16=plan.bf16)
             dlA = _empty(LORA_R, D, like=dh)
             if u.dtype == torch.bfloat16:                     # bf16 mode: drop(LN1(h)) was stored as bf16 by the forward
                 b_in, ldb_in = (ud, D) if ud.numel() else (u, KE)

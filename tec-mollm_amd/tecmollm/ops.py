@@ -215,6 +215,11 @@ def _kernel_name(g: TecmGemm, use16: bool = False) -> str:
             if can16 and want16:
                 return "gemm_bf16_dma5_kernel"
             return "gemm_bf16_dma4_kernel" if ring else ("gemm_bf16_dma3_kernel" if sel == "3" else "gemm_bf16_dma_kernel")
+        # mirrors tecm_gemm16_tn_try (csrc/gemm_bf16_tn.hip): weight gradients from bf16 tensors in their natural orientation
+        if (both16 and g.a_layout == A_KM and g.b_layout == B_KN and g.split_k >= 2 and not g.a_win.enabled
+                and (not g.b_win.enabled or g.b_win.pad == 0) and os.environ.get("TECM_BF16_TN", "")[:1] != "0"
+                and lib().tecm_gemm_tn_splits(g.M, g.N, g.K) > 0):
+            return "gemm_bf16_tn_kernel"
         return f"gemm_bf16_kernel<{g.a_layout},{g.b_layout},{win16},{drp16}>"
     av = _vec(g.A, g.lda, g.a_win, g.a_layout == A_MK, g.K)
     bv = _vec(g.B, g.ldb, g.b_win, g.b_layout == B_NK, g.K)
@@ -268,6 +273,10 @@ def pick_split_k(Mo: int, No: int, K: int, target_blocks: int = 512, min_chunk: 
     split costs one slab of partial sums that the reducer has to read back.  The fp32 kernel has 128 x 128 tiles and
     two blocks per CU; the bf16 kernel (prec = PREC_BF16 and at least 64 output columns) 256 x 128 tiles and ONE block
     per CU, so its grid should be one round of at most 256 blocks, not 270."""
+    if int(prec) == PREC_BF16:
+        tn = lib().tecm_gemm_tn_splits(Mo, No, K)      # the natural-orientation kernel's own choice for shapes it serves
+        if tn >= 2:
+            return int(tn)
     if int(prec) == PREC_BF16 and No >= BF16_MIN_N:
         tiles = ((Mo + 255) // 256) * ((No + 127) // 128)
         s = max(1, 256 // max(tiles, 1))

@@ -494,3 +494,60 @@ def test_conv_fwd_sequence_tile_kernel(dev, Bn, Lc, N, cin, ld_in, Cout, f32):
         y16 = torch.full((Bn, Lc, N, CT), float("nan"), device=dev, dtype=torch.bfloat16)
         ops.conv_fwd(xd, wd[0], wd[1], wd[2], bias, y16, Bn, Lc, N, Cout, cin, ld_in)
         assert torch.equal(y16, y.bfloat16())
+
+
+# ------------------------------------------------------------------ natural-orientation weight-gradient kernel (round 4)
+_TN_SHAPES = [  # Mo, No, K rows (B, Lout, N), window of the B operand (Lin, stride, taps, Cw) or None, alpha
+    (576, 2304, (3, 1, 1471), (3, 3, 3, 768), 1.0),        # head W1: the view(S, P * 768) of the time-major hidden state
+    (768, 512, (2, 3, 1013), (12, 4, 4, 128), 1.0),        # patch projection: 'b (p l) d -> b p (l d)'
+    (64, 192, (2, 24, 211), None, 1.0),                    # first 1x1 conv (compact activations)
+    (128, 384, (1, 12, 701), None, 1.0),                   # second 1x1 conv
+    (2304, 32, (1, 3, 1900), None, 2.0),                   # lora_B (the 32 z columns of the 800-wide row buffer)
+    (32, 768, (1, 3, 1900), None, 1.0),                    # lora_A (dz = columns 768.. of the 800-wide gradient buffer)
+    (576, 2304, (1, 1, 4096), None, 1.0),                  # K a multiple of every stage / split size
+]
+
+
+@pytest.mark.parametrize("Mo,No,rows,bwin,alpha", _TN_SHAPES, ids=[f"{s[0]}x{s[1]}" + ("w" if s[3] else "") + f"_{i}"
+                                                                   for i, s in enumerate(_TN_SHAPES)])
+def test_bf16_weight_gradient_natural_orientation_kernel(dev, Mo, No, rows, bwin, alpha, monkeypatch):
+    """csrc/gemm_bf16_tn.hip against fp64 on the bf16 values and against the register-transposing kernel it replaces
+    (TECM_BF16_TN=0): same products, another summation order.  K has a ragged tail (rows % 32 != 0) in most cases, split
+    counts as the library picks them AND a count that leaves the last split short."""
+    from tecmollm import ops, _lib
+    Bq, Lout, N = rows
+    K = Bq * Lout * N
+    lda = Mo if Mo != 32 else 800                           # lora_A reads dz out of the [d LN1-out | dz] buffer
+    A = _rand(K, lda, dev=dev, seed=11).bfloat16()
+    a_off = lda - Mo
+    if bwin:
+        Lin, stride, taps, Cw = bwin
+        src = _rand(Bq, Lin, N, Cw, dev=dev, seed=12).bfloat16()
+        w = ops.win(N, Lin, Lout, stride, taps, Cw, 0)
+        # logical B[(b, to, n)][tap * Cw + c] = src[b, to * stride + tap, n, c]
+        idx = (torch.arange(Lout, device=dev)[:, None] * stride + torch.arange(taps, device=dev)[None, :])   # (Lout, taps)
+        Bl = src[:, idx]                                     # (Bq, Lout, taps, N, Cw)
+        Bl = Bl.permute(0, 1, 3, 2, 4).reshape(K, taps * Cw)
+        Bt, ldb, b_off = src, Cw, 0
+    else:
+        ldb = No if No != 32 else 800
+        Bt = _rand(K, ldb, dev=dev, seed=12).bfloat16()
+        b_off = ldb - No
+        Bl = Bt[:, b_off:]
+        w = None
+    ref = alpha * (A[:, a_off:].double().t() @ Bl.double())
+    want = _lib.lib().tecm_gemm_tn_splits(Mo, No, K)
+    assert want >= 2 and ops.pick_split_k(Mo, No, K, prec=ops.PREC_BF16) == want
+    outs = {}
+    for tn, split in (("1", want), ("1", 3), ("0", want)):
+        monkeypatch.setenv("TECM_BF16_TN", tn)
+        C = torch.full((Mo, No), float("nan"), device=dev)
+        rec = ops.enable_gemm_timing(detail=True)
+        ops.gemm(Mo, No, K, A, lda, Bt, ldb, C, No, a_layout=ops.A_KM, b_layout=ops.B_KN, a_off=a_off, b_off=b_off, b_win=w,
+                 alpha=alpha, split_k=split, bf16=True)
+        agg = ops.summarize_gemm_timing(rec)
+        ops.disable_gemm_timing()
+        assert len(agg) == 1 and all(("gemm_bf16_tn_kernel" in k) == (tn == "1") for k in agg), agg.keys()
+        assert _rel(C, ref) < TOL, (tn, split)
+        outs[(tn, split)] = C
+    assert _rel(outs[("1", want)], outs[("0", want)]) < 1e-5

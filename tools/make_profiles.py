@@ -71,6 +71,8 @@ def main():
 
     # ---- kernel statistics
     ks = kernels(f"{d}/stats/p_results.db")
+    if "adamw_kernel" in ks:             # one optimizer launch per step: counts the steps of bench.py's per-shape GEMM timing pass
+        steps = ks["adamw_kernel"][0]    # (3 more after the timed region) as well
     tot = sum(v[1] for v in ks.values())
     out = [f"# Round {tag[1:]} -- rocprofv3 --kernel-trace --stats of `python3 bench.py --precision {prec} --steps {j['steps']} "
            f"--warmup {j['warmup']} --no-cpu-baseline --no-other-precisions`\n",

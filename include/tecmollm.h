@@ -381,8 +381,10 @@ int tecm_cast_bf16(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, 
  * tensor is consumed several times.  cols, ld_src, ld_dst multiples of 4; 16-byte aligned. */
 /* dst_bf16 != 0: dst is a bf16 tensor -- the cast autocast applies to the dropped value in front of a bf16 Linear
  * (train.py:68), done once where the masked tensor is only ever read by bf16 contractions. */
-int tecm_dropout_apply(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int32_t dst_bf16, int64_t rows,
-                       int32_t cols, const TecmDrop* drop, void* stream);
+/* dst2_bf16 != NULL (dst fp32): the same masked values a second time as a bf16 tensor [r][ld_dst2] -- a gradient whose
+ * column sums want the fp32 values and whose two bf16 contractions (dW, dX of the patch projection) read the rounded ones. */
+int tecm_dropout_apply(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int32_t dst_bf16, void* dst2_bf16,
+                       int64_t ld_dst2, int64_t rows, int32_t cols, const TecmDrop* drop, void* stream);
 
 /* dst[r*ldd + c] = scale * src[c*lds + r]  (r < rows, c < cols): builds the K-extended c_attn weight
  * [W ; (alpha/r) * B^T] (modules.py:177-183) and other small transposes. */

@@ -99,10 +99,13 @@ __global__ __launch_bounds__(256) void transpose_scale_kernel(const float* __res
 }
 
 // dst = dropout(src, drop): element (r, c) keeps iff hash(seed, r*drop.ld + c) passes; float4 streaming copy
-template <bool OUT16>
+// (DUAL: an fp32 result AND its bf16 twin in one pass -- a gradient that column sums read exactly and two bf16
+//  contractions read rounded)
+template <bool OUT16, bool DUAL = false>
 __global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restrict__ src, int64_t lds_, void* __restrict__ dst_,
                                                             int64_t ldd, int64_t rows, int32_t cols4, uint64_t seed,
-                                                            int64_t dld, uint32_t thresh, float inv) {
+                                                            int64_t dld, uint32_t thresh, float inv,
+                                                            __bf16* __restrict__ dst2 = nullptr, int64_t ldd2 = 0) {
   const int64_t total = rows * cols4;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int64_t r = i / cols4;
@@ -115,6 +118,7 @@ __global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restr
     v.w *= tecm_drop_mult(seed, di + 3, thresh, inv);
     if constexpr (OUT16) tecm_store_bf16x4(static_cast<__bf16*>(dst_) + r * ldd + c, v.x, v.y, v.z, v.w);
     else *reinterpret_cast<float4*>(static_cast<float*>(dst_) + r * ldd + c) = v;
+    if constexpr (DUAL) tecm_store_bf16x4(dst2 + r * ldd2 + c, v.x, v.y, v.z, v.w);
   }
 }
 
@@ -219,22 +223,30 @@ extern "C" int tecm_cast_bf16(const float* src, int64_t ld_src, void* dst, int64
   return TECM_OK;
 }
 
-extern "C" int tecm_dropout_apply(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int32_t dst_bf16, int64_t rows,
-                                  int32_t cols, const TecmDrop* drop, void* stream) {
+extern "C" int tecm_dropout_apply(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int32_t dst_bf16, void* dst2_bf16,
+                                  int64_t ld_dst2, int64_t rows, int32_t cols, const TecmDrop* drop, void* stream) {
   TECM_REQUIRE(src && dst && drop, TECM_E_ARG, "tecm_dropout_apply: null pointer");
   TECM_REQUIRE(rows > 0 && cols > 0 && drop->p > 0.f && drop->p < 1.f, TECM_E_ARG, "tecm_dropout_apply: bad shape / p");
   TECM_REQUIRE(cols % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0 && tecm_aligned(src, 16) &&
                    tecm_aligned(dst, dst_bf16 ? 8 : 16),
                TECM_E_ALIGN, "tecm_dropout_apply: rows must be 16-byte (fp32) / 8-byte (bf16) friendly");
+  TECM_REQUIRE(!dst2_bf16 || (!dst_bf16 && ld_dst2 % 4 == 0 && tecm_aligned(dst2_bf16, 8)), TECM_E_ARG,
+               "tecm_dropout_apply: the second (bf16) output goes with an fp32 first output, rows 8-byte friendly");
   const int64_t total = rows * (cols / 4);
   const int64_t want = (total + 255) / 256;
   const dim3 grid((unsigned)(want < 8192 ? want : 8192));
-  if (dst_bf16)
-    hipLaunchKernelGGL(dropout_apply_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, dst, ld_dst, rows,
-                       cols / 4, drop->seed, drop->ld, tecm_drop_thresh(drop->p), 1.0f / (1.0f - drop->p));
+  const uint32_t th = tecm_drop_thresh(drop->p);
+  const float inv = 1.0f / (1.0f - drop->p);
+  hipStream_t st = (hipStream_t)stream;
+  if (dst2_bf16)
+    hipLaunchKernelGGL((dropout_apply_kernel<false, true>), grid, dim3(256), 0, st, src, ld_src, dst, ld_dst, rows, cols / 4,
+                       drop->seed, drop->ld, th, inv, static_cast<__bf16*>(dst2_bf16), ld_dst2);
+  else if (dst_bf16)
+    hipLaunchKernelGGL((dropout_apply_kernel<true, false>), grid, dim3(256), 0, st, src, ld_src, dst, ld_dst, rows, cols / 4,
+                       drop->seed, drop->ld, th, inv, (__bf16*)nullptr, (int64_t)0);
   else
-    hipLaunchKernelGGL(dropout_apply_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, dst, ld_dst, rows,
-                       cols / 4, drop->seed, drop->ld, tecm_drop_thresh(drop->p), 1.0f / (1.0f - drop->p));
+    hipLaunchKernelGGL((dropout_apply_kernel<false, false>), grid, dim3(256), 0, st, src, ld_src, dst, ld_dst, rows, cols / 4,
+                       drop->seed, drop->ld, th, inv, (__bf16*)nullptr, (int64_t)0);
   TECM_CHECK_LAUNCH("tecm_dropout_apply");
   return TECM_OK;
 }

@@ -379,14 +379,19 @@ class ConvBlockFn(torch.autograd.Function):
         # final 1x1 strided conv
         dbf = colsum(dout, Cout, Mo, 1, 1, Cout)[0]
         dwf = _empty(Cout, CT, like=inp)
-        gemm(Cout, CT, Mo, dout, Cout, act, CT, dwf, CT, a_layout=A_KM, b_layout=B_KN,
+        # bf16 mode: both contractions read dout as a bf16 twin (their loaders would round it; the bias gradient above sums fp32)
+        if int(bf16) == ops.PREC_BF16 and act.dtype == torch.bfloat16 and ctx.compact and ops.tn_ok(Cout, CT, Mo) and Cout % 8 == 0:
+            dout_g = ops.bf16_twin(dout, Mo, Cout)
+        else:
+            dout_g = dout
+        gemm(Cout, CT, Mo, dout_g, Cout, act, CT, dwf, CT, a_layout=A_KM, b_layout=B_KN,
              b_win=None if ctx.compact else win(N, Lc, Lo, stride, 1, CT, 0),
              split_k=pick_split_k(Cout, CT, Mo, prec=bf16), bf16=bf16)
         # the gradient at the 1x1 conv's input: a bf16 tensor in bf16 mode (what the backward of a bf16 Conv1d hands to the
         # fp32 GELU backward under autocast), read once by the GroupNorm + GELU backward
         d16 = act.dtype == torch.bfloat16 and ops.uses_bf16(CT, Cout, Cout, CT, b_layout=B_KN)
         dact = torch.empty(B, Lo, N, CT, device=inp.device, dtype=torch.bfloat16 if d16 else torch.float32)
-        gemm(Mo, CT, Cout, dout, Cout, wf2, CT, dact, CT, b_layout=B_KN, bf16=bf16)
+        gemm(Mo, CT, Cout, dout_g, Cout, wf2, CT, dact, CT, b_layout=B_KN, bf16=bf16)
         # GroupNorm + GELU
         dy = torch.empty(B, Lc, N, CT, device=inp.device, dtype=act.dtype)
         dgamma, dbeta, dbconv = ops.groupnorm_gelu_bwd(dact, stride, y, gamma, beta, stats, dy, B, Lc, N, Cout)
@@ -447,7 +452,9 @@ class PatchEmbedFn(torch.autograd.Function):
         a_in = conv16 if (conv16 is not None and int(plan.bf16) == ops.PREC_BF16 and D % 8 == 0) else conv
         gemm(M, d_llm, K, a_in, D, Wp, K, h0, d_llm, a_win=w, bias=bp,
              rowbias=(wpe, wpe.shape[1], N, P) if wpe is not None else None, out_drop=dspec, bf16=plan.bf16)
-        ctx.save_for_backward(conv, Wp, wpe if wpe is not None else Wp)
+        # the weight gradient contracts the same tensor the forward read: the bf16 copy in bf16 mode (what its loader would
+        # round the fp32 one to), at half the bytes and in the form the LDS-DMA kernel takes
+        ctx.save_for_backward(a_in, Wp, wpe if wpe is not None else Wp)
         ctx.meta = (B, Lc, N, D, P, d_llm, patch_len, wpe is not None, dspec)
         ctx.plan = plan
         return h0
@@ -463,20 +470,31 @@ class PatchEmbedFn(torch.autograd.Function):
         w = win(N, Lc, P, patch_len, patch_len, D, 0)
         # the embd-dropout mask of the forward epilogue, applied once: the masked gradient feeds two column sums and
         # two GEMMs
+        # (bf16 mode: the two GEMMs read a bf16 twin -- what their loaders would round the fp32 values to -- so that the
+        #  weight gradient runs on the natural-orientation LDS-DMA kernel; the column sums keep the fp32 values)
+        t16 = int(plan.bf16) == ops.PREC_BF16 and conv.dtype == torch.bfloat16 and \
+            ops.tn_ok(d_llm, K, M) and d_llm % 8 == 0
+        dh16 = None
         if dspec is not None:
-            dh0 = ops.dropout_apply(dh0, M, d_llm, dspec)
+            if t16:
+                dh0, dh16 = ops.dropout_apply(dh0, M, d_llm, dspec, twin_bf16=True)
+            else:
+                dh0 = ops.dropout_apply(dh0, M, d_llm, dspec)
+        elif t16:
+            dh16 = ops.bf16_twin(dh0, M, d_llm)
         dbp = colsum(dh0, d_llm, M, 1, 1, d_llm)[0]
         dwpe = None
         if has_wpe:
             dwpe = torch.zeros_like(wpe)
             colsum(dh0, d_llm, B, N, P, d_llm, out=dwpe)                     # rows 0..P-1 of wpe
         dWp = _empty(d_llm, K, like=conv)
-        gemm(d_llm, K, M, dh0, d_llm, conv, D, dWp, K, a_layout=A_KM, b_layout=B_KN, b_win=w,
+        dg = dh16 if dh16 is not None else dh0
+        gemm(d_llm, K, M, dg, d_llm, conv, D, dWp, K, a_layout=A_KM, b_layout=B_KN, b_win=w,
              split_k=pick_split_k(d_llm, K, M, prec=plan.bf16), bf16=plan.bf16)
         dconv = _empty(B, Lc, N, D, like=conv)
         if P * patch_len != Lc:
             dconv.zero_()
-        gemm(M, K, d_llm, dh0, d_llm, Wp, K, dconv, D, b_layout=B_KN, c_win=w, bf16=plan.bf16)
+        gemm(M, K, d_llm, dg, d_llm, Wp, K, dconv, D, b_layout=B_KN, c_win=w, bf16=plan.bf16)
         return dconv, None, dWp, dbp, dwpe, None, None
 
 
@@ -805,10 +823,13 @@ class HeadFn(torch.autograd.Function):
              out_drop=hspec, bf16=plan.bf16)
         db1 = colsum(dpre, Hd, S, 1, 1, Hd)[0]
         dW1 = _empty(Hd, K1, like=hid)
-        gemm(Hd, K1, S, dpre, Hd, hid, D, dW1, K1, a_layout=A_KM, b_layout=B_KN, b_win=w,       # hid = dropout(hid) here
+        # bf16 mode: both contractions read dpre as a bf16 twin (what their loaders round it to; db1 above sums the fp32 values)
+        dp = ops.bf16_twin(dpre, S, Hd) if (int(plan.bf16) == ops.PREC_BF16 and hid.dtype == torch.bfloat16 and
+                                             ops.tn_ok(Hd, K1, S) and Hd % 8 == 0) else dpre
+        gemm(Hd, K1, S, dp, Hd, hid, D, dW1, K1, a_layout=A_KM, b_layout=B_KN, b_win=w,       # hid = dropout(hid) here
              split_k=pick_split_k(Hd, K1, S, prec=plan.bf16), bf16=plan.bf16)
         dhid = _empty(B, T, N, D, like=hid)
-        gemm(S, K1, Hd, dpre, Hd, W1, K1, dhid, D, b_layout=B_KN, c_win=w, out_drop=pspec, bf16=plan.bf16)
+        gemm(S, K1, Hd, dp, Hd, W1, K1, dhid, D, b_layout=B_KN, c_win=w, out_drop=pspec, bf16=plan.bf16)
         return dhid, dW1, db1, dW2, db2, None
 
 

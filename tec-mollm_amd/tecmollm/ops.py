@@ -267,6 +267,11 @@ def summarize_gemm_timing(records: list) -> dict:
     return agg
 
 
+def tn_ok(Mo: int, No: int, K: int) -> bool:
+    """Does the natural-orientation bf16 weight-gradient kernel (csrc/gemm_bf16_tn.hip) serve an Mo x No output over K rows?"""
+    return os.environ.get("TECM_BF16_TN", "")[:1] != "0" and lib().tecm_gemm_tn_splits(Mo, No, K) >= 2
+
+
 def pick_split_k(Mo: int, No: int, K: int, target_blocks: int = 512, min_chunk: int = 512,
                  max_splits: int = 256, prec: int = 0) -> int:
     """Split the (huge) reduction dim of a weight-gradient GEMM so the grid fills 256 CUs; capped because every
@@ -453,13 +458,23 @@ def cast_bf16(src: torch.Tensor, lds: int, dst: torch.Tensor, ldd: int, rows: in
 
 
 def dropout_apply(src: torch.Tensor, rows: int, cols: int, spec: TecmDrop, ld: Optional[int] = None,
-                  out_bf16: bool = False) -> torch.Tensor:
+                  out_bf16: bool = False, twin_bf16: bool = False):
     """dropout(src) with the library's counter-based mask (index = row*spec.ld + col) as a new contiguous tensor; out_bf16:
-    a bf16 one (the masked value rounded once, for a tensor only bf16 contractions read)."""
+    a bf16 one (the masked value rounded once, for a tensor only bf16 contractions read); twin_bf16: (fp32 result, its bf16
+    twin) from one pass."""
     dst = torch.empty_like(src, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    twin = torch.empty_like(src, dtype=torch.bfloat16) if twin_bf16 else None
     ld = cols if ld is None else ld
-    check(lib().tecm_dropout_apply(src.data_ptr(), ld, dst.data_ptr(), ld, 1 if out_bf16 else 0, rows, cols, C.byref(spec),
-                                   stream_ptr()), "tecm_dropout_apply")
+    check(lib().tecm_dropout_apply(src.data_ptr(), ld, dst.data_ptr(), ld, 1 if out_bf16 else 0, ptr(twin), ld, rows, cols,
+                                   C.byref(spec), stream_ptr()), "tecm_dropout_apply")
+    return (dst, twin) if twin_bf16 else dst
+
+
+def bf16_twin(src: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
+    """A bf16 copy of a contiguous fp32 (rows, cols) matrix for bf16 contractions that would round it in their loaders
+    anyway (bit-identical) -- the natural-orientation weight-gradient kernel takes its operands by LDS-DMA, bf16 only."""
+    dst = torch.empty(src.shape, device=src.device, dtype=torch.bfloat16)
+    cast_bf16(src, cols, dst, cols, rows, cols)
     return dst
 
 

@@ -609,5 +609,7 @@ def test_dropout_apply_matches_numpy_mirror(dev, rows, cols, ld, p):
     # the same mask again in a second call (pure function of seed and index), and a different one for another seed
     assert torch.equal(ops.dropout_apply(src, rows, cols, spec), out)
     assert torch.equal(ops.dropout_apply(src, rows, cols, spec, out_bf16=True), out.bfloat16())     # the bf16 form: rounded once
+    o32, o16 = ops.dropout_apply(src, rows, cols, spec, twin_bf16=True)                           # both from one pass
+    assert torch.equal(o32, out) and torch.equal(o16, out.bfloat16())
     if p > 0 and rows * cols > 100:
         assert not torch.equal(ops.dropout_apply(src, rows, cols, ops.drop(p, seed + 1, ld)), out)

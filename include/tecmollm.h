@@ -376,6 +376,13 @@ int tecm_conv_dw_f32(const TecmConvDw* p, void* stream);
  * the 32 LoRA columns z = drop(LN1(h)) A^T, reference modules.py:177-186). */
 int tecm_cast_bf16(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int32_t cols, void* stream);
 
+/* bf16 forms of a trainable fp32 weight W [rows][cols] in one launch: same_bf16 = W rounded ([rows][ld_same]) and / or
+ * transposed_bf16 = W^T rounded ([cols][ld_tr]) -- the values a bf16 contraction rounds W to in its loader, as tensors the
+ * LDS-DMA GEMM can take as its [row][k] operand in the forward (nn.Linear / Conv1d(k=1): y = x W^T) and in the
+ * input-gradient contraction (dx = dy W).  Either pointer may be NULL. */
+int tecm_weight_bf16(const float* src, int64_t ld_src, void* same_bf16, int64_t ld_same, void* transposed_bf16, int64_t ld_tr,
+                     int32_t rows, int32_t cols, void* stream);
+
 /* dst[r][c] = src[r][c] * keep(seed, r*drop.ld + c) / (1 - p): the counter-based dropout mask every kernel of this
  * library recomputes (F.dropout of tec_mollm.py:115, GPT-2's embd dropout), materialised once where the masked
  * tensor is consumed several times.  cols, ld_src, ld_dst multiples of 4; 16-byte aligned. */

@@ -98,6 +98,29 @@ __global__ __launch_bounds__(256) void transpose_scale_kernel(const float* __res
   }
 }
 
+// bf16 forms of a trainable fp32 weight W [R][C], one launch: `same` = W rounded ([R][C]), `tr` = W^T rounded ([C][R]).
+// A bf16 contraction would round the fp32 weight in its loader to exactly these values; as bf16 tensors they can be the
+// [row][k] operand of the LDS-DMA GEMM in the forward (same) and in the input-gradient contraction (tr).
+__global__ __launch_bounds__(256) void weight_bf16_kernel(const float* __restrict__ src, int64_t lds_, __bf16* __restrict__ same,
+                                                          int64_t ld_same, __bf16* __restrict__ tr, int64_t ld_tr, int R,
+                                                          int Cc) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+  const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  for (int j = ty; j < 32; j += 8) {
+    const int r = r0 + j, c = c0 + tx;
+    const float v = (r < R && c < Cc) ? src[(int64_t)r * lds_ + c] : 0.f;
+    tile[j][tx] = v;
+    if (same && r < R && c < Cc) same[(int64_t)r * ld_same + c] = (__bf16)v;
+  }
+  __syncthreads();
+  if (tr)
+    for (int j = ty; j < 32; j += 8) {
+      const int c = c0 + j, r = r0 + tx;
+      if (r < R && c < Cc) tr[(int64_t)c * ld_tr + r] = (__bf16)tile[tx][j];
+    }
+}
+
 // dst = dropout(src, drop): element (r, c) keeps iff hash(seed, r*drop.ld + c) passes; float4 streaming copy
 // (DUAL: an fp32 result AND its bf16 twin in one pass -- a gradient that column sums read exactly and two bf16
 //  contractions read rounded)
@@ -220,6 +243,17 @@ extern "C" int tecm_cast_bf16(const float* src, int64_t ld_src, void* dst, int64
   hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, ld_src,
                      static_cast<__bf16*>(dst), ld_dst, rows, cols / 4);
   TECM_CHECK_LAUNCH("tecm_cast_bf16");
+  return TECM_OK;
+}
+
+extern "C" int tecm_weight_bf16(const float* src, int64_t ld_src, void* same_bf16, int64_t ld_same, void* transposed_bf16,
+                                int64_t ld_tr, int32_t rows, int32_t cols, void* stream) {
+  TECM_REQUIRE(src && (same_bf16 || transposed_bf16), TECM_E_ARG, "tecm_weight_bf16: null pointer");
+  TECM_REQUIRE(rows > 0 && cols > 0 && ld_src >= cols && (!same_bf16 || ld_same >= cols) && (!transposed_bf16 || ld_tr >= rows),
+               TECM_E_ARG, "tecm_weight_bf16: bad shape");
+  hipLaunchKernelGGL(weight_bf16_kernel, dim3((rows + 31) / 32, (cols + 31) / 32), dim3(256), 0, (hipStream_t)stream, src,
+                     ld_src, static_cast<__bf16*>(same_bf16), ld_same, static_cast<__bf16*>(transposed_bf16), ld_tr, rows, cols);
+  TECM_CHECK_LAUNCH("tecm_weight_bf16");
   return TECM_OK;
 }
 

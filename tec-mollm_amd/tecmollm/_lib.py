@@ -188,6 +188,8 @@ EXPORTS = {
     "tecm_conv_dx_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "tecm_transpose_scale": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_float,
                                        C.c_void_p]),
+    "tecm_weight_bf16": (C.c_int, [c_f32p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                   C.c_void_p]),
     "tecm_dropout_apply": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int64,
                                      C.c_int32, C.POINTER(TecmDrop), C.c_void_p]),
     "tecm_adamw_clip_step": (C.c_int, [C.POINTER(TecmAdamW), C.c_void_p]),

@@ -346,6 +346,13 @@ class ConvBlockFn(torch.autograd.Function):
         wf2 = wf.view(Cout, CT)
         out16 = None
         awin = None if compact else win(N, Lc, Lo, stride, 1, CT, 0)
+        # bf16 mode, compact bf16 activations: the 1x1 conv and its input gradient are plain contractions of bf16 tensors
+        # once the weight is one too -- W and W^T rounded (one tiny launch; what the loaders would round W to), so that the
+        # LDS-DMA GEMM serves them
+        wfT16 = None
+        if int(bf16) == ops.PREC_BF16 and compact and act.dtype == torch.bfloat16 and Cout % 8 == 0:
+            wf2, wfT16 = ops.weight_bf16(wf2, same=True, transposed=True)
+        ctx.wfT16 = wfT16
         if side16:
             # one epilogue, two forms of the same values: the fp32 tensor autograd sees (written through the epilogue's
             # pre-activation store; there is no activation here) and a bf16 copy for the window GEMMs that read it next
@@ -391,7 +398,10 @@ class ConvBlockFn(torch.autograd.Function):
         # fp32 GELU backward under autocast), read once by the GroupNorm + GELU backward
         d16 = act.dtype == torch.bfloat16 and ops.uses_bf16(CT, Cout, Cout, CT, b_layout=B_KN)
         dact = torch.empty(B, Lo, N, CT, device=inp.device, dtype=torch.bfloat16 if d16 else torch.float32)
-        gemm(Mo, CT, Cout, dout_g, Cout, wf2, CT, dact, CT, b_layout=B_KN, bf16=bf16)
+        if ctx.wfT16 is not None and dout_g.dtype == torch.bfloat16 and d16:
+            gemm(Mo, CT, Cout, dout_g, Cout, ctx.wfT16, Cout, dact, CT, bf16=bf16)       # [row][k] operands: the LDS-DMA kernel
+        else:
+            gemm(Mo, CT, Cout, dout_g, Cout, wf2, CT, dact, CT, b_layout=B_KN, bf16=bf16)
         # GroupNorm + GELU
         dy = torch.empty(B, Lc, N, CT, device=inp.device, dtype=act.dtype)
         dgamma, dbeta, dbconv = ops.groupnorm_gelu_bwd(dact, stride, y, gamma, beta, stats, dy, B, Lc, N, Cout)
@@ -494,7 +504,12 @@ class PatchEmbedFn(torch.autograd.Function):
         dconv = _empty(B, Lc, N, D, like=conv)
         if P * patch_len != Lc:
             dconv.zero_()
-        gemm(M, K, d_llm, dg, d_llm, Wp, K, dconv, D, b_layout=B_KN, c_win=w, bf16=plan.bf16)
+        if dh16 is not None and K % 8 == 0:
+            # W^T rounded to bf16 ([K][d_llm], one tiny launch): both operands [row][k] bf16 tensors -> the LDS-DMA kernel
+            WpT16 = ops.weight_bf16(Wp, same=False, transposed=True)[1]
+            gemm(M, K, d_llm, dh16, d_llm, WpT16, d_llm, dconv, D, c_win=w, bf16=plan.bf16)
+        else:
+            gemm(M, K, d_llm, dg, d_llm, Wp, K, dconv, D, b_layout=B_KN, c_win=w, bf16=plan.bf16)
         return dconv, None, dWp, dbp, dwpe, None, None
 
 
@@ -829,7 +844,11 @@ class HeadFn(torch.autograd.Function):
         gemm(Hd, K1, S, dp, Hd, hid, D, dW1, K1, a_layout=A_KM, b_layout=B_KN, b_win=w,       # hid = dropout(hid) here
              split_k=pick_split_k(Hd, K1, S, prec=plan.bf16), bf16=plan.bf16)
         dhid = _empty(B, T, N, D, like=hid)
-        gemm(S, K1, Hd, dp, Hd, W1, K1, dhid, D, b_layout=B_KN, c_win=w, out_drop=pspec, bf16=plan.bf16)
+        if dp.dtype == torch.bfloat16 and K1 % 8 == 0:
+            W1T16 = ops.weight_bf16(W1, same=False, transposed=True)[1]      # [K1][Hd] bf16: [row][k] operands for the LDS-DMA kernel
+            gemm(S, K1, Hd, dp, Hd, W1T16, Hd, dhid, D, c_win=w, out_drop=pspec, bf16=plan.bf16)
+        else:
+            gemm(S, K1, Hd, dp, Hd, W1, K1, dhid, D, b_layout=B_KN, c_win=w, out_drop=pspec, bf16=plan.bf16)
         return dhid, dW1, db1, dW2, db2, None
 
 

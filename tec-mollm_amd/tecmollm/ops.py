@@ -470,6 +470,15 @@ def dropout_apply(src: torch.Tensor, rows: int, cols: int, spec: TecmDrop, ld: O
     return (dst, twin) if twin_bf16 else dst
 
 
+def weight_bf16(W: torch.Tensor, same: bool = True, transposed: bool = False):
+    """(W rounded to bf16 [R][C] or None, W^T rounded to bf16 [C][R] or None) of a contiguous fp32 matrix, one launch."""
+    R, Cc = W.shape
+    s = torch.empty(R, Cc, device=W.device, dtype=torch.bfloat16) if same else None
+    t = torch.empty(Cc, R, device=W.device, dtype=torch.bfloat16) if transposed else None
+    check(lib().tecm_weight_bf16(W.data_ptr(), Cc, ptr(s), Cc, ptr(t), R, R, Cc, stream_ptr()), "tecm_weight_bf16")
+    return s, t
+
+
 def bf16_twin(src: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
     """A bf16 copy of a contiguous fp32 (rows, cols) matrix for bf16 contractions that would round it in their loaders
     anyway (bit-identical) -- the natural-orientation weight-gradient kernel takes its operands by LDS-DMA, bf16 only."""

@@ -231,7 +231,10 @@ int tecm_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const fl
                        int64_t ldy, void* y16, int64_t ldy16,
                        void* y16d /* optional third output: bf16(dropout(y, drop)) -- the LoRA branch's input, peft
                                      lora_dropout in front of lora_A (modules.py:181), cast as autocast casts it */,
-                       int64_t ldy16d, const TecmDrop* drop /* of y16d; element index row*drop->ld + c */,
+                       int64_t ldy16d, const TecmDrop* drop /* of y16d; element index row*drop->ld + c; p = 0: no mask */,
+                       int32_t y16d_seq_T, int32_t y16d_seq_N /* both > 0: y16d is written SEQUENCE-major -- the time-major
+                                     row (b, t, n) of M = B*T*N goes to row (b, n, t): PredictionHead's view(batch, -1)
+                                     (modules.py:307) of ln_f's output as a plain [B*N][T*D] matrix.  0, 0: same rows as y */,
                        float* stats /* (M,2) mean,rstd */, int64_t M, int32_t D, float eps, void* stream);
 /* dx = dres (optional) + LN'(dy).  Optional second output dx_masked = dropout(dx, mask_drop): the
  * residual-stream gradient is consumed twice in GPT2Block's backward, once as is (residual path) and
@@ -249,13 +252,20 @@ typedef struct TecmLnAdd {
   int32_t bf16, _pad;
   TecmDrop drop;
 } TecmLnAdd;
+/* dy in the sequence-major form tecm_layernorm_fwd can write y16d in (rows (b, n, t), bf16) and still in front of the
+ * forward's dropout:  dy[(b,t,n)][c] = keep((b,t,n), c) / (1 - p) * dy16[(b,n,t)][c]  -- the gradient the head's first Linear
+ * returns for F.dropout(ln_f(h)) (tec_mollm.py:115), taken as it is.  T == 0 / NULL: plain rows. */
+typedef struct TecmLnDyMap {
+  int32_t T, N;
+  TecmDrop drop;                 /* p == 0: no mask */
+} TecmLnDyMap;
 int tecm_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                        const float* stats, const float* dres, float* dx, void* dx_masked, int32_t masked_bf16,
                        const TecmDrop* mask_drop, float* dgb_partials, int32_t* num_blocks, int64_t M, int32_t D,
                        const TecmLnAdd* add /* NULL: none */,
                        int32_t dy_bf16 /* != 0: dy is bf16 -- the gradient a bf16 Linear returns for its input under
                                           autocast (train.py:68) */,
-                       void* stream);
+                       const TecmLnDyMap* dymap /* NULL: none; needs dy_bf16 and no second stream */, void* stream);
 
 /* Causal multi-head self-attention over T tokens per sequence (GPT2Attention, modeling_gpt2.py:54-73,
  * :144-226; all-ones attention_mask tec_mollm.py:111 => pure causal).  qkv: (B,T,N,3*D) time-major

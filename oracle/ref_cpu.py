@@ -407,7 +407,9 @@ def forward(x: torch.Tensor, tf: torch.Tensor, edge_index: torch.Tensor, p: Para
     C = xs.shape[-1]
     xt = xs.view(L, B, N, C).permute(1, 2, 0, 3).reshape(B * N, L, C)
     tok = temporal_encoder(xt, p, cfg["temporal_strides"], cfg["patch_len"], q)
-    hid = _mul(gpt2_lora(tok, p, cfg["llm_layers"], q, masks), masks, "post")
+    # (grad_stored: the gradient the head's first Linear -- a bf16 contraction under autocast -- returns for its input is a
+    #  bf16 tensor; the device stores it as such in front of the dropout's and ln_f's backward)
+    hid = grad_stored(_mul(gpt2_lora(tok, p, cfg["llm_layers"], q, masks), masks, "post"), q)
     pred = head(hid, p, q, masks)
     return pred.view(B, N, -1).permute(0, 2, 1).unsqueeze(-1)
 

@@ -33,10 +33,20 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                                                             const float* __restrict__ beta, float* __restrict__ y,
                                                             int64_t ldy, void* __restrict__ y16, int64_t ldy16,
                                                             void* __restrict__ y16d, int64_t ldy16d, DropCtxN dd,
-                                                            float* __restrict__ stats, int64_t M, int D, float eps) {
+                                                            float* __restrict__ stats, int64_t M, int D, float eps,
+                                                            int permT, int permN) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * 4 + wave;
   if (row >= M) return;
+  // y16d may be written SEQUENCE-major: time-major row (b, t, n) -> row (b, n, t), i.e. PredictionHead's view(batch, -1)
+  // (modules.py:307) of the (B*N, T, D) hidden state as a plain [B*N][T*D] matrix (the mask index stays the time-major one)
+  int64_t drow = row;
+  if (permT > 0) {
+    const int64_t tn = (int64_t)permT * permN;
+    const int64_t b = row / tn, rem = row - b * tn;
+    const int64_t t = rem / permN, n = rem - t * permN;
+    drow = (b * permN + n) * permT + t;
+  }
   const float* xr = x + row * ldx;
   float4 v[NCH];
   float s = 0.f;
@@ -75,7 +85,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
       // cast autocast applies to the DROPPED fp32 value; read by the LoRA-A GEMM and by its weight gradient
       if (y16d) {
         const uint64_t di = (uint64_t)(row * dd.ld + c);
-        tecm_store_bf16x4(static_cast<__bf16*>(y16d) + row * ldy16d + c,
+        tecm_store_bf16x4(static_cast<__bf16*>(y16d) + drow * ldy16d + c,
                           o.x * tecm_drop_mult(dd.seed, di, dd.thresh, dd.inv),
                           o.y * tecm_drop_mult(dd.seed, di + 1, dd.thresh, dd.inv),
                           o.z * tecm_drop_mult(dd.seed, di + 2, dd.thresh, dd.inv),
@@ -103,14 +113,23 @@ struct LnAdd {
 };
 
 // DY16: dy is a bf16 matrix (bf16 mode: the gradient a bf16 Linear hands back for its input, train.py:68)
-template <int NCH, bool ADD, bool DY16 = false>
+// DYMAP (with DY16): that matrix is SEQUENCE-major -- row (b, n, t) for the time-major row (b, t, n) this kernel walks -- and
+// still in front of a dropout: dy[row][c] = keep(row, c) / (1 - p) * dy16[(b, n, t)][c].  The gradient the head's first
+// Linear returns for F.dropout(hidden) (tec_mollm.py:115, modules.py:307), consumed by ln_f's backward without a pass of
+// its own for the mask or the layout.
+struct LnDyMap {
+  int T, N;
+  DropCtxN drop;
+};
+template <int NCH, bool ADD, bool DY16 = false, bool DYMAP = false>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, int64_t lddy,
                                                             const float* __restrict__ x, int64_t ldx,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ stats,
                                                             const float* __restrict__ dres, float* __restrict__ dx,
                                                             float* __restrict__ dxm, int dxm_bf16, DropCtxN odc,
-                                                            float* __restrict__ partials, int64_t M, int D, LnAdd ad) {
+                                                            float* __restrict__ partials, int64_t M, int D, LnAdd ad,
+                                                            LnDyMap dm = LnDyMap{}) {
   __shared__ float red[4][2 * 4 * 64 * NCH];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float4 dg[NCH], db[NCH], gm[NCH];
@@ -126,6 +145,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     const float mean = stats[2 * row], rstd = stats[2 * row + 1];
     float4 xh[NCH], g[NCH];
     float s1 = 0.f, s2 = 0.f;
+    int64_t yrow = row;
+    if constexpr (DYMAP) {
+      const int64_t tn = (int64_t)dm.T * dm.N;
+      const int64_t b = row / tn, rem = row - b * tn;
+      const int64_t t = rem / dm.N, n = rem - t * dm.N;
+      yrow = (b * dm.N + n) * dm.T + t;
+    }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = 4 * (lane + 64 * i);
@@ -133,8 +159,17 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         const float4 xv = *reinterpret_cast<const float4*>(x + row * ldx + c);
         float4 d;
         if constexpr (DY16) {
-          const tecm_bf16x4 h = *reinterpret_cast<const tecm_bf16x4*>(reinterpret_cast<const __bf16*>(dy) + row * lddy + c);
+          const tecm_bf16x4 h = *reinterpret_cast<const tecm_bf16x4*>(reinterpret_cast<const __bf16*>(dy) + yrow * lddy + c);
           d = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+          if constexpr (DYMAP) {
+            if (dm.drop.thresh) {
+              const uint64_t di = (uint64_t)(row * dm.drop.ld + c);
+              d.x *= tecm_drop_mult(dm.drop.seed, di, dm.drop.thresh, dm.drop.inv);
+              d.y *= tecm_drop_mult(dm.drop.seed, di + 1, dm.drop.thresh, dm.drop.inv);
+              d.z *= tecm_drop_mult(dm.drop.seed, di + 2, dm.drop.thresh, dm.drop.inv);
+              d.w *= tecm_drop_mult(dm.drop.seed, di + 3, dm.drop.thresh, dm.drop.inv);
+            }
+          }
         } else {
           d = *reinterpret_cast<const float4*>(dy + row * lddy + c);
         }
@@ -1071,8 +1106,11 @@ extern "C" int tecm_gn_y16_supported(int32_t L, int32_t N, int32_t Cout) { retur
 
 extern "C" int tecm_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y,
                                   int64_t ldy, void* y16, int64_t ldy16, void* y16d, int64_t ldy16d, const TecmDrop* drop,
-                                  float* stats, int64_t M, int32_t D, float eps, void* stream) {
-  TECM_REQUIRE(x && gamma && beta && (y || y16) && stats, TECM_E_ARG, "tecm_layernorm_fwd: null pointer");
+                                  int32_t y16d_seq_T, int32_t y16d_seq_N, float* stats, int64_t M, int32_t D, float eps,
+                                  void* stream) {
+  TECM_REQUIRE(x && gamma && beta && (y || y16 || y16d) && stats, TECM_E_ARG, "tecm_layernorm_fwd: null pointer");
+  TECM_REQUIRE(y16d_seq_T == 0 || (y16d && y16d_seq_T > 0 && y16d_seq_N > 0 && M % ((int64_t)y16d_seq_T * y16d_seq_N) == 0),
+               TECM_E_ARG, "tecm_layernorm_fwd: the sequence-major form needs y16d and M = B * T * N");
   TECM_REQUIRE(!y16d || (tecm_aligned(y16d, 8) && ldy16d % 4 == 0 && ldy16d >= D), TECM_E_ALIGN,
                "tecm_layernorm_fwd: the dropped bf16 output must be 8-byte aligned with a leading dimension multiple of 4");
   TECM_REQUIRE(!y16d || (drop && drop->p >= 0.f && drop->p < 1.f), TECM_E_ARG, "tecm_layernorm_fwd: y16d needs its dropout spec");
@@ -1089,7 +1127,7 @@ extern "C" int tecm_layernorm_fwd(const float* x, int64_t ldx, const float* gamm
   hipStream_t st = (hipStream_t)stream;
 #define LN_FWD(NCH) \
   hipLaunchKernelGGL((layernorm_fwd_kernel<NCH>), grid, dim3(256), 0, st, x, ldx, gamma, beta, y, ldy, y16, ldy16, y16d, ldy16d, \
-                     dd, stats, M, D, eps)
+                     dd, stats, M, D, eps, (int)y16d_seq_T, (int)y16d_seq_N)
   switch (nch) {
     case 1: LN_FWD(1); break;
     case 2: LN_FWD(2); break;
@@ -1105,7 +1143,7 @@ extern "C" int tecm_layernorm_bwd(const float* dy, int64_t lddy, const float* x,
                                   const float* stats, const float* dres, float* dx, void* dx_masked,
                                   int32_t masked_bf16, const TecmDrop* mask_drop, float* dgb_partials,
                                   int32_t* num_blocks, int64_t M, int32_t D, const TecmLnAdd* add, int32_t dy_bf16,
-                                  void* stream) {
+                                  const TecmLnDyMap* dymap, void* stream) {
   TECM_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAXCH, TECM_E_ARG, "tecm_layernorm_bwd: bad M/D");
   const int nb = ln_blocks(M);
   if (num_blocks) *num_blocks = nb;
@@ -1125,9 +1163,19 @@ extern "C" int tecm_layernorm_bwd(const float* dy, int64_t lddy, const float* x,
                  "tecm_layernorm_bwd: dy2 must be 16-byte (fp32) / 8-byte (bf16) friendly");
     ad.dy2 = add->dy2; ad.ld = add->ld; ad.bf16 = add->bf16; ad.drop = make_dropn(&add->drop);
   }
+ LnDyMap dm{};
+  const bool has_map = dymap != nullptr && dymap->T > 0;
+  if (has_map) {
+    TECM_REQUIRE(dy_bf16 && !has_add && dymap->N > 0 && M % ((int64_t)dymap->T * dymap->N) == 0, TECM_E_ARG,
+                 "tecm_layernorm_bwd: the sequence-major dy is a bf16 matrix of M = B * T * N rows, without a second stream");
+    dm.T = dymap->T; dm.N = dymap->N; dm.drop = make_dropn(&dymap->drop);
+  }
 #define LN_BWD(NCH)                                                                                                       \
   do {                                                                                                                    \
-    if (has_add && dy_bf16)                                                                                               \
+    if (has_map)                                                                                                          \
+      hipLaunchKernelGGL((layernorm_bwd_kernel<NCH, false, true, true>), dim3(nb), dim3(256), 0, st, dy, lddy, x, ldx, gamma, \
+                         stats, dres, dx, static_cast<float*>(dx_masked), (int)masked_bf16, odc, dgb_partials, M, D, ad, dm); \
+    else if (has_add && dy_bf16)                                                                                               \
       hipLaunchKernelGGL((layernorm_bwd_kernel<NCH, true, true>), dim3(nb), dim3(256), 0, st, dy, lddy, x, ldx, gamma, stats, \
                          dres, dx, static_cast<float*>(dx_masked), (int)masked_bf16, odc, dgb_partials, M, D, ad);        \
     else if (has_add)                                                                                                     \
@@ -1261,7 +1309,8 @@ extern "C" int tecm_groupnorm_gelu_bwd(const void* dact_, int32_t dstride, const
   if (io_bf16 & TECM_GN_Y_BF16) {                        // every tensor bf16
     // the four-channel register kernel with 8-byte y / dact loads where its geometry serves the sequence (measured at B = 8:
     // 1.3x faster than the 8-channel kernel in this direction: more requests in flight per lane), else the 8-channel one
-    const int npq = tecm_aligned(dact_, 8) ? gn_reg_pairs(L, N, Cout, 4, 9, y_, dy_) : 0;
+    const char* wps_env = std::getenv("TECM_GN_BWD_WPS");        // "8": force the 8-wave geometry (A/B diagnostics)
+    const int npq = (tecm_aligned(dact_, 8) && !(wps_env && wps_env[0] == '8')) ? gn_reg_pairs(L, N, Cout, 4, 9, y_, dy_) : 0;
     if (npq > 0) {
 #define GN_BWD_Q16(CPB) \
   hipLaunchKernelGGL((gn_gelu_bwd_reg<CPB, 4, 9, true, true, true>), dim3(nb), dim3(256), 0, st, dact_, dstride, L2, y_, gamma, \

@@ -19,7 +19,9 @@ dict, same forward signature and output shape, same parameter names.  Difference
 """
 from __future__ import annotations
 
+import dataclasses
 import logging
+import os
 from typing import Optional
 
 import torch
@@ -31,6 +33,7 @@ from .modules import (LLMBackbone, PredictionHead, SpatialEncoder, SpatioTempora
                       _need_cuda, make_plan)
 
 log = logging.getLogger(__name__)
+_FUSE_HEAD = os.environ.get("TECM_FUSE_HEAD", "1") != "0"     # "0": ln_f and the head as separate stages (A/B diagnostics)
 
 _REQUIRED = ("num_nodes", "d_emb", "spatial_in_channels_base", "spatial_out_channels", "spatial_heads",
              "temporal_channel_list", "temporal_strides", "patch_len", "d_llm", "llm_layers", "temporal_seq_len",
@@ -103,9 +106,11 @@ class TEC_MoLLM(nn.Module):
         # 5. temporal encoder (+ wpe and embd dropout of the GPT-2 front end) -> (B, P, N, 768)
         wpe = self.llm_backbone.trunk.wpe.weight
         h0 = self.temporal_encoder.forward_tm(xs, self.c_spatial, wpe, plan, need_dinp=True)
-        # 6. GPT-2 blocks with LoRA
+        # 6. GPT-2 blocks with LoRA; 7. dropout + prediction head -> (B, N, L_out)
+        # (bf16 mode: ln_f hands the head its operand directly -- dropped, rounded, sequence-major; F_.GPT2StackFn)
+        if int(plan.bf16) == F_.ops.PREC_BF16 and _FUSE_HEAD:
+            plan = dataclasses.replace(plan, fuse_head=True)
         hid = self.llm_backbone.forward_tm(h0, plan)
-        # 7. dropout + prediction head -> (B, N, L_out)
         pred = self.prediction_head.forward_tm(hid, plan)
         # 8. (B, N, L_out) -> (B, L_out, N, 1), a permuted view like tec_mollm.py:123
         return pred.permute(0, 2, 1).unsqueeze(-1)

@@ -80,6 +80,10 @@ class TecmLnAdd(C.Structure):
     _fields_ = [("dy2", C.c_void_p), ("ld", C.c_int64), ("bf16", C.c_int32), ("_pad", C.c_int32), ("drop", TecmDrop)]
 
 
+class TecmLnDyMap(C.Structure):
+    _fields_ = [("T", C.c_int32), ("N", C.c_int32), ("drop", TecmDrop)]
+
+
 class TecmAdamW(C.Structure):
     _fields_ = [
         ("n", C.c_int64),
@@ -151,11 +155,11 @@ EXPORTS = {
                                           C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                           C.c_int32, C.c_void_p]),
     "tecm_layernorm_fwd": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_void_p, C.c_int64,
-                                     C.c_void_p, C.c_int64, C.POINTER(TecmDrop),
+                                     C.c_void_p, C.c_int64, C.POINTER(TecmDrop), C.c_int32, C.c_int32,
                                      c_f32p, C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
     "tecm_layernorm_bwd": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p,
                                      C.c_int32, C.POINTER(TecmDrop), c_f32p, C.POINTER(C.c_int32), C.c_int64, C.c_int32,
-                                     C.POINTER(TecmLnAdd), C.c_int32, C.c_void_p]),
+                                     C.POINTER(TecmLnAdd), C.c_int32, C.POINTER(TecmLnDyMap), C.c_void_p]),
     "tecm_attention_fwd": (C.c_int, [c_f32p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                      C.c_int32, C.POINTER(TecmDrop), C.c_void_p]),
     "tecm_cast_bf16": (C.c_int, [c_f32p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),

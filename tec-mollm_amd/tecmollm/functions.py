@@ -60,6 +60,7 @@ class DropPlan:
     p: float
     base_seed: int
     bf16: bool = False      # run the dense contractions on the bf16 matrix cores (autocast semantics)
+    fuse_head: bool = False  # bf16 mode, whole model: ln_f writes the head's operand directly (see GPT2StackFn / HeadFn)
 
     def spec(self, site: int, ld: int):
         if not self.training or self.p <= 0.0:
@@ -682,9 +683,20 @@ class GPT2StackFn(torch.autograd.Function):
             saved += [h, u_s, ud_s, st1, wcat, qkv, h2, st2, a]
             h = h3
         lnfw, lnfb = params[n_layers * GPT2StackFn.PER_LAYER:]
-        out = _empty(B, T, N, D, like=h)
         stf = _empty(M, 2, like=h)
-        ops.layernorm_fwd(h, D, lnfw, lnfb, out, D, stf, M, D)
+        # bf16 mode inside the whole model (plan.fuse_head): ln_f's only reader is F.dropout + the head's first Linear
+        # (tec_mollm.py:115, modules.py:307), a bf16 contraction over view(B*N, T*D).  ln_f then writes exactly that operand:
+        # dropout applied, rounded to bf16, rows in sequence-major order -- no fp32 ln_f output, no dropout pass, no window view
+        # in the head GEMMs; the gradient comes back in the same form and ln_f's backward applies the mask (round 4).
+        ctx.fused = bool(plan.fuse_head) and int(plan.bf16) == ops.PREC_BF16 and D % 8 == 0
+        if ctx.fused:
+            out = torch.empty(B, N, T * D, device=h.device, dtype=torch.bfloat16)
+            pspec = plan.spec(SITE_POST, D)
+            ops.layernorm_fwd(h, D, lnfw, lnfb, None, D, stf, M, D, y16d=out, ldy16d=D,
+                              drop16d=pspec if pspec is not None else ops.NO_DROP, seq_major=(T, N))
+        else:
+            out = _empty(B, T, N, D, like=h)
+            ops.layernorm_fwd(h, D, lnfw, lnfb, out, D, stf, M, D)
         ctx.save_for_backward(h, stf, *saved, *params)
         ctx.meta = (B, T, N, D, n_layers, plan, len(saved))
         return out
@@ -718,7 +730,8 @@ class GPT2StackFn(torch.autograd.Function):
         base_f = 3 + n_layers * GPT2StackFn.PER_LAYER
         dlnfw, dlnfb = ops.layernorm_bwd(dout, D, h_last, D, lnfw, stf, None, dh, M, D,
                                          dx_masked=dhm if sp is not None else None, mask_drop=sp,
-                                         need_dgb=nig[base_f] or nig[base_f + 1])
+                                         need_dgb=nig[base_f] or nig[base_f + 1],
+                                         dy_seq_major=(T, N, plan.spec(SITE_POST, D)) if ctx.fused else None)
         pgrads: List[Optional[torch.Tensor]] = [None] * (n_layers * GPT2StackFn.PER_LAYER)
         for i in reversed(range(n_layers)):
             (ln1w, ln1b, Wqkv, bqkv, lA, lB, Wo, bo, ln2w, ln2b, Wfc, bfc, Wpr,
@@ -798,6 +811,9 @@ class HeadFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, hid, W1, b1, W2, b2, plan: DropPlan):
+        ctx.fused = hid.dim() == 3 and hid.dtype == torch.bfloat16
+        if ctx.fused:
+            return HeadFn._forward_fused(ctx, hid, W1, b1, W2, b2, plan)
         B, T, N, D = hid.shape
         S = B * N
         Hd, K1 = W1.shape
@@ -824,7 +840,54 @@ class HeadFn(torch.autograd.Function):
         return pred
 
     @staticmethod
+    def _forward_fused(ctx, hid, W1, b1, W2, b2, plan: DropPlan):
+        """hid = bf16(F.dropout(ln_f(h))) as the plain (B, N, T*D) matrix GPT2StackFn wrote (plan.fuse_head): every head
+        contraction is a plain one over bf16 tensors -- W1 and W1^T rounded once per step (tecm_weight_bf16)."""
+        B, N, K1 = hid.shape
+        S = B * N
+        Hd = W1.shape[0]
+        Lo = W2.shape[0]
+        hspec = plan.spec(SITE_HEAD, Hd)
+        W1_16, W1T16 = ops.weight_bf16(W1, same=True, transposed=True)
+        pre = _empty(S, Hd, like=hid)
+        h1 = _empty(S, Hd, like=hid)
+        gemm(S, Hd, K1, hid, K1, W1_16, K1, h1, Hd, bias=b1, preact=(pre, Hd), act=ACT_GELU_ERF, out_drop=hspec, bf16=plan.bf16)
+        pred = _empty(B, N, Lo, like=hid)
+        gemm(S, Lo, Hd, h1, Hd, W2, Hd, pred, Lo, bias=b2, bf16=plan.bf16)
+        ctx.save_for_backward(hid, W1, W2, pre, h1)
+        ctx.W1T16 = W1T16
+        ctx.meta = (B, N, K1, Hd, Lo, hspec)
+        ctx.plan = plan
+        return pred
+
+    @staticmethod
+    def _backward_fused(ctx, dpred):
+        hid, W1, W2, pre, h1 = ctx.saved_tensors
+        B, N, K1, Hd, Lo, hspec = ctx.meta
+        plan = ctx.plan
+        S = B * N
+        dpred = dpred.contiguous()
+        db2 = colsum(dpred, Lo, S, 1, 1, Lo)[0]
+        dW2 = _empty(Lo, Hd, like=hid)
+        gemm(Lo, Hd, S, dpred, Lo, h1, Hd, dW2, Hd, a_layout=A_KM, b_layout=B_KN, split_k=pick_split_k(Lo, Hd, S, prec=plan.bf16), bf16=plan.bf16)
+        dpre = _empty(S, Hd, like=hid)
+        gemm(S, Hd, Lo, dpred, Lo, W2, Hd, dpre, Hd, b_layout=B_KN, act=ACT_GELU_ERF, dact_src=(pre, Hd),
+             out_drop=hspec, bf16=plan.bf16)
+        db1 = colsum(dpre, Hd, S, 1, 1, Hd)[0]
+        dp = ops.bf16_twin(dpre, S, Hd)                     # what both contractions round dpre to (db1 sums the fp32 values)
+        dW1 = _empty(Hd, K1, like=hid)
+        gemm(Hd, K1, S, dp, Hd, hid, K1, dW1, K1, a_layout=A_KM, b_layout=B_KN,
+             split_k=pick_split_k(Hd, K1, S, prec=plan.bf16), bf16=plan.bf16)
+        # the gradient a bf16 Linear returns for its input is a bf16 tensor under autocast (train.py:68): stored as such, in
+        # the operand's own (sequence-major) layout; ln_f's backward applies the dropout mask and the layout
+        dhid = torch.empty(B, N, K1, device=hid.device, dtype=torch.bfloat16)
+        gemm(S, K1, Hd, dp, Hd, ctx.W1T16, Hd, dhid, K1, bf16=plan.bf16)
+        return dhid, dW1, db1, dW2, db2, None
+
+    @staticmethod
     def backward(ctx, dpred):
+        if ctx.fused:
+            return HeadFn._backward_fused(ctx, dpred)
         hid, W1, W2, pre, h1 = ctx.saved_tensors
         B, T, N, D, Hd, K1, Lo, w, pspec, hspec = ctx.meta
         plan = ctx.plan

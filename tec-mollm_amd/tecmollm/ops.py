@@ -295,17 +295,20 @@ def pick_split_k(Mo: int, No: int, K: int, target_blocks: int = 512, min_chunk: 
 def layernorm_fwd(x: torch.Tensor, ldx: int, gamma: torch.Tensor, beta: torch.Tensor, y: Optional[torch.Tensor], ldy: int,
                   stats: torch.Tensor, M: int, D: int, eps: float = 1e-5, y_off: int = 0,
                   y16: Optional[torch.Tensor] = None, ldy16: int = 0, y16d: Optional[torch.Tensor] = None, ldy16d: int = 0,
-                  drop16d: Optional[TecmDrop] = None) -> None:
+                  drop16d: Optional[TecmDrop] = None, seq_major: Optional[Tuple[int, int]] = None) -> None:
     """y (fp32) and / or y16 (bf16 copy for a bf16 matrix-core GEMM, BASELINE configs[2]); y16d: a third, optional bf16
-    output = dropout(y, drop16d) rounded -- the LoRA branch's input (peft lora_dropout, modules.py:181)."""
+    output = dropout(y, drop16d) rounded -- the LoRA branch's input (peft lora_dropout, modules.py:181).  seq_major = (T, N):
+    y16d is written sequence-major -- row (b, n, t) for the time-major row (b, t, n) -- the head's view(batch, -1) of ln_f's
+    (dropped) output as a plain matrix; drop16d may then be NO_DROP (eval mode)."""
     for t, what in ((y16, "y16"), (y16d, "y16d")):
         if t is not None and t.dtype != torch.bfloat16:
             raise _lib.TecmError(f"layernorm_fwd: {what} must be a bfloat16 tensor")
     if y16d is not None and drop16d is None:
         raise _lib.TecmError("layernorm_fwd: y16d needs its dropout spec")
+    sT, sN = seq_major if seq_major is not None else (0, 0)
     check(lib().tecm_layernorm_fwd(x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(),
                                    None if y is None else _off(y, y_off), ldy, ptr(y16), ldy16, ptr(y16d), ldy16d,
-                                   C.byref(drop16d) if drop16d is not None else None,
+                                   C.byref(drop16d) if drop16d is not None else None, sT, sN,
                                    stats.data_ptr(), M, D, eps, stream_ptr()), "tecm_layernorm_fwd")
 
 
@@ -323,16 +326,17 @@ def _ln_add(add) -> Optional["_lib.TecmLnAdd"]:
 def layernorm_bwd_blocks(M: int, D: int) -> int:
     nb = C.c_int32(0)
     check(lib().tecm_layernorm_bwd(None, 0, None, 0, None, None, None, None, None, 0, None, None, C.byref(nb), M, D,
-                                   None, 0, None), "tecm_layernorm_bwd(query)")
+                                   None, 0, None, None), "tecm_layernorm_bwd(query)")
     return nb.value
 
 
 def layernorm_bwd(dy: torch.Tensor, lddy: int, x: torch.Tensor, ldx: int, gamma: torch.Tensor, stats: torch.Tensor,
                   dres: Optional[torch.Tensor], dx: torch.Tensor, M: int, D: int,
                   dx_masked: Optional[torch.Tensor] = None,
-                  mask_drop: Optional[TecmDrop] = None, need_dgb: bool = True, add=None):
+                  mask_drop: Optional[TecmDrop] = None, need_dgb: bool = True, add=None, dy_seq_major=None):
     """dx = dres + LN'(dy); optional dx_masked = dropout(dx, mask_drop) -- fp32, or bf16 when its only reader is a bf16
-    GEMM.  dy: fp32 or bf16.  add = (dy2, ld, drop): a second gradient stream of the same tensor, dy += dropmask * dy2 before
+    GEMM.  dy: fp32 or bf16.  dy_seq_major = (T, N, drop spec or None): dy is the bf16 sequence-major matrix (rows (b, n, t))
+    the head's first Linear returned, still in front of the post-LLM dropout whose mask is applied here.  add = (dy2, ld, drop): a second gradient stream of the same tensor, dy += dropmask * dy2 before
     the LayerNorm backward (the LoRA branch's input gradient through lora_dropout's backward).  Returns (dgamma, dbeta), or
     (None, None) when need_dgb is False (frozen LayerNorm: the per-block partials are not reduced)."""
     m16 = 1 if (dx_masked is not None and dx_masked.dtype == torch.bfloat16) else 0
@@ -342,9 +346,14 @@ def layernorm_bwd(dy: torch.Tensor, lddy: int, x: torch.Tensor, ldx: int, gamma:
     partials = torch.empty(nb, 2 * D, device=dx.device, dtype=torch.float32)
     nbc = C.c_int32(0)
     od = mask_drop if mask_drop is not None else NO_DROP
+    dm = None
+    if dy_seq_major is not None:
+        mT, mN, mdrop = dy_seq_major
+        dm = _lib.TecmLnDyMap(T=mT, N=mN, drop=mdrop if mdrop is not None else NO_DROP)
     check(lib().tecm_layernorm_bwd(dy.data_ptr(), lddy, x.data_ptr(), ldx, gamma.data_ptr(), stats.data_ptr(),
                                    ptr(dres), dx.data_ptr(), ptr(dx_masked), m16, C.byref(od), partials.data_ptr(),
-                                   C.byref(nbc), M, D, C.byref(ad) if ad is not None else None, dy16, stream_ptr()),
+                                   C.byref(nbc), M, D, C.byref(ad) if ad is not None else None, dy16,
+                                   C.byref(dm) if dm is not None else None, stream_ptr()),
           "tecm_layernorm_bwd")
     if not need_dgb:
         return None, None

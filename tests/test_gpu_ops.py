@@ -250,6 +250,41 @@ def test_layernorm_fwd_dropped_bf16_output_is_the_lora_branch_input(dev, M):
     assert torch.equal(y16b[:, :D], y16[:, :D]) and torch.equal(y16db, y16d)
 
 
+@pytest.mark.parametrize("B,T,N,p", [(2, 3, 211, 0.1), (1, 6, 37, 0.1), (3, 3, 5, 0.0)])
+def test_layernorm_sequence_major_dropped_output_and_its_gradient(dev, B, T, N, p):
+    """ln_f -> F.dropout -> PredictionHead.view(batch, -1) (tec_mollm.py:115, modules.py:307) without a pass of its own:
+    tecm_layernorm_fwd writes bf16(dropout(LN(x))) with row (b, t, n) at row (b, n, t), and tecm_layernorm_bwd takes the
+    bf16 gradient of that matrix in the same layout and applies the mask (index = the time-major one) itself.  Against the
+    plain kernels fed a permuted / pre-masked tensor, bit for bit."""
+    from tecmollm import ops, rng
+    D = 768
+    M = B * T * N
+    x = _rand(M, D, dev=dev, seed=1)
+    g, b = 1 + 0.1 * _rand(D, dev=dev, seed=2), 0.1 * _rand(D, dev=dev, seed=3)
+    st, st2 = torch.empty(M, 2, device=dev), torch.empty(M, 2, device=dev)
+    spec = ops.drop(p, 777, D) if p > 0 else ops.NO_DROP
+    seq = torch.empty(B, N, T * D, device=dev, dtype=torch.bfloat16)
+    ops.layernorm_fwd(x, D, g, b, None, D, st, M, D, y16d=seq, ldy16d=D, drop16d=spec, seq_major=(T, N))
+    y = torch.empty(M, D, device=dev)
+    ops.layernorm_fwd(x, D, g, b, y, D, st2, M, D)
+    idx = np.arange(M * D, dtype=np.uint64).reshape(M, D)
+    mult = torch.from_numpy(rng.keep_mult(777, idx, p)).to(dev) if p > 0 else torch.ones(M, D, device=dev)
+    want = (y * mult).bfloat16().view(B, T, N, D).permute(0, 2, 1, 3).reshape(B, N, T * D)
+    assert torch.equal(seq, want) and torch.equal(st, st2)
+    # backward
+    dseq = _rand(B, N, T * D, dev=dev, seed=4).bfloat16()
+    dres = _rand(M, D, dev=dev, seed=5)
+    dx, dxm = torch.empty(M, D, device=dev), torch.empty(M, D, device=dev, dtype=torch.bfloat16)
+    dg, db = ops.layernorm_bwd(dseq, D, x, D, g, st, dres, dx, M, D, dx_masked=dxm, mask_drop=ops.drop(0.1, 7, D),
+                               dy_seq_major=(T, N, spec if p > 0 else None))
+    dy_tm = dseq.view(B, N, T, D).permute(0, 2, 1, 3).reshape(M, D).float() * mult          # what the kernel forms (fp32)
+    dx_r, dxm_r = torch.empty_like(dx), torch.empty_like(dxm)
+    dg_r, db_r = ops.layernorm_bwd(dy_tm.contiguous(), D, x, D, g, st, dres, dx_r, M, D, dx_masked=dxm_r, mask_drop=ops.drop(0.1, 7, D))
+    assert torch.equal(dx, dx_r) and torch.equal(dxm, dxm_r) and torch.equal(dg, dg_r) and torch.equal(db, db_r)
+    with pytest.raises(ops._lib.TecmError):               # the remapped dy is a bf16 matrix
+        ops.layernorm_bwd(dseq.float(), D, x, D, g, st, dres, dx, M, D, dy_seq_major=(T, N, None))
+
+
 @pytest.mark.parametrize("M,dt", [(1000, torch.float32), (1000, torch.bfloat16), (37, torch.float32), (4099, torch.bfloat16)])
 def test_layernorm_bwd_adds_a_masked_second_gradient_stream(dev, M, dt):
     """tecm_layernorm_bwd with TecmLnAdd: dy += dropmask * dy2 before the LayerNorm backward -- the gradient peft's LoRA

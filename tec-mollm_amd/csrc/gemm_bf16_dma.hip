@@ -92,9 +92,18 @@ __global__ __launch_bounds__(DNTH, 1) void gemm_bf16_dma_kernel(const TecmGemm g
     gm = gm < g.M ? gm : g.M - 1;                      // clamped rows feed accumulator rows that are never stored
     int64_t gn = n0 + row;
     gn = gn < g.N ? gn : g.N - 1;
+    if (g.a_win.enabled) {                             // pad-free window view (host-checked): tap 0 of row (bq, t_out, n)
+      const int64_t bt = gm / g.a_win.N, n = gm - bt * g.a_win.N;
+      const int64_t bq = bt / g.a_win.Lout, to = bt - bq * g.a_win.Lout;
+      gm = (bq * g.a_win.Lin + to * g.a_win.stride_t) * g.a_win.N + n;
+    }
     asrc[i] = Ah + gm * g.lda + chunk * 8;
     bsrc[i] = Bh + gn * g.ldb + chunk * 8;
   }
+  // a window view's K runs tap by tap: after Cw / 64 K-tiles the source row moves one time step (N rows) on
+  const int tiles_per_tap = g.a_win.enabled ? g.a_win.Cw / DBK : 0x7fffffff;
+  const int64_t tap_jump = g.a_win.enabled ? (int64_t)g.a_win.N * g.lda - g.a_win.Cw : 0;
+  int tap_tile = 0;
   auto issue_tile = [&](__bf16* buf, bool tail) {
     __bf16* a_dst = buf + (wave * 4) * PIECE;
     __bf16* b_dst = buf + A_ELEMS + (wave * 4) * PIECE;
@@ -109,6 +118,11 @@ __global__ __launch_bounds__(DNTH, 1) void gemm_bf16_dma_kernel(const TecmGemm g
       }
       asrc[i] += DBK;
       bsrc[i] += DBK;
+    }
+    if (++tap_tile == tiles_per_tap) {
+      tap_tile = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asrc[i] += tap_jump;
     }
   };
 
@@ -1045,6 +1059,18 @@ int tecm_gemm16_dma_try(const TecmGemm& g, hipStream_t st) {
   const bool both = (g.io_bf16 & TECM_IO_A_BF16) && (g.io_bf16 & TECM_IO_B_BF16);
   if (!both || !(g.io_bf16 & TECM_P0_VEC4) || g.split_k > 1 || g.K % 32 != 0 || g.K < DBK || g.M < DBM || g.N < DBN / 2)
     return 0;
+  if (g.a_win.enabled) {
+    // a pad-free window view of A whose taps are whole K-tiles (the patch projection's 'b (p l) d -> b p (l d)',
+    // modules.py:114): served by the first geometry, whose source pointers move one time step on at every tap boundary
+    const TecmWin& w = g.a_win;
+    if (g.b_win.enabled || w.pad != 0 || w.Cw % DBK != 0 || (int64_t)(w.Lout - 1) * w.stride_t + w.taps > w.Lin ||
+        g.M % ((int64_t)w.Lout * w.N) != 0)
+      return 0;
+    const int wtm = (int)((g.M + DBM - 1) / DBM), wtn = (int)((g.N + DBN - 1) / DBN);
+    hipLaunchKernelGGL(gemm_bf16_dma_kernel, dim3((unsigned)(wtm * wtn)), dim3(DNTH), 0, st, g, wtm, wtn);
+    TECM_CHECK_LAUNCH("tecm_gemm_bf16/dma-window");
+    return 1;
+  }
   // the 128-column geometry where the 256-column tile would waste more than half of its last n-tile (N = 800);
   // TECM_BF16_DMA = 1 / 2 forces one of the two (A/B diagnostics, tools/dma_ab.sh)
   const int nrem = (int)(g.N % DBN);

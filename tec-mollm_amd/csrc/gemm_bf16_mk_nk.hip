@@ -8,6 +8,10 @@ int tecm_gemm16_res_a_mk_nk(const TecmGemm& g, hipStream_t st);  // gemm_bf16_re
 
 int tecm_gemm16_dispatch_mk_nk(const TecmGemm& g, bool win, bool drop, hipStream_t st) {
   const bool a16 = g.io_bf16 & TECM_IO_A_BF16, b16 = g.io_bf16 & TECM_IO_B_BF16;
+  if (win && a16 && b16 && !drop && g.a_win.enabled && !g.b_win.enabled) {
+    const int served = tecm_gemm16_dma_try(g, st);      // pad-free window views whose taps are whole K-tiles
+    if (served != 0) return served;
+  }
   if (win && (a16 || b16)) {
     TECM_REQUIRE(a16 && !b16 && !g.b_win.enabled, TECM_E_ARG,
                  "tecm_gemm_bf16: MK x NK with a window serves a bf16 A only (B fp32, no b_win)");

@@ -461,7 +461,13 @@ class PatchEmbedFn(torch.autograd.Function):
         w = win(N, Lc, P, patch_len, patch_len, D, 0)
         dspec = plan.spec(SITE_EMBD, d_llm) if wpe is not None else None
         a_in = conv16 if (conv16 is not None and int(plan.bf16) == ops.PREC_BF16 and D % 8 == 0) else conv
-        gemm(M, d_llm, K, a_in, D, Wp, K, h0, d_llm, a_win=w, bias=bp,
+        # bf16 operands + taps that are whole 64-wide K-tiles inside the sequence: the LDS-DMA kernel walks the window view
+        # itself; it takes the weight as a bf16 tensor too (W and, for the backward, W^T rounded: one launch)
+        ctx.WpT16 = None
+        Wf = Wp
+        if a_in.dtype == torch.bfloat16 and D % 64 == 0 and P * patch_len == Lc and M >= 256 and d_llm >= 128:
+            Wf, ctx.WpT16 = ops.weight_bf16(Wp, same=True, transposed=True)
+        gemm(M, d_llm, K, a_in, D, Wf, K, h0, d_llm, a_win=w, bias=bp,
              rowbias=(wpe, wpe.shape[1], N, P) if wpe is not None else None, out_drop=dspec, bf16=plan.bf16)
         # the weight gradient contracts the same tensor the forward read: the bf16 copy in bf16 mode (what its loader would
         # round the fp32 one to), at half the bytes and in the form the LDS-DMA kernel takes
@@ -507,7 +513,7 @@ class PatchEmbedFn(torch.autograd.Function):
             dconv.zero_()
         if dh16 is not None and K % 8 == 0:
             # W^T rounded to bf16 ([K][d_llm], one tiny launch): both operands [row][k] bf16 tensors -> the LDS-DMA kernel
-            WpT16 = ops.weight_bf16(Wp, same=False, transposed=True)[1]
+            WpT16 = ctx.WpT16 if ctx.WpT16 is not None else ops.weight_bf16(Wp, same=False, transposed=True)[1]
             gemm(M, K, d_llm, dh16, d_llm, WpT16, d_llm, dconv, D, c_win=w, bf16=plan.bf16)
         else:
             gemm(M, K, d_llm, dg, d_llm, Wp, K, dconv, D, b_layout=B_KN, c_win=w, bf16=plan.bf16)

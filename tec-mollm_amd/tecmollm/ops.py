@@ -199,6 +199,10 @@ def _kernel_name(g: TecmGemm, use16: bool = False) -> str:
         if (g.io_bf16 & (IO_A_BF16 | IO_B_BF16)) and not (g.a_layout == A_MK and g.b_layout == B_NK and win16 == "false"):
             win16 = "true"                             # the bf16-resident window / transposed instances are built WIN = true
         both16 = (g.io_bf16 & IO_A_BF16) and (g.io_bf16 & IO_B_BF16)
+        if (both16 and g.a_layout == A_MK and g.b_layout == B_NK and g.a_win.enabled and not g.b_win.enabled and drp16 == "false"
+                and g.a_win.pad == 0 and g.a_win.Cw % 64 == 0 and g.split_k <= 1 and g.M >= 256 and g.N >= 128
+                and os.environ.get("TECM_BF16_DMA", "")[:1] != "0"):
+            return "gemm_bf16_dma_kernel"                  # the window route of tecm_gemm16_dma_try
         # mirrors tecm_gemm16_dma_try (csrc/gemm_bf16_dma.hip); the float4-epilogue condition holds for every bf16 call
         sel = os.environ.get("TECM_BF16_DMA", "")[:1]
         if (both16 and g.split_k <= 1 and g.N % 4 == 0 and g.K % 32 == 0 and g.K >= 64 and g.M >= 256 and g.N >= 128

@@ -551,3 +551,35 @@ def test_bf16_weight_gradient_natural_orientation_kernel(dev, Mo, No, rows, bwin
         assert _rel(C, ref) < TOL, (tn, split)
         outs[(tn, split)] = C
     assert _rel(outs[("1", want)], outs[("0", want)]) < 1e-5
+
+
+@pytest.mark.parametrize("Bq,Lin,N,taps,Cw,Nout", [(2, 12, 211, 4, 128, 768), (1, 8, 300, 2, 64, 256)])
+def test_bf16_dma_kernel_walks_a_window_view_of_a(dev, Bq, Lin, N, taps, Cw, Nout):
+    """The patch projection 'b (p l) d -> b p (l d)' + Linear (modules.py:114-116) with bf16 operands: the first LDS-DMA
+    geometry moves its A source pointers one time step on at every tap boundary.  Against fp64 on the bf16 values and the
+    register-staged kernel fed an fp32 copy of the same (already rounded) weight, generic epilogue (row bias + dropout)."""
+    from tecmollm import ops
+    Lout = Lin // taps
+    M, K = Bq * Lout * N, taps * Cw
+    src = _rand(Bq, Lin, N, Cw, dev=dev, seed=21).bfloat16()
+    W = _rand(Nout, K, dev=dev, seed=22, scale=0.05)
+    W16 = W.bfloat16()
+    bias = _rand(Nout, dev=dev, seed=23)
+    wpe = _rand(Lout, Nout, dev=dev, seed=24)
+    w = ops.win(N, Lin, Lout, taps, taps, Cw, 0)
+    spec = ops.drop(0.1, 4242, Nout)
+    outs = []
+    for Wop in (W16, W16.float()):
+        C = torch.full((M, Nout), float("nan"), device=dev)
+        rec = ops.enable_gemm_timing(detail=True)
+        ops.gemm(M, Nout, K, src, Cw, Wop, K, C, Nout, a_win=w, bias=bias, rowbias=(wpe, Nout, N, Lout), out_drop=spec, bf16=True)
+        names = list(ops.summarize_gemm_timing(rec))
+        ops.disable_gemm_timing()
+        assert ("gemm_bf16_dma_kernel" in names[0]) == (Wop.dtype == torch.bfloat16), names
+        outs.append(C)
+    A = src.view(Bq, Lout, taps, N, Cw).permute(0, 1, 3, 2, 4).reshape(M, K).double()
+    ref = A @ W16.double().t() + bias.double() + wpe.double().repeat_interleave(N, 0).repeat(Bq, 1)
+    from tecmollm import rng
+    mult = torch.from_numpy(rng.keep_mult(4242, np.arange(M * Nout, dtype=np.uint64).reshape(M, Nout), 0.1)).to(dev).double()
+    assert _rel(outs[0], ref * mult) < TOL and _rel(outs[1], ref * mult) < TOL
+    assert _rel(outs[0], outs[1]) < 1e-6

@@ -207,6 +207,9 @@ int tecm_spatial_bwd_blocks(const TecmSpatial* d);
  * y_bf16): forward with TECM_GN_OUT_BF16, backward with TECM_GN_OUT_BF16 | TECM_GN_DACT_BF16 -- every tensor bf16, statistics
  * and arithmetic fp32.  Served for L * 3*Cout/8 <= 2304 (tecm_gn_y16_supported). */
 #define TECM_GN_Y_BF16 1
+/* forward only, with TECM_GN_Y_BF16 | TECM_GN_OUT_BF16: `stats` is an INPUT -- the (mean, rstd) tecm_conv_fwd_bf16 computed from
+ * the rounded y it produced (TecmConvFwd::stats); the norm + GELU then is elementwise over the time steps act keeps. */
+#define TECM_GN_STATS_GIVEN 8
 int tecm_gn_y16_supported(int32_t L, int32_t N, int32_t Cout);
 /* act_stride s >= 1: only the time steps t % s == 0 are written, into a COMPACT (B, ceil(L / s), N, CT) tensor -- the
  * stride-s 1x1 conv behind the block (modules.py:36-41) reads nothing else; the statistics cover every step.  s > 1 is
@@ -332,6 +335,11 @@ typedef struct TecmConvFwd {
   float* y;                    /* fp32; y_bf16 != 0 (tecm_conv_fwd_bf16 only): a bf16 (B, Lc, N, 3*Cout) tensor -- what a bf16
                                   Conv1d returns under autocast (train.py:68), read by the TECM_GN_Y_BF16 norm kernels */
   int32_t B, Lc, N, Cout, ld_in, y_bf16;
+  float* stats;                /* optional (tecm_conv_fwd_bf16 with y_bf16, Lc <= 48): (B*N, 3, 2) = mean, rstd of GroupNorm(1, Cout)
+                                  (modules.py:28) per sequence and branch, from the ROUNDED y the kernel holds in registers -- the
+                                  norm forward then is elementwise (TECM_GN_STATS_GIVEN).  NULL: not computed */
+  float eps;                   /* GroupNorm eps (1e-5) */
+  int32_t _pad;
 } TecmConvFwd;
 int tecm_conv_fwd_pack(const float* w3, const float* w5, const float* w7, void* wpack, int32_t Cout, int32_t Cin,
                        int32_t ld_in, void* stream);

@@ -448,6 +448,8 @@ struct FArgs {
   const float* bias;           // [3 * Cout]: b3 | b5 | b7
   float* y;                    // fp32 (B, Lc, N, 3 * Cout) -- or bf16 when y16 (the bf16 kernel only)
   int y16;
+  float* stats;                // y16 and whole sequences per tile: GroupNorm(1) statistics (B*N, 3, 2) of the rounded y
+  float eps;
   int B, Lc, N, Cout, ld_in, TC, nchunk, nblk, pitch;
   int nb32;                    // Cout / 32: unit u = (kernel size j = u / nb32, channel block u % nb32)
   unsigned long long assign;   // 4 waves x 3 unit ids of 4 bits (15 = none): no kernel-argument arrays -- indexing
@@ -486,6 +488,12 @@ __global__ __launch_bounds__(NTH, 2) void conv_fwd_seq_kernel(const FArgs a) {
   const int ntt = tc >> 3;
   const int cpt = a.ld_in / 8;                             // chunks per tap
   const unsigned cpt_magic = (unsigned)((65536 + cpt - 1) / cpt);      // q / cpt for q < 256
+  // GroupNorm statistics of this wave's units, per (branch, node): (count, mean, M2), merged with Chan's rule
+  float rcnt[3] = {0.f, 0.f, 0.f}, rmean[3][NB], rm2[3][NB];
+#pragma unroll
+  for (int jb = 0; jb < 3; ++jb)
+#pragma unroll
+    for (int n = 0; n < NB; ++n) rmean[jb][n] = rm2[jb][n] = 0.f;
 #pragma unroll 1
   for (int ui = 0; ui < 3; ++ui) {
     const int u = (int)((a.assign >> (12 * wave + 4 * ui)) & 15ull);
@@ -558,6 +566,44 @@ __global__ __launch_bounds__(NTH, 2) void conv_fwd_seq_kernel(const FArgs a) {
     //      (e & 3) + 8 (e >> 2) + 4 h of its row tile, i.e. time step 8 i + 2 (e >> 2) + h, node e & 3
     const float bv = a.bias[col0 + r];
     const int tstride = a.N * CT;                          // one time step, in elements (a tile spans < 2^31 of them)
+    if (a.stats) {
+      // statistics of the values as stored (rounded to bf16), two passes over the registers: unit mean, then squared
+      // deviations; lane (channel, h) holds node e & 3 at 4 * ntt time steps
+      float sm[NB] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < MAXT; ++i)
+        if (i < ntt) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) sm[e & 3] += (float)(__bf16)(acc[i][e] + bv);
+        }
+      const float ucnt = (float)(32 * tc);
+      float um[NB], uq[NB] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int n = 0; n < NB; ++n) um[n] = wave_sum(sm[n]) / ucnt;
+#pragma unroll
+      for (int i = 0; i < MAXT; ++i)
+        if (i < ntt) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const float dv = (float)(__bf16)(acc[i][e] + bv) - um[e & 3];
+            uq[e & 3] += dv * dv;
+          }
+        }
+#pragma unroll
+      for (int n = 0; n < NB; ++n) uq[n] = wave_sum(uq[n]);
+#pragma unroll
+      for (int jb = 0; jb < 3; ++jb)
+        if (jb == j) {                                     // wave-uniform
+          const float tot = rcnt[jb] + ucnt, fr = ucnt / tot;
+#pragma unroll
+          for (int n = 0; n < NB; ++n) {
+            const float dl = um[n] - rmean[jb][n];
+            rm2[jb][n] += uq[n] + dl * dl * rcnt[jb] * fr;
+            rmean[jb][n] += dl * fr;
+          }
+          rcnt[jb] = tot;
+        }
+    }
     if (a.y16) {
       // y as the bf16 tensor a bf16 Conv1d produces under autocast (train.py:68): neighbouring lanes (channels c, c + 1)
       // trade one value per register pair, so that the even lane stores (c, c + 1) of node e0 & 3 and the odd lane
@@ -592,6 +638,39 @@ __global__ __launch_bounds__(NTH, 2) void conv_fwd_seq_kernel(const FArgs a) {
           const int n = e & 3;
           if (n0 + n < a.N) yb[(8 * i + 2 * (e >> 2)) * tstride + n * CT] = acc[i][e] + bv;
         }
+      }
+    }
+  }
+  if (a.stats) {
+    // the four waves' (count, mean, M2) per (branch, node) meet in a fixed order: bit-reproducible statistics
+    __shared__ float xst[4][3][NB][3];
+    if (lane == 0) {
+#pragma unroll
+      for (int jb = 0; jb < 3; ++jb)
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+          xst[wave][jb][n][0] = rcnt[jb];
+          xst[wave][jb][n][1] = rmean[jb][n];
+          xst[wave][jb][n][2] = rm2[jb][n];
+        }
+    }
+    __syncthreads();
+    if (tid < 3 * NB) {
+      const int jb = tid / NB, n = tid % NB;
+      float cnt = 0.f, mean = 0.f, m2 = 0.f;
+      for (int w = 0; w < 4; ++w) {
+        const float c2 = xst[w][jb][n][0];
+        if (c2 > 0.f) {
+          const float tot = cnt + c2, fr = c2 / tot, dl = xst[w][jb][n][1] - mean;
+          m2 += xst[w][jb][n][2] + dl * dl * cnt * fr;
+          mean += dl * fr;
+          cnt = tot;
+        }
+      }
+      if (n0 + n < a.N) {
+        float* st = a.stats + (((int64_t)b * a.N + n0 + n) * 3 + jb) * 2;
+        st[0] = mean;
+        st[1] = 1.0f / sqrtf(m2 / cnt + a.eps);
       }
     }
   }
@@ -804,12 +883,16 @@ static int conv_fwd_launch(const TecmConvFwd* p, void* stream, bool f32, const c
   a.bias = p->bias;
   a.y = p->y;
   a.y16 = p->y_bf16 != 0;
+  a.stats = p->stats;
+  a.eps = p->eps;
   TECM_REQUIRE(!(a.y16 && f32), TECM_E_ARG, "%s: a bf16 y is written by the bf16 kernel only", who);
   TECM_REQUIRE(!a.y16 || tecm_aligned(p->y, 4), TECM_E_ALIGN, "%s: y must be 4-byte aligned", who);
   a.B = p->B; a.Lc = p->Lc; a.N = p->N; a.Cout = p->Cout; a.ld_in = p->ld_in;
   const size_t lds = conv_fwd_lds(p->Lc, p->ld_in, f32, &a.pitch, &a.TC);
   a.nchunk = (p->Lc + a.TC - 1) / a.TC;
   a.nblk = (p->N + NB - 1) / NB;
+  TECM_REQUIRE(!a.stats || (a.y16 && !f32 && a.nchunk == 1 && p->eps > 0.f), TECM_E_ARG,
+               "%s: GroupNorm statistics come with a bf16 y and sequences of at most %d steps (one tile per sequence)", who, a.TC);
   TECM_REQUIRE(lds <= 64 * 1024, TECM_E_LDS, "%s: %zu B of LDS per tile", who, lds);
   // units (kernel size j, 32-channel block), longest first, each to the least loaded wave
   const int nb32 = p->Cout / 32;

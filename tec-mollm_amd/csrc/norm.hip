@@ -1094,6 +1094,33 @@ int gn16_ng(int L, int N, int Cout, const void* a, const void* b) {
   if (octs <= 384 * 6) return 6;
   return 0;
 }
+// GroupNorm(1) + GELU forward with the statistics GIVEN (conv_fwd_seq computes them from the y it holds in registers): what is
+// left is elementwise and needs only the time steps the strided 1x1 conv reads -- one oct (8 channels) per lane per visit,
+// every access a 16-byte one, no sequence held anywhere, no synchronisation.  act is the compact (B, L / stride, N, CT) tensor.
+__global__ __launch_bounds__(256) void gn_apply_fwd16_kernel(const void* __restrict__ y, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, void* __restrict__ act,
+                                                             const float* __restrict__ stats, int B, int L, int N, int Cout,
+                                                             int stride) {
+  const int CT = 3 * Cout, OPR = CT / 8;                       // octs per row
+  const int Lo = (L + stride - 1) / stride;
+  const int64_t total = (int64_t)B * Lo * N * OPR;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int o = (int)(i % OPR);
+    const int64_t row = i / OPR;                               // (b, to, n)
+    const int n = (int)(row % N);
+    const int64_t bt = row / N;
+    const int to = (int)(bt % Lo), b = (int)(bt / Lo);
+    const int c = o * 8, br = c / Cout;
+    const float2 ms = *reinterpret_cast<const float2*>(stats + (((int64_t)b * N + n) * 3 + br) * 2);
+    const f32x8 v = gn_ld8(y, (((int64_t)b * L + (int64_t)to * stride) * N + n) * CT + c);
+    const f32x8 g = gn_ld8f(gamma + c), be = gn_ld8f(beta + c);
+    f32x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = gelu_erf_fast((v[e] - ms.x) * ms.y * g[e] + be[e]);
+    gn_st8(act, row * CT + c, r);
+  }
+}
+
 int gn_blocks(int64_t S) {
   const int64_t want = (S + 3) / 4;
   return (int)(want < 1024 ? want : 1024);
@@ -1204,9 +1231,22 @@ extern "C" int tecm_groupnorm_gelu_fwd(const void* y_, const float* gamma, const
                                        int32_t io_bf16, int32_t act_stride, void* stream) {
   const float* y = reinterpret_cast<const float*>(y_);
   float* act = reinterpret_cast<float*>(act_);
-  TECM_REQUIRE(io_bf16 == 0 || io_bf16 == TECM_GN_OUT_BF16 || io_bf16 == (TECM_GN_OUT_BF16 | TECM_GN_Y_BF16), TECM_E_ARG,
-               "tecm_groupnorm_gelu_fwd: io_bf16 is 0, TECM_GN_OUT_BF16 or TECM_GN_OUT_BF16 | TECM_GN_Y_BF16");
+  TECM_REQUIRE(io_bf16 == 0 || io_bf16 == TECM_GN_OUT_BF16 || io_bf16 == (TECM_GN_OUT_BF16 | TECM_GN_Y_BF16) ||
+                   io_bf16 == (TECM_GN_OUT_BF16 | TECM_GN_Y_BF16 | TECM_GN_STATS_GIVEN),
+               TECM_E_ARG, "tecm_groupnorm_gelu_fwd: io_bf16 is 0, OUT_BF16, OUT_BF16 | Y_BF16 or the latter | STATS_GIVEN");
   TECM_REQUIRE(act_stride >= 1, TECM_E_ARG, "tecm_groupnorm_gelu_fwd: act_stride must be at least 1");
+  if (io_bf16 & TECM_GN_STATS_GIVEN) {                   // elementwise: the statistics were computed by tecm_conv_fwd_bf16
+    TECM_REQUIRE(y_ && gamma && beta && act_ && stats, TECM_E_ARG, "tecm_groupnorm_gelu_fwd: null pointer");
+    TECM_REQUIRE(B > 0 && L > 0 && N > 0 && Cout > 0 && Cout % 8 == 0 && tecm_aligned(y_, 16) && tecm_aligned(act_, 16) &&
+                     tecm_aligned(gamma, 16) && tecm_aligned(beta, 16) && tecm_aligned(stats, 8),
+                 TECM_E_ARG, "tecm_groupnorm_gelu_fwd: the elementwise form needs Cout %% 8 == 0 and 16-byte aligned tensors");
+    const int64_t octs = (int64_t)B * ((L + act_stride - 1) / act_stride) * N * (3 * Cout / 8);
+    const int64_t want = (octs + 255) / 256;
+    hipLaunchKernelGGL(gn_apply_fwd16_kernel, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, (hipStream_t)stream, y_,
+                       gamma, beta, act_, stats, B, L, N, Cout, (int)act_stride);
+    TECM_CHECK_LAUNCH("tecm_groupnorm_gelu_fwd/apply16");
+    return TECM_OK;
+  }
   const bool io16 = (io_bf16 & TECM_GN_OUT_BF16) != 0;
   if (io_bf16 & TECM_GN_Y_BF16) {                        // every tensor bf16: the oct kernels
     TECM_REQUIRE(y_ && gamma && beta && act_ && stats, TECM_E_ARG, "tecm_groupnorm_gelu_fwd: null pointer");

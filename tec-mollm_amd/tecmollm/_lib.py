@@ -131,7 +131,7 @@ class TecmConvDw(C.Structure):
 class TecmConvFwd(C.Structure):
     _fields_ = [("inp", C.c_void_p), ("wpack", C.c_void_p), ("bias", c_f32p), ("y", c_f32p),
                 ("B", C.c_int32), ("Lc", C.c_int32), ("N", C.c_int32), ("Cout", C.c_int32), ("ld_in", C.c_int32),
-                ("y_bf16", C.c_int32)]
+                ("y_bf16", C.c_int32), ("stats", c_f32p), ("eps", C.c_float), ("_pad", C.c_int32)]
 
 
 TECM_NORM_BLOCKS = 512

@@ -316,8 +316,13 @@ class ConvBlockFn(torch.autograd.Function):
         # bias | gamma | beta of the three branches as the 3*Cout vectors the kernels read: one launch, not three cats
         bgb = ops.pack_vectors([b3, b5, b7, g3, g5, g7, be3, be5, be7])
         bias3, gamma, beta = bgb[:CT], bgb[CT:2 * CT], bgb[2 * CT:]
+        # ... and the kernel that produces the bf16 y also has every sequence whole in its registers: it hands over the
+        # GroupNorm statistics, and the norm + GELU forward is an elementwise pass over the time steps act keeps
+        stats = _empty(B * N, 3, 2, like=inp)
+        st_given = y16 and ops.conv_fwd_stats_ok(Lc)
         if fwd_seq:
-            ops.conv_fwd(seq_in.detach(), w3.detach(), w5.detach(), w7.detach(), bias3, y, B, Lc, N, Cout, cin, ld_in)
+            ops.conv_fwd(seq_in.detach(), w3.detach(), w5.detach(), w7.detach(), bias3, y, B, Lc, N, Cout, cin, ld_in,
+                         stats=stats if st_given else None)
         # the window-GEMM operands ([Cout][k*ld_in] forward, [k*Cout][ld_in] d-input) are only packed when a GEMM will read
         # them: the forward below, or a backward whose sequence-tile kernels do not serve this shape / precision
         dx_gemm = need_dinp and not ConvBlockFn._dx_seq(bf16, r16, Lc, Cout, ld_in)
@@ -341,8 +346,8 @@ class ConvBlockFn(torch.autograd.Function):
         compact = stride > 1 and ops.gn_reg_ok(Lc, N, Cout) and int(bf16) in (ops.PREC_FP32, ops.PREC_BF16)
         La = Lo if compact else Lc
         act = torch.empty(B, La, N, CT, device=inp.device, dtype=adt)
-        stats = _empty(B * N, 3, 2, like=inp)
-        ops.groupnorm_gelu_fwd(y, gamma, beta, act, stats, B, Lc, N, Cout, act_stride=stride if compact else 1)
+        ops.groupnorm_gelu_fwd(y, gamma, beta, act, stats, B, Lc, N, Cout, act_stride=stride if compact else 1,
+                               stats_given=st_given)
         out = _empty(B, Lo, N, Cout, like=inp)
         wf2 = wf.view(Cout, CT)
         out16 = None

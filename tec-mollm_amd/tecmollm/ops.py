@@ -394,15 +394,26 @@ def gn_y16_ok(L: int, N: int, Cout: int) -> bool:
     return os.environ.get("TECM_Y16", "1")[:1] != "0" and lib().tecm_gn_y16_supported(L, N, Cout) == 1
 
 
+GN_STATS_GIVEN = 8
+
+
 def groupnorm_gelu_fwd(y: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, act: torch.Tensor,
-                       stats: torch.Tensor, B: int, L: int, N: int, Cout: int, eps: float = 1e-5, act_stride: int = 1) -> None:
+                       stats: torch.Tensor, B: int, L: int, N: int, Cout: int, eps: float = 1e-5, act_stride: int = 1,
+                       stats_given: bool = False) -> None:
     """act: fp32, or bf16 in bf16 mode (its dtype says which); y is fp32.  act_stride s > 1: act is the COMPACT
-    (B, ceil(L / s), N, 3*Cout) tensor of the time steps t % s == 0 (all the stride-s 1x1 conv behind it reads)."""
+    (B, ceil(L / s), N, 3*Cout) tensor of the time steps t % s == 0 (all the stride-s 1x1 conv behind it reads).
+    stats_given (all-bf16 form only): `stats` already holds (mean, rstd) -- conv_fwd(..., stats=) computed them from the y it
+    wrote -- and the call is an elementwise pass over the time steps act keeps."""
     La = (L + act_stride - 1) // act_stride
     if act.numel() != B * La * N * 3 * Cout:
         raise _lib.TecmError(f"groupnorm_gelu_fwd: act must hold (B, {La}, N, 3*Cout) values for act_stride {act_stride}")
+    io = _gn_io(y, act)
+    if stats_given:
+        if io != (GN_Y_BF16 | GN_OUT_BF16):
+            raise _lib.TecmError("groupnorm_gelu_fwd: given statistics go with a bf16 y and a bf16 act")
+        io |= GN_STATS_GIVEN
     check(lib().tecm_groupnorm_gelu_fwd(y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), act.data_ptr(),
-                                        stats.data_ptr(), B, L, N, Cout, eps, _gn_io(y, act), act_stride, stream_ptr()),
+                                        stats.data_ptr(), B, L, N, Cout, eps, io, act_stride, stream_ptr()),
           "tecm_groupnorm_gelu_fwd")
 
 
@@ -661,8 +672,14 @@ def conv_fwd_seq_ok(Lc: int, Cout: int, ld_in: int, f32: bool = False) -> bool:
             and lib().tecm_conv_fwd_supported(Lc, Cout, ld_in, 1 if f32 else 0) == 1)
 
 
+def conv_fwd_stats_ok(Lc: int) -> bool:
+    """conv_fwd can compute the GroupNorm statistics when one tile holds a whole sequence (csrc/conv_seq.hip: 48 time steps)."""
+    return Lc <= 48 and os.environ.get("TECM_CONV_STATS", "1")[:1] != "0"
+
+
 def conv_fwd(inp: torch.Tensor, w3: torch.Tensor, w5: torch.Tensor, w7: torch.Tensor, bias: torch.Tensor,
-             y: torch.Tensor, B: int, Lc: int, N: int, Cout: int, cin: int, ld_in: int) -> None:
+             y: torch.Tensor, B: int, Lc: int, N: int, Cout: int, cin: int, ld_in: int,
+             stats: Optional[torch.Tensor] = None, eps: float = 1e-5) -> None:
     """y (B, Lc, N, 3*Cout) fp32 = the three parallel Conv1d (k = 3, 5, 7) of a Multi_Scale_Conv_Block (modules.py:43-60)
     of inp (B, Lc, N, ld_in), bias (3*Cout) included, in one launch (csrc/conv_seq.hip).  inp bf16: the bf16 mode's
     arithmetic; inp fp32: exact fp32."""
@@ -679,7 +696,8 @@ def conv_fwd(inp: torch.Tensor, w3: torch.Tensor, w5: torch.Tensor, w7: torch.Te
     wpack = torch.empty(nval, device=y.device, dtype=inp.dtype)
     check(pack(w3.data_ptr(), w5.data_ptr(), w7.data_ptr(), wpack.data_ptr(), Cout, cin, ld_in, stream_ptr()), what + "/pack")
     d = _lib.TecmConvFwd(inp=inp.data_ptr(), wpack=wpack.data_ptr(), bias=bias.data_ptr(), y=y.data_ptr(), B=B, Lc=Lc,
-                         N=N, Cout=Cout, ld_in=ld_in, y_bf16=1 if y.dtype == torch.bfloat16 else 0)
+                         N=N, Cout=Cout, ld_in=ld_in, y_bf16=1 if y.dtype == torch.bfloat16 else 0,
+                         stats=ptr(stats), eps=eps)     # stats: (B*N, 3, 2) GroupNorm(1) mean / rstd of the bf16 y (one tile per sequence)
     if _timing is None:
         check(run(C.byref(d), stream_ptr()), what)
         return

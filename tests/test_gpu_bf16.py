@@ -583,3 +583,39 @@ def test_bf16_dma_kernel_walks_a_window_view_of_a(dev, Bq, Lin, N, taps, Cw, Nou
     mult = torch.from_numpy(rng.keep_mult(4242, np.arange(M * Nout, dtype=np.uint64).reshape(M, Nout), 0.1)).to(dev).double()
     assert _rel(outs[0], ref * mult) < TOL and _rel(outs[1], ref * mult) < TOL
     assert _rel(outs[0], outs[1]) < 1e-6
+
+
+@pytest.mark.parametrize("Bn,Lc,N,cin,ld_in,Cout,stride", [(2, 48, 7, 22, 24, 64, 2), (1, 24, 9, 64, 64, 128, 2), (1, 8, 5, 22, 24, 64, 1)])
+def test_conv_fwd_hands_the_groupnorm_statistics_over(dev, Bn, Lc, N, cin, ld_in, Cout, stride):
+    """tecm_conv_fwd_bf16 with TecmConvFwd::stats: (mean, rstd) of GroupNorm(1, Cout) per sequence and branch from the rounded
+    y it holds in registers, then the elementwise norm + GELU (TECM_GN_STATS_GIVEN) -- against fp64 statistics of the y it
+    wrote and against the sequence-resident kernel that computes its own."""
+    from tecmollm import ops
+    CT = 3 * Cout
+    inp = torch.zeros(Bn, Lc, N, ld_in, device=dev)
+    inp[..., :cin] = _rand(Bn, Lc, N, cin, dev=dev, seed=31)
+    inp16 = inp.bfloat16()
+    ws = [_rand(Cout, cin, k, dev=dev, seed=32 + k, scale=0.2) for k in (3, 5, 7)]
+    bias = _rand(CT, dev=dev, seed=40)
+    gamma, beta = 1 + 0.1 * _rand(CT, dev=dev, seed=41), 0.1 * _rand(CT, dev=dev, seed=42)
+    y = torch.empty(Bn, Lc, N, CT, device=dev, dtype=torch.bfloat16)
+    y0 = torch.empty_like(y)
+    stats = torch.full((Bn * N, 3, 2), float("nan"), device=dev)
+    ops.conv_fwd(inp16, *ws, bias, y, Bn, Lc, N, Cout, cin, ld_in, stats=stats)
+    ops.conv_fwd(inp16, *ws, bias, y0, Bn, Lc, N, Cout, cin, ld_in)
+    assert torch.equal(y, y0)
+    yd = y.double().view(Bn, Lc, N, 3, Cout).permute(0, 2, 3, 1, 4).reshape(Bn * N, 3, -1)
+    mean, var = yd.mean(-1), yd.var(-1, unbiased=False)
+    assert _rel(stats[..., 0], mean) < 1e-5 and _rel(stats[..., 1], 1.0 / torch.sqrt(var + 1e-5)) < 1e-5
+    La = (Lc + stride - 1) // stride
+    act = torch.empty(Bn, La, N, CT, device=dev, dtype=torch.bfloat16)
+    ops.groupnorm_gelu_fwd(y, gamma, beta, act, stats, Bn, Lc, N, Cout, act_stride=stride, stats_given=True)
+    xh = (yd - mean[..., None]) / torch.sqrt(var[..., None] + 1e-5)
+    xh = xh.view(Bn, N, 3, Lc, Cout).permute(0, 3, 1, 2, 4).reshape(Bn, Lc, N, CT)
+    ref = torch.nn.functional.gelu(xh * gamma.double() + beta.double())[:, ::stride]
+    assert float((act.double() - ref).abs().max()) < 2.0 ** -8 * float(ref.abs().max()) + 1e-6      # one bf16 rounding
+    if ops.gn_y16_ok(Lc, N, Cout):                           # the sequence-resident kernel (own statistics)
+        act1, st1 = torch.empty_like(act), torch.empty_like(stats)
+        ops.groupnorm_gelu_fwd(y, gamma, beta, act1, st1, Bn, Lc, N, Cout, act_stride=stride)
+        assert _rel(st1, stats) < 1e-5
+        assert float((act1.float() != act.float()).float().mean()) < 2e-3      # rounding flips only

@@ -224,7 +224,11 @@ int tecm_groupnorm_gelu_fwd(const void* y, const float* gamma, const float* beta
 int tecm_groupnorm_gelu_bwd(const void* dact, int32_t dstride, const void* y, const float* gamma,
                             const float* beta, const float* stats, void* dy, float* dgb_partials,
                             int32_t* num_blocks, int32_t B, int32_t L, int32_t N, int32_t Cout,
-                            int32_t io_bf16, void* stream);
+                            int32_t io_bf16,
+                            float* seq_sums /* optional workspace of B*N*6 floats (all-bf16 form, Cout 64 / 128): the backward
+                                               then runs as two streaming kernels -- per-sequence sums, then an elementwise
+                                               pass -- instead of holding each sequence in registers.  NULL: one kernel */,
+                            void* stream);
 
 /* ------------------------------------------------------------------ stage a-6 pieces
  * nn.LayerNorm(768, eps=1e-5) of GPT2Block / ln_f (modeling_gpt2.py:262-310, :620). */

@@ -455,7 +455,7 @@ struct FArgs {
   unsigned long long assign;   // 4 waves x 3 unit ids of 4 bits (15 = none): no kernel-argument arrays -- indexing
 };                             //   one dynamically makes the compiler copy the whole struct to scratch
 
-__global__ __launch_bounds__(NTH, 2) void conv_fwd_seq_kernel(const FArgs a) {
+__global__ __launch_bounds__(NTH, 3) void conv_fwd_seq_kernel(const FArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -488,12 +488,10 @@ __global__ __launch_bounds__(NTH, 2) void conv_fwd_seq_kernel(const FArgs a) {
   const int ntt = tc >> 3;
   const int cpt = a.ld_in / 8;                             // chunks per tap
   const unsigned cpt_magic = (unsigned)((65536 + cpt - 1) / cpt);      // q / cpt for q < 256
-  // GroupNorm statistics of this wave's units, per (branch, node): (count, mean, M2), merged with Chan's rule
-  float rcnt[3] = {0.f, 0.f, 0.f}, rmean[3][NB], rm2[3][NB];
-#pragma unroll
-  for (int jb = 0; jb < 3; ++jb)
-#pragma unroll
-    for (int n = 0; n < NB; ++n) rmean[jb][n] = rm2[jb][n] = 0.f;
+  // GroupNorm statistics: every unit leaves (mean, M2) of its 32 channels per node in LDS (no running registers: they cost
+  // the kernel its third wave per SIMD); twelve lanes merge them with Chan's rule at the end, in a fixed order
+  __shared__ float xst[4][3][2 * NB + 1];                  // [wave][unit slot]: branch (-1: none), 4 means, 4 M2s
+  if (a.stats && lane < 3) xst[wave][lane][0] = -1.f;
 #pragma unroll 1
   for (int ui = 0; ui < 3; ++ui) {
     const int u = (int)((a.assign >> (12 * wave + 4 * ui)) & 15ull);
@@ -567,43 +565,39 @@ __global__ __launch_bounds__(NTH, 2) void conv_fwd_seq_kernel(const FArgs a) {
     const float bv = a.bias[col0 + r];
     const int tstride = a.N * CT;                          // one time step, in elements (a tile spans < 2^31 of them)
     if (a.stats) {
-      // statistics of the values as stored (rounded to bf16), two passes over the registers: unit mean, then squared
-      // deviations; lane (channel, h) holds node e & 3 at 4 * ntt time steps
-      float sm[NB] = {0.f, 0.f, 0.f, 0.f};
+      // statistics of the values AS STORED: the accumulators are replaced by the rounded y once (the store below converts
+      // exactly), then one pass of shifted sums -- shift = the wave's first value, so that sum((v - s)^2) -
+      // sum(v - s)^2 / n does not cancel when |mean| >> std -- and eight wave reductions per unit
 #pragma unroll
       for (int i = 0; i < MAXT; ++i)
         if (i < ntt) {
 #pragma unroll
-          for (int e = 0; e < 16; ++e) sm[e & 3] += (float)(__bf16)(acc[i][e] + bv);
+          for (int e = 0; e < 16; ++e) acc[i][e] = (float)(__bf16)(acc[i][e] + bv);
         }
-      const float ucnt = (float)(32 * tc);
-      float um[NB], uq[NB] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int n = 0; n < NB; ++n) um[n] = wave_sum(sm[n]) / ucnt;
+      float s1[NB] = {0.f, 0.f, 0.f, 0.f}, s2[NB] = {0.f, 0.f, 0.f, 0.f};
+      const float sh = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, acc[0][0])));
 #pragma unroll
       for (int i = 0; i < MAXT; ++i)
         if (i < ntt) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
-            const float dv = (float)(__bf16)(acc[i][e] + bv) - um[e & 3];
-            uq[e & 3] += dv * dv;
+            const float dv = acc[i][e] - sh;
+            s1[e & 3] += dv;
+            s2[e & 3] += dv * dv;
           }
         }
+      const float ucnt = (float)(32 * tc);
 #pragma unroll
-      for (int n = 0; n < NB; ++n) uq[n] = wave_sum(uq[n]);
-#pragma unroll
-      for (int jb = 0; jb < 3; ++jb)
-        if (jb == j) {                                     // wave-uniform
-          const float tot = rcnt[jb] + ucnt, fr = ucnt / tot;
-#pragma unroll
-          for (int n = 0; n < NB; ++n) {
-            const float dl = um[n] - rmean[jb][n];
-            rm2[jb][n] += uq[n] + dl * dl * rcnt[jb] * fr;
-            rmean[jb][n] += dl * fr;
-          }
-          rcnt[jb] = tot;
+      for (int n = 0; n < NB; ++n) {
+        const float t1 = wave_sum(s1[n]), t2 = wave_sum(s2[n]);
+        if (lane == 0) {
+          xst[wave][ui][1 + n] = sh + t1 / ucnt;
+          xst[wave][ui][1 + NB + n] = fmaxf(t2 - t1 * t1 / ucnt, 0.f);
         }
+      }
+      if (lane == 0) xst[wave][ui][0] = (float)j;
     }
+    const float bvs = a.stats ? 0.f : bv;                  // the bias is already inside the rounded accumulators
     if (a.y16) {
       // y as the bf16 tensor a bf16 Conv1d produces under autocast (train.py:68): neighbouring lanes (channels c, c + 1)
       // trade one value per register pair, so that the even lane stores (c, c + 1) of node e0 & 3 and the odd lane
@@ -616,7 +610,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_fwd_seq_kernel(const FArgs a) {
         if (i < ntt) {
 #pragma unroll
           for (int ep = 0; ep < 8; ++ep) {
-            const float v0 = acc[i][2 * ep] + bv, v1 = acc[i][2 * ep + 1] + bv;
+            const float v0 = acc[i][2 * ep] + bvs, v1 = acc[i][2 * ep + 1] + bvs;
             const float send = odd ? v0 : v1;
             const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, false));
             bf16x2 pk;
@@ -642,31 +636,19 @@ __global__ __launch_bounds__(NTH, 2) void conv_fwd_seq_kernel(const FArgs a) {
     }
   }
   if (a.stats) {
-    // the four waves' (count, mean, M2) per (branch, node) meet in a fixed order: bit-reproducible statistics
-    __shared__ float xst[4][3][NB][3];
-    if (lane == 0) {
-#pragma unroll
-      for (int jb = 0; jb < 3; ++jb)
-#pragma unroll
-        for (int n = 0; n < NB; ++n) {
-          xst[wave][jb][n][0] = rcnt[jb];
-          xst[wave][jb][n][1] = rmean[jb][n];
-          xst[wave][jb][n][2] = rm2[jb][n];
-        }
-    }
     __syncthreads();
     if (tid < 3 * NB) {
       const int jb = tid / NB, n = tid % NB;
+      const float ucnt = (float)(32 * tc);
       float cnt = 0.f, mean = 0.f, m2 = 0.f;
-      for (int w = 0; w < 4; ++w) {
-        const float c2 = xst[w][jb][n][0];
-        if (c2 > 0.f) {
-          const float tot = cnt + c2, fr = c2 / tot, dl = xst[w][jb][n][1] - mean;
-          m2 += xst[w][jb][n][2] + dl * dl * cnt * fr;
-          mean += dl * fr;
-          cnt = tot;
-        }
-      }
+      for (int w = 0; w < 4; ++w)
+        for (int q = 0; q < 3; ++q)
+          if (xst[w][q][0] == (float)jb) {
+            const float tot = cnt + ucnt, fr = ucnt / tot, dl = xst[w][q][1 + n] - mean;
+            m2 += xst[w][q][1 + NB + n] + dl * dl * cnt * fr;
+            mean += dl * fr;
+            cnt = tot;
+          }
       if (n0 + n < a.N) {
         float* st = a.stats + (((int64_t)b * a.N + n0 + n) * 3 + jb) * 2;
         st[0] = mean;

@@ -1121,6 +1121,136 @@ __global__ __launch_bounds__(256) void gn_apply_fwd16_kernel(const void* __restr
   }
 }
 
+// ------------------------------------------------------------------ GroupNorm(1) + GELU backward on bf16 tensors, split (round 4)
+// The sequence-resident backward (a block holds one sequence in registers: load, reduce, barrier, reduce, barrier, write)
+// runs at 2.3 TB/s of its 1.07 GB -- two waves per SIMD, every phase exposed.  The same arithmetic as TWO streaming kernels
+// with no resident sequence:
+//   sums   a block owns NPB nodes of one sample and walks the time steps the strided 1x1 conv read (the only ones with a
+//          gradient); a lane keeps one (node, channel oct): sum d and sum d * y_hat per (sequence, branch), d gamma / d beta
+//          per channel in registers across the block's items.  Reads y (those steps) + dact: 0.43 GB.
+//   apply  elementwise: dy = rstd * (d - mean(d) - y_hat * mean(d y_hat)), d recomputed (GELU' a second time is cheaper than
+//          a resident sequence); a lane keeps its channel oct, so the conv-bias gradient (column sums of dy) stays in
+//          registers.  Reads y + dact, writes dy: 1.07 GB.
+// Both deterministic (fixed lane -> channel map, per-block partial rows summed by tecm_colsum).
+template <int CPB>
+__global__ __launch_bounds__(256) void gn_bwd_sums16_kernel(const void* __restrict__ dact, int dstride, int L2,
+                                                            const void* __restrict__ y, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, const float* __restrict__ stats,
+                                                            float* __restrict__ sums, float* __restrict__ partials, int B,
+                                                            int L, int N) {
+  constexpr int CT = 192 * CPB, OPR = CT / 8, OPB = OPR / 3, NPB = 256 / OPR;
+  __shared__ float red[NPB][OPR][2];
+  __shared__ float pg[2][NPB][CT];
+  const int nl = threadIdx.x / OPR, o = threadIdx.x - nl * OPR;
+  const bool lane_on = nl < NPB;
+  const int c = o * 8, br = o / OPB;
+  const f32x8 gm = lane_on ? gn_ld8f(gamma + c) : f32x8{}, bt = lane_on ? gn_ld8f(beta + c) : f32x8{};
+  f32x8 dg = {}, db = {};
+  const int nblk = (N + NPB - 1) / NPB;
+  const int items = B * nblk;
+  for (int item = blockIdx.x; item < items; item += gridDim.x) {
+    const int b = item / nblk, n = (item - b * nblk) * NPB + nl;
+    const bool on = lane_on && n < N;
+    const int nn = on ? n : 0;
+    const float2 ms = *reinterpret_cast<const float2*>(stats + (((int64_t)b * N + nn) * 3 + (lane_on ? br : 0)) * 2);
+    float a1 = 0.f, a2 = 0.f;
+    if (on) {
+      const int64_t yb = ((int64_t)b * L * N + nn) * CT + c, dbs = ((int64_t)b * L2 * N + nn) * CT + c;
+      const int64_t ystep = (int64_t)dstride * N * CT, dstep = (int64_t)N * CT;
+#pragma unroll 4
+      for (int t2 = 0; t2 < L2; ++t2) {
+        const f32x8 yv = gn_ld8(y, yb + t2 * ystep), dv = gn_ld8(dact, dbs + t2 * dstep);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float h_ = (yv[e] - ms.x) * ms.y;
+          const float g_ = dv[e] * GN_DGELU(h_ * gm[e] + bt[e]);
+          dg[e] += g_ * h_;
+          db[e] += g_;
+          const float d_ = g_ * gm[e];
+          a1 += d_;
+          a2 += d_ * h_;
+        }
+      }
+    }
+    __syncthreads();                                          // red is free again
+    if (lane_on) { red[nl][o][0] = a1; red[nl][o][1] = a2; }
+    __syncthreads();
+    if (threadIdx.x < NPB * 3) {                              // (node, branch): OPB octs in a fixed order
+      const int q = threadIdx.x / 3, bb = threadIdx.x - q * 3;
+      const int n2 = (item - b * nblk) * NPB + q;
+      float t1 = 0.f, t2 = 0.f;
+      for (int k = 0; k < OPB; ++k) { t1 += red[q][bb * OPB + k][0]; t2 += red[q][bb * OPB + k][1]; }
+      if (n2 < N) {
+        float* so = sums + (((int64_t)b * N + n2) * 3 + bb) * 2;
+        so[0] = t1;
+        so[1] = t2;
+      }
+    }
+  }
+  __syncthreads();
+  if (lane_on) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { pg[0][nl][c + e] = dg[e]; pg[1][nl][c + e] = db[e]; }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < 2 * CT; k += 256) {
+    const int w = k / CT, cc = k - w * CT;
+    float t = 0.f;
+    for (int q = 0; q < NPB; ++q) t += pg[w][q][cc];
+    partials[(int64_t)blockIdx.x * 3 * CT + k] = t;
+  }
+}
+
+template <int CPB>
+__global__ __launch_bounds__(256) void gn_bwd_apply16_kernel(const void* __restrict__ dact, int dstride, int L2,
+                                                             const void* __restrict__ y, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ stats,
+                                                             const float* __restrict__ sums, void* __restrict__ dy,
+                                                             float* __restrict__ partials, int B, int L, int N) {
+  constexpr int CT = 192 * CPB, OPR = CT / 8, OPB = OPR / 3, RPB = 256 / OPR;
+  __shared__ float pg[RPB][CT];
+  const int rl = threadIdx.x / OPR, o = threadIdx.x - rl * OPR;
+  const bool lane_on = rl < RPB;
+  const int c = o * 8, br = o / OPB;
+  const f32x8 gm = lane_on ? gn_ld8f(gamma + c) : f32x8{}, bt = lane_on ? gn_ld8f(beta + c) : f32x8{};
+  const float inv_cnt = 1.0f / (float)(L * CPB * 64);
+  f32x8 dys = {};
+  const int64_t rows = (int64_t)B * L * N;
+  if (lane_on)
+    for (int64_t row = (int64_t)blockIdx.x * RPB + rl; row < rows; row += (int64_t)gridDim.x * RPB) {
+      const int n = (int)(row % N);
+      const int64_t bt_ = row / N;
+      const int t = (int)(bt_ % L), b = (int)(bt_ / L);
+      const int64_t si = (((int64_t)b * N + n) * 3 + br) * 2;
+      const float2 ms = *reinterpret_cast<const float2*>(stats + si);
+      const float2 sm = *reinterpret_cast<const float2*>(sums + si);
+      const float m1 = sm.x * inv_cnt, m2 = sm.y * inv_cnt;
+      const f32x8 yv = gn_ld8(y, row * CT + c);
+      const bool has = (t % dstride) == 0;
+      f32x8 dv = {};
+      if (has) dv = gn_ld8(dact, (((int64_t)b * L2 + t / dstride) * N + n) * CT + c);
+      f32x8 ov;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float h_ = (yv[e] - ms.x) * ms.y;
+        const float d_ = has ? dv[e] * GN_DGELU(h_ * gm[e] + bt[e]) * gm[e] : 0.f;
+        ov[e] = ms.y * (d_ - m1 - h_ * m2);
+        dys[e] += ov[e];
+      }
+      gn_st8(dy, row * CT + c, ov);
+    }
+  if (lane_on) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) pg[rl][c + e] = dys[e];
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < CT; k += 256) {
+    float t = 0.f;
+    for (int q = 0; q < RPB; ++q) t += pg[q][k];
+    partials[(int64_t)blockIdx.x * 3 * CT + 2 * CT + k] = t;
+  }
+}
+
 int gn_blocks(int64_t S) {
   const int64_t want = (S + 3) / 4;
   return (int)(want < 1024 ? want : 1024);
@@ -1328,7 +1458,7 @@ extern "C" int tecm_groupnorm_gelu_fwd(const void* y_, const float* gamma, const
 extern "C" int tecm_groupnorm_gelu_bwd(const void* dact_, int32_t dstride, const void* y_, const float* gamma,
                                        const float* beta, const float* stats, void* dy_, float* dgb_partials,
                                        int32_t* num_blocks, int32_t B, int32_t L, int32_t N, int32_t Cout,
-                                       int32_t io_bf16, void* stream) {
+                                       int32_t io_bf16, float* seq_sums, void* stream) {
   const float* y = reinterpret_cast<const float*>(y_);
   float* dy = reinterpret_cast<float*>(dy_);
   TECM_REQUIRE((io_bf16 & ~(TECM_GN_OUT_BF16 | TECM_GN_DACT_BF16 | TECM_GN_Y_BF16)) == 0 &&
@@ -1346,6 +1476,26 @@ extern "C" int tecm_groupnorm_gelu_bwd(const void* dact_, int32_t dstride, const
   TECM_REQUIRE(dact && y && gamma && beta && stats && dgb_partials, TECM_E_ARG, "tecm_groupnorm_gelu_bwd: null pointer");
   const int L2 = (L + dstride - 1) / dstride;
   hipStream_t st = (hipStream_t)stream;
+  if ((io_bf16 & TECM_GN_Y_BF16) && seq_sums && (Cout == 64 || Cout == 128) && tecm_aligned(dact_, 16) && tecm_aligned(y_, 16) &&
+      tecm_aligned(dy_, 16)) {
+    // every tensor bf16 and a workspace for the per-sequence sums: the two streaming kernels (see gn_bwd_sums16_kernel)
+    const char* sp = std::getenv("TECM_GN_BWD_SPLIT");
+    if (!(sp && sp[0] == '0')) {
+      if (Cout == 64) {
+        hipLaunchKernelGGL(gn_bwd_sums16_kernel<1>, dim3(nb), dim3(256), 0, st, dact_, dstride, L2, y_, gamma, beta, stats, seq_sums,
+                           dgb_partials, B, L, N);
+        hipLaunchKernelGGL(gn_bwd_apply16_kernel<1>, dim3(nb), dim3(256), 0, st, dact_, dstride, L2, y_, gamma, beta, stats, seq_sums,
+                           dy_, dgb_partials, B, L, N);
+      } else {
+        hipLaunchKernelGGL(gn_bwd_sums16_kernel<2>, dim3(nb), dim3(256), 0, st, dact_, dstride, L2, y_, gamma, beta, stats, seq_sums,
+                           dgb_partials, B, L, N);
+        hipLaunchKernelGGL(gn_bwd_apply16_kernel<2>, dim3(nb), dim3(256), 0, st, dact_, dstride, L2, y_, gamma, beta, stats, seq_sums,
+                           dy_, dgb_partials, B, L, N);
+      }
+      TECM_CHECK_LAUNCH("tecm_groupnorm_gelu_bwd/split16");
+      return TECM_OK;
+    }
+  }
   if (io_bf16 & TECM_GN_Y_BF16) {                        // every tensor bf16
     // the four-channel register kernel with 8-byte y / dact loads where its geometry serves the sequence (measured at B = 8:
     // 1.3x faster than the 8-channel kernel in this direction: more requests in flight per lane), else the 8-channel one

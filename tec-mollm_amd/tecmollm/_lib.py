@@ -153,7 +153,7 @@ EXPORTS = {
     "tecm_gn_y16_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "tecm_groupnorm_gelu_bwd": (C.c_int, [c_f32p, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                           C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                                          C.c_int32, C.c_void_p]),
+                                          C.c_int32, c_f32p, C.c_void_p]),
     "tecm_layernorm_fwd": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_void_p, C.c_int64,
                                      C.c_void_p, C.c_int64, C.POINTER(TecmDrop), C.c_int32, C.c_int32,
                                      c_f32p, C.c_int64, C.c_int32, C.c_float, C.c_void_p]),

@@ -424,7 +424,7 @@ def groupnorm_gelu_bwd(dact: torch.Tensor, dstride: int, y: torch.Tensor, gamma:
     together with a bf16 dy) the bf16 tensor the strided 1x1 conv's d-input GEMM wrote."""
     nb = C.c_int32(0)
     check(lib().tecm_groupnorm_gelu_bwd(None, dstride, None, None, None, None, None, None, C.byref(nb), B, L, N, Cout,
-                                        0, None), "tecm_groupnorm_gelu_bwd(query)")
+                                        0, None, None), "tecm_groupnorm_gelu_bwd(query)")
     CT = 3 * Cout
     partials = torch.empty(nb.value, 3 * CT, device=dy.device, dtype=torch.float32)
     io = _gn_io(y, dy)
@@ -434,9 +434,11 @@ def groupnorm_gelu_bwd(dact: torch.Tensor, dstride: int, y: torch.Tensor, gamma:
         io |= GN_DACT_BF16
     elif io & GN_Y_BF16:
         raise _lib.TecmError("groupnorm_gelu_bwd: a bf16 y comes with a bf16 dact")
+    # all-bf16 form: a small workspace for the per-sequence sums lets the library run the two streaming kernels
+    sums = torch.empty(B * N * 6, device=dy.device, dtype=torch.float32) if (io & GN_Y_BF16) else None
     check(lib().tecm_groupnorm_gelu_bwd(dact.data_ptr(), dstride, y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                         stats.data_ptr(), dy.data_ptr(), partials.data_ptr(), C.byref(nb), B, L, N,
-                                        Cout, io, stream_ptr()), "tecm_groupnorm_gelu_bwd")
+                                        Cout, io, ptr(sums), stream_ptr()), "tecm_groupnorm_gelu_bwd")
     dgb = colsum(partials, 3 * CT, nb.value, 1, 1, 3 * CT)
     return dgb[0, :CT], dgb[0, CT:2 * CT], dgb[0, 2 * CT:]
 

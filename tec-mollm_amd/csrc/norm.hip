@@ -1137,7 +1137,7 @@ __global__ __launch_bounds__(256) void gn_bwd_sums16_kernel(const void* __restri
                                                             const void* __restrict__ y, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const float* __restrict__ stats,
                                                             float* __restrict__ sums, float* __restrict__ partials, int B,
-                                                            int L, int N) {
+                                                            int L, int N, int active) {
   constexpr int CT = 192 * CPB, OPR = CT / 8, OPB = OPR / 3, NPB = 256 / OPR;
   __shared__ float red[NPB][OPR][2];
   __shared__ float pg[2][NPB][CT];
@@ -1148,7 +1148,8 @@ __global__ __launch_bounds__(256) void gn_bwd_sums16_kernel(const void* __restri
   f32x8 dg = {}, db = {};
   const int nblk = (N + NPB - 1) / NPB;
   const int items = B * nblk;
-  for (int item = blockIdx.x; item < items; item += gridDim.x) {
+  // `active` blocks share the items evenly (the rest of the grid only writes its zero partial row)
+  for (int item = blockIdx.x < active ? blockIdx.x : items; item < items; item += active) {
     const int b = item / nblk, n = (item - b * nblk) * NPB + nl;
     const bool on = lane_on && n < N;
     const int nn = on ? n : 0;
@@ -1481,14 +1482,19 @@ extern "C" int tecm_groupnorm_gelu_bwd(const void* dact_, int32_t dstride, const
     // every tensor bf16 and a workspace for the per-sequence sums: the two streaming kernels (see gn_bwd_sums16_kernel)
     const char* sp = std::getenv("TECM_GN_BWD_SPLIT");
     if (!(sp && sp[0] == '0')) {
+      // items = (sample, node group); as many active blocks as make every one of them own the same number of items
+      const int npb = Cout == 64 ? 10 : 5;
+      const int items = B * ((N + npb - 1) / npb);
+      const int per = (items + nb - 1) / nb;
+      const int active = (items + per - 1) / per;
       if (Cout == 64) {
         hipLaunchKernelGGL(gn_bwd_sums16_kernel<1>, dim3(nb), dim3(256), 0, st, dact_, dstride, L2, y_, gamma, beta, stats, seq_sums,
-                           dgb_partials, B, L, N);
+                           dgb_partials, B, L, N, active);
         hipLaunchKernelGGL(gn_bwd_apply16_kernel<1>, dim3(nb), dim3(256), 0, st, dact_, dstride, L2, y_, gamma, beta, stats, seq_sums,
                            dy_, dgb_partials, B, L, N);
       } else {
         hipLaunchKernelGGL(gn_bwd_sums16_kernel<2>, dim3(nb), dim3(256), 0, st, dact_, dstride, L2, y_, gamma, beta, stats, seq_sums,
-                           dgb_partials, B, L, N);
+                           dgb_partials, B, L, N, active);
         hipLaunchKernelGGL(gn_bwd_apply16_kernel<2>, dim3(nb), dim3(256), 0, st, dact_, dstride, L2, y_, gamma, beta, stats, seq_sums,
                            dy_, dgb_partials, B, L, N);
       }

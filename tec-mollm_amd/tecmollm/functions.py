@@ -497,18 +497,23 @@ class PatchEmbedFn(torch.autograd.Function):
         t16 = int(plan.bf16) == ops.PREC_BF16 and conv.dtype == torch.bfloat16 and \
             ops.tn_ok(d_llm, K, M) and d_llm % 8 == 0
         dh16 = None
+        cdrop = None                                       # mask the column sums apply to dh0 on the fly
         if dspec is not None:
             if t16:
-                dh0, dh16 = ops.dropout_apply(dh0, M, d_llm, dspec, twin_bf16=True)
+                # the masked gradient only exists as the bf16 tensor the two GEMMs read; the column sums mask the fp32 one
+                dh16 = ops.dropout_apply(dh0, M, d_llm, dspec, out_bf16=True)
+                cdrop = dspec
             else:
                 dh0 = ops.dropout_apply(dh0, M, d_llm, dspec)
         elif t16:
             dh16 = ops.bf16_twin(dh0, M, d_llm)
-        dbp = colsum(dh0, d_llm, M, 1, 1, d_llm)[0]
         dwpe = None
         if has_wpe:
             dwpe = torch.zeros_like(wpe)
-            colsum(dh0, d_llm, B, N, P, d_llm, out=dwpe)                     # rows 0..P-1 of wpe
+            colsum(dh0, d_llm, B, N, P, d_llm, out=dwpe, in_drop=cdrop)      # rows 0..P-1 of wpe
+            dbp = colsum(dwpe, d_llm, P, 1, 1, d_llm)[0]                     # the bias gradient = the sum of those P rows:
+        else:                                                                #   no second pass over the M x d_llm gradient
+            dbp = colsum(dh0, d_llm, M, 1, 1, d_llm, in_drop=cdrop)[0]
         dWp = _empty(d_llm, K, like=conv)
         dg = dh16 if dh16 is not None else dh0
         gemm(d_llm, K, M, dg, d_llm, conv, D, dWp, K, a_layout=A_KM, b_layout=B_KN, b_win=w,

@@ -557,3 +557,28 @@ def test_bench_counts_gpus_from_sysfs_without_the_hip_runtime(tmp_path, monkeypa
     src = open(os.path.join(ROOT, "bench.py")).read()
     launcher = src[src.index("def launch_ranks"):src.index("def make_config")]
     assert "torch.cuda" not in launcher                               # the parent never asks the runtime
+
+
+def test_isa_audit_of_hand_issued_lds_reads_catches_early_uses():
+    """__graft_entry__.audit_hand_issued_lds_reads (run by build() on gemm_bf16_tn.hip's ISA): a register a hand-issued
+    ds_read_b64_tr_b16 writes may not be touched before the counted s_waitcnt that retires it."""
+    import __graft_entry__ as ge
+    ok = """
+_Zkernel:
+	ds_read_b64_tr_b16 v[10:11], v2 offset:64
+	ds_read_b64_tr_b16 v[12:13], v2 offset:128
+	v_add_u32_e32 v3, 1, v2
+	s_waitcnt lgkmcnt(1)
+	v_mfma_f32_32x32x16_bf16 a[0:15], v[10:11], v[20:21], a[0:15]
+	s_waitcnt lgkmcnt(0)
+	v_mov_b32_e32 v14, v12
+	s_endpgm
+"""
+    assert ge.audit_hand_issued_lds_reads(ok, "ok") == 2
+    early_use = ok.replace("v_add_u32_e32 v3, 1, v2", "v_mov_b32_e32 v3, v13")
+    copied = ok.replace("s_waitcnt lgkmcnt(1)", "s_waitcnt lgkmcnt(2)")            # the first read is not retired yet
+    smem = ok.replace("v_add_u32_e32 v3, 1, v2", "s_load_dwordx2 s[4:5], s[0:1], 0x0")
+    across = ok.replace("s_waitcnt lgkmcnt(1)", ".LBB0_1:")
+    for bad in (early_use, copied, smem, across):
+        with pytest.raises(RuntimeError):
+            ge.audit_hand_issued_lds_reads(bad, "bad")

@@ -296,6 +296,12 @@ int tecm_attention_bwd(const float* qkv, const float* dctx, void* dqkv, int32_t 
 int tecm_colsum(const float* in, int64_t ld, int64_t outer, int64_t inner, int32_t nseg, int32_t C,
                 float* out, int64_t ldo, int32_t accumulate, float scale, const TecmDrop* in_drop,
                 float* workspace /* >= 1024*nseg*C floats */, void* stream);
+/* ... and, from the same pass, the (masked) input as a bf16 matrix twin[row][ld_twin] (C % 4 == 0, C <= 1024, 16-byte friendly
+ * rows): a gradient whose column sums are a bias gradient (fp32 values) and which two bf16 contractions read next (the
+ * rounded values) -- backward of nn.Linear / Conv1d(k=1), train.py:85. */
+int tecm_colsum_twin(const float* in, int64_t ld, int64_t outer, int64_t inner, int32_t nseg, int32_t C,
+                     float* out, int64_t ldo, int32_t accumulate, float scale, const TecmDrop* in_drop,
+                     float* workspace, void* twin_bf16, int64_t ld_twin, void* stream);
 
 /* nn.HuberLoss(delta) mean (train.py:372) fused with its gradient: pred/target/dpred are (n) floats
  * addressed through pred_index: element e of pred = pred[e], target likewise (both contiguous in the

@@ -980,7 +980,8 @@ __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ i
 // slivers (narrow matrices -- 24 .. 128 columns -- ran at 0.3 .. 1 TB/s through the lane-per-column kernel).
 __global__ __launch_bounds__(256) void colsum_stage1_v4(const float* __restrict__ in, int64_t ld, int64_t outer,
                                                         int64_t inner, int nseg, int C, DropCtxN idc,
-                                                        float* __restrict__ ws, int64_t chunk) {
+                                                        float* __restrict__ ws, int64_t chunk,
+                                                        __bf16* __restrict__ twin = nullptr, int64_t ld_twin = 0) {
   __shared__ float4 red[256];
   const int Q = C >> 2;                       // quads per row (host: Q <= 256)
   const int RPB = 256 / Q;                    // row slots per pass
@@ -1011,6 +1012,8 @@ __global__ __launch_bounds__(256) void colsum_stage1_v4(const float* __restrict_
             v.z *= tecm_drop_mult(idc.seed, di + 2, idc.thresh, idc.inv);
             v.w *= tecm_drop_mult(idc.seed, di + 3, idc.thresh, idc.inv);
           }
+          // every row is visited exactly once: the (masked) values can leave as a bf16 twin on the way (tecm_colsum_twin)
+          if (twin) tecm_store_bf16x4(twin + row * ld_twin + 4 * q, v.x, v.y, v.z, v.w);
           a[u].x += v.x; a[u].y += v.y; a[u].z += v.z; a[u].w += v.w;
         }
       }
@@ -1591,9 +1594,9 @@ extern "C" int tecm_groupnorm_gelu_bwd(const void* dact_, int32_t dstride, const
   return TECM_OK;
 }
 
-extern "C" int tecm_colsum(const float* in, int64_t ld, int64_t outer, int64_t inner, int32_t nseg, int32_t C,
-                           float* out, int64_t ldo, int32_t accumulate, float scale, const TecmDrop* in_drop,
-                           float* workspace, void* stream) {
+static int colsum_impl(const float* in, int64_t ld, int64_t outer, int64_t inner, int32_t nseg, int32_t C, float* out,
+                       int64_t ldo, int32_t accumulate, float scale, const TecmDrop* in_drop, float* workspace, void* twin,
+                       int64_t ld_twin, void* stream) {
   TECM_REQUIRE(in && out && workspace, TECM_E_ARG, "tecm_colsum: null pointer");
   TECM_REQUIRE(outer > 0 && inner > 0 && nseg > 0 && C > 0, TECM_E_ARG, "tecm_colsum: bad shape");
   const int colblocks = (C + 63) / 64;
@@ -1613,13 +1616,14 @@ extern "C" int tecm_colsum(const float* in, int64_t ld, int64_t outer, int64_t i
     const int64_t chunk4 = (total + rb4 - 1) / rb4;
     rb4 = (total + chunk4 - 1) / chunk4;
     hipLaunchKernelGGL(colsum_stage1_v4, dim3((unsigned)rb4, nseg), dim3(256), 0, st, in, ld, outer, inner, nseg, C,
-                       idc, workspace, chunk4);
+                       idc, workspace, chunk4, static_cast<__bf16*>(twin), ld_twin);
     TECM_CHECK_LAUNCH("tecm_colsum/stage1_v4");
     hipLaunchKernelGGL(colsum_stage2, dim3(colblocks, nseg), dim3(512), 0, st, workspace, (int)rb4, nseg, C, out, ldo,
                        accumulate, scale);
     TECM_CHECK_LAUNCH("tecm_colsum/stage2");
     return TECM_OK;
   }
+  TECM_REQUIRE(!twin, TECM_E_ALIGN, "tecm_colsum_twin: needs C %% 4 == 0, C <= 1024 and 16-byte friendly rows");
   hipLaunchKernelGGL(colsum_stage1, dim3(colblocks, (unsigned)rb, nseg), dim3(256), 0, st, in, ld, outer, inner, nseg,
                      C, idc, workspace, chunk);
   TECM_CHECK_LAUNCH("tecm_colsum/stage1");
@@ -1627,4 +1631,20 @@ extern "C" int tecm_colsum(const float* in, int64_t ld, int64_t outer, int64_t i
                      accumulate, scale);
   TECM_CHECK_LAUNCH("tecm_colsum/stage2");
   return TECM_OK;
+}
+
+extern "C" int tecm_colsum(const float* in, int64_t ld, int64_t outer, int64_t inner, int32_t nseg, int32_t C,
+                           float* out, int64_t ldo, int32_t accumulate, float scale, const TecmDrop* in_drop,
+                           float* workspace, void* stream) {
+  return colsum_impl(in, ld, outer, inner, nseg, C, out, ldo, accumulate, scale, in_drop, workspace, nullptr, 0, stream);
+}
+
+// The same pass also writes the (masked) values as a bf16 matrix twin[row][ld_twin]: the operand two bf16 contractions
+// read next (their loaders would round the fp32 values to exactly these), at no extra read of `in`.
+extern "C" int tecm_colsum_twin(const float* in, int64_t ld, int64_t outer, int64_t inner, int32_t nseg, int32_t C,
+                                float* out, int64_t ldo, int32_t accumulate, float scale, const TecmDrop* in_drop,
+                                float* workspace, void* twin_bf16, int64_t ld_twin, void* stream) {
+  TECM_REQUIRE(twin_bf16 && ld_twin >= C && ld_twin % 4 == 0 && tecm_aligned(twin_bf16, 8), TECM_E_ARG,
+               "tecm_colsum_twin: the bf16 twin needs 8-byte friendly rows of at least C values");
+  return colsum_impl(in, ld, outer, inner, nseg, C, out, ldo, accumulate, scale, in_drop, workspace, twin_bf16, ld_twin, stream);
 }

@@ -167,6 +167,8 @@ EXPORTS = {
                                      C.c_int32, C.POINTER(TecmDrop), C.c_void_p]),
     "tecm_colsum": (C.c_int, [c_f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, c_f32p, C.c_int64,
                               C.c_int32, C.c_float, C.POINTER(TecmDrop), c_f32p, C.c_void_p]),
+    "tecm_colsum_twin": (C.c_int, [c_f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, c_f32p, C.c_int64,
+                                   C.c_int32, C.c_float, C.POINTER(TecmDrop), c_f32p, C.c_void_p, C.c_int64, C.c_void_p]),
     "tecm_huber_fwd_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_float, C.c_float, c_f32p,
                                      C.c_void_p]),
     "tecm_huber_fwd_bwd_strided": (C.c_int, [c_f32p, C.POINTER(C.c_int64), c_f32p, C.POINTER(C.c_int64), c_f32p, c_f32p,

@@ -390,13 +390,15 @@ class ConvBlockFn(torch.autograd.Function):
         dout = dout.contiguous()
         wf2 = wf.view(Cout, CT)
         # final 1x1 strided conv
-        dbf = colsum(dout, Cout, Mo, 1, 1, Cout)[0]
-        dwf = _empty(Cout, CT, like=inp)
-        # bf16 mode: both contractions read dout as a bf16 twin (their loaders would round it; the bias gradient above sums fp32)
+        # bf16 mode: both contractions read dout as a bf16 twin (their loaders would round it) -- written by the pass that sums
+        # the fp32 values into the bias gradient
         if int(bf16) == ops.PREC_BF16 and act.dtype == torch.bfloat16 and ctx.compact and ops.tn_ok(Cout, CT, Mo) and Cout % 8 == 0:
-            dout_g = ops.bf16_twin(dout, Mo, Cout)
+            dout_g = torch.empty(Mo, Cout, device=dout.device, dtype=torch.bfloat16)
+            dbf = colsum(dout, Cout, Mo, 1, 1, Cout, twin=dout_g)[0]
         else:
             dout_g = dout
+            dbf = colsum(dout, Cout, Mo, 1, 1, Cout)[0]
+        dwf = _empty(Cout, CT, like=inp)
         gemm(Cout, CT, Mo, dout_g, Cout, act, CT, dwf, CT, a_layout=A_KM, b_layout=B_KN,
              b_win=None if ctx.compact else win(N, Lc, Lo, stride, 1, CT, 0),
              split_k=pick_split_k(Cout, CT, Mo, prec=bf16), bf16=bf16)
@@ -498,22 +500,20 @@ class PatchEmbedFn(torch.autograd.Function):
             ops.tn_ok(d_llm, K, M) and d_llm % 8 == 0
         dh16 = None
         cdrop = None                                       # mask the column sums apply to dh0 on the fly
-        if dspec is not None:
-            if t16:
-                # the masked gradient only exists as the bf16 tensor the two GEMMs read; the column sums mask the fp32 one
-                dh16 = ops.dropout_apply(dh0, M, d_llm, dspec, out_bf16=True)
-                cdrop = dspec
-            else:
-                dh0 = ops.dropout_apply(dh0, M, d_llm, dspec)
-        elif t16:
-            dh16 = ops.bf16_twin(dh0, M, d_llm)
+        if t16:
+            # ONE pass over dh0: the embd-dropout mask applied on the fly, the masked values summed in fp32 (wpe / bias
+            # gradients) and written as the bf16 tensor the two GEMMs read; the fp32 masked gradient is never materialised
+            dh16 = torch.empty(M, d_llm, device=dh0.device, dtype=torch.bfloat16)
+            cdrop = dspec
+        elif dspec is not None:
+            dh0 = ops.dropout_apply(dh0, M, d_llm, dspec)
         dwpe = None
         if has_wpe:
             dwpe = torch.zeros_like(wpe)
-            colsum(dh0, d_llm, B, N, P, d_llm, out=dwpe, in_drop=cdrop)      # rows 0..P-1 of wpe
+            colsum(dh0, d_llm, B, N, P, d_llm, out=dwpe, in_drop=cdrop, twin=dh16)   # rows 0..P-1 of wpe
             dbp = colsum(dwpe, d_llm, P, 1, 1, d_llm)[0]                     # the bias gradient = the sum of those P rows:
         else:                                                                #   no second pass over the M x d_llm gradient
-            dbp = colsum(dh0, d_llm, M, 1, 1, d_llm, in_drop=cdrop)[0]
+            dbp = colsum(dh0, d_llm, M, 1, 1, d_llm, in_drop=cdrop, twin=dh16)[0]
         dWp = _empty(d_llm, K, like=conv)
         dg = dh16 if dh16 is not None else dh0
         gemm(d_llm, K, M, dg, d_llm, conv, D, dWp, K, a_layout=A_KM, b_layout=B_KN, b_win=w,
@@ -889,8 +889,8 @@ class HeadFn(torch.autograd.Function):
         dpre = _empty(S, Hd, like=hid)
         gemm(S, Hd, Lo, dpred, Lo, W2, Hd, dpre, Hd, b_layout=B_KN, act=ACT_GELU_ERF, dact_src=(pre, Hd),
              out_drop=hspec, bf16=plan.bf16)
-        db1 = colsum(dpre, Hd, S, 1, 1, Hd)[0]
-        dp = ops.bf16_twin(dpre, S, Hd)                     # what both contractions round dpre to (db1 sums the fp32 values)
+        dp = torch.empty(S, Hd, device=hid.device, dtype=torch.bfloat16)     # what both contractions round dpre to, written by
+        db1 = colsum(dpre, Hd, S, 1, 1, Hd, twin=dp)[0]                      # the pass that sums the fp32 values into db1
         dW1 = _empty(Hd, K1, like=hid)
         gemm(Hd, K1, S, dp, Hd, hid, K1, dW1, K1, a_layout=A_KM, b_layout=B_KN,
              split_k=pick_split_k(Hd, K1, S, prec=plan.bf16), bf16=plan.bf16)
@@ -915,11 +915,14 @@ class HeadFn(torch.autograd.Function):
         dpre = _empty(S, Hd, like=hid)
         gemm(S, Hd, Lo, dpred, Lo, W2, Hd, dpre, Hd, b_layout=B_KN, act=ACT_GELU_ERF, dact_src=(pre, Hd),
              out_drop=hspec, bf16=plan.bf16)
-        db1 = colsum(dpre, Hd, S, 1, 1, Hd)[0]
         dW1 = _empty(Hd, K1, like=hid)
-        # bf16 mode: both contractions read dpre as a bf16 twin (what their loaders round it to; db1 above sums the fp32 values)
-        dp = ops.bf16_twin(dpre, S, Hd) if (int(plan.bf16) == ops.PREC_BF16 and hid.dtype == torch.bfloat16 and
-                                             ops.tn_ok(Hd, K1, S) and Hd % 8 == 0) else dpre
+        # bf16 mode: both contractions read dpre as a bf16 twin (what their loaders round it to), written by the db1 pass
+        if int(plan.bf16) == ops.PREC_BF16 and hid.dtype == torch.bfloat16 and ops.tn_ok(Hd, K1, S) and Hd % 8 == 0:
+            dp = torch.empty(S, Hd, device=hid.device, dtype=torch.bfloat16)
+            db1 = colsum(dpre, Hd, S, 1, 1, Hd, twin=dp)[0]
+        else:
+            dp = dpre
+            db1 = colsum(dpre, Hd, S, 1, 1, Hd)[0]
         gemm(Hd, K1, S, dp, Hd, hid, D, dW1, K1, a_layout=A_KM, b_layout=B_KN, b_win=w,       # hid = dropout(hid) here
              split_k=pick_split_k(Hd, K1, S, prec=plan.bf16), bf16=plan.bf16)
         dhid = _empty(B, T, N, D, like=hid)

@@ -465,12 +465,19 @@ def attention_bwd(qkv: torch.Tensor, dctx: torch.Tensor, dqkv: torch.Tensor, B: 
 
 def colsum(inp: torch.Tensor, ld: int, outer: int, inner: int, nseg: int, Cn: int, *, in_off: int = 0,
            scale: float = 1.0, in_drop: Optional[TecmDrop] = None, out: Optional[torch.Tensor] = None,
-           accumulate: bool = False) -> torch.Tensor:
-    """out[s][c] = scale * sum_{o<outer, j<inner} in[((o*nseg + s)*inner + j)*ld + c]  -> (nseg, Cn)."""
+           accumulate: bool = False, twin: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[s][c] = scale * sum_{o<outer, j<inner} in[((o*nseg + s)*inner + j)*ld + c]  -> (nseg, Cn).
+    twin: a contiguous bf16 (rows, Cn) tensor that receives the (masked) input values from the same pass."""
     if out is None:
         out = torch.empty(nseg, Cn, device=inp.device, dtype=torch.float32)
     ws = torch.empty(1024 * nseg * Cn, device=inp.device, dtype=torch.float32)     # contract: include/tecmollm.h
     idr = in_drop if in_drop is not None else NO_DROP
+    if twin is not None:
+        if twin.dtype != torch.bfloat16 or twin.numel() != outer * nseg * inner * Cn:
+            raise _lib.TecmError("colsum: twin must be a contiguous bf16 tensor of the input's rows x Cn")
+        check(lib().tecm_colsum_twin(_off(inp, in_off), ld, outer, inner, nseg, Cn, out.data_ptr(), Cn, 1 if accumulate else 0,
+                                     scale, C.byref(idr), ws.data_ptr(), twin.data_ptr(), Cn, stream_ptr()), "tecm_colsum_twin")
+        return out
     check(lib().tecm_colsum(_off(inp, in_off), ld, outer, inner, nseg, Cn, out.data_ptr(), Cn, 1 if accumulate else 0,
                             scale, C.byref(idr), ws.data_ptr(), stream_ptr()), "tecm_colsum")
     return out

@@ -648,3 +648,22 @@ def test_dropout_apply_matches_numpy_mirror(dev, rows, cols, ld, p):
     assert torch.equal(o32, out) and torch.equal(o16, out.bfloat16())
     if p > 0 and rows * cols > 100:
         assert not torch.equal(ops.dropout_apply(src, rows, cols, ops.drop(p, seed + 1, ld)), out)
+
+
+@pytest.mark.parametrize("outer,inner,nseg,Cn,p", [(2, 211, 3, 768, 0.1), (1000, 1, 1, 64, 0.0), (37, 5, 1, 576, 0.25)])
+def test_colsum_writes_the_masked_input_as_a_bf16_twin(dev, outer, inner, nseg, Cn, p):
+    """tecm_colsum_twin: the column sums of tecm_colsum (same bits) and, from the same pass, the (masked) input as a bf16
+    matrix -- the gradient a bias / wpe gradient sums in fp32 and two bf16 contractions read rounded."""
+    from tecmollm import ops, rng
+    rows = outer * nseg * inner
+    src = _rand(rows, Cn, dev=dev, seed=5)
+    spec = ops.drop(p, 99, Cn) if p > 0 else None
+    twin = torch.full((rows, Cn), float("nan"), device=dev, dtype=torch.bfloat16)
+    a = ops.colsum(src, Cn, outer, inner, nseg, Cn, in_drop=spec, twin=twin)
+    b = ops.colsum(src, Cn, outer, inner, nseg, Cn, in_drop=spec)
+    assert torch.equal(a, b)
+    mult = torch.from_numpy(rng.keep_mult(99, np.arange(rows * Cn, dtype=np.uint64).reshape(rows, Cn), p)).to(dev) if p > 0 \
+        else torch.ones(rows, Cn, device=dev)
+    assert torch.equal(twin, (src * mult).bfloat16())
+    with pytest.raises(ops._lib.TecmError):
+        ops.colsum(src[:, :6].contiguous(), 6, rows, 1, 1, 6, twin=torch.empty(rows, 6, device=dev, dtype=torch.bfloat16))

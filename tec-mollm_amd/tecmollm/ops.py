@@ -472,6 +472,12 @@ def colsum(inp: torch.Tensor, ld: int, outer: int, inner: int, nseg: int, Cn: in
         out = torch.empty(nseg, Cn, device=inp.device, dtype=torch.float32)
     ws = torch.empty(1024 * nseg * Cn, device=inp.device, dtype=torch.float32)     # contract: include/tecmollm.h
     idr = in_drop if in_drop is not None else NO_DROP
+    if twin is not None and not (Cn % 4 == 0 and Cn <= 1024 and ld % 4 == 0):
+        # wider than the one-pass kernel's 256 column quads (the head at L_in = 96: 1152 columns): two passes
+        if in_drop is not None or ld != Cn or in_off:
+            raise _lib.TecmError("colsum: a bf16 twin of a masked or strided input needs Cn % 4 == 0 and Cn <= 1024")
+        cast_bf16(inp, Cn, twin, Cn, outer * nseg * inner, Cn)
+        twin = None
     if twin is not None:
         if twin.dtype != torch.bfloat16 or twin.numel() != outer * nseg * inner * Cn:
             raise _lib.TecmError("colsum: twin must be a contiguous bf16 tensor of the input's rows x Cn")

@@ -665,5 +665,8 @@ def test_colsum_writes_the_masked_input_as_a_bf16_twin(dev, outer, inner, nseg, 
     mult = torch.from_numpy(rng.keep_mult(99, np.arange(rows * Cn, dtype=np.uint64).reshape(rows, Cn), p)).to(dev) if p > 0 \
         else torch.ones(rows, Cn, device=dev)
     assert torch.equal(twin, (src * mult).bfloat16())
-    with pytest.raises(ops._lib.TecmError):
-        ops.colsum(src[:, :6].contiguous(), 6, rows, 1, 1, 6, twin=torch.empty(rows, 6, device=dev, dtype=torch.bfloat16))
+    # wider than 1024 columns (the head's hidden width at L_in = 96): sums + a separate cast, same results
+    wide = _rand(64, 1152, dev=dev, seed=6)
+    tw = torch.empty(64, 1152, device=dev, dtype=torch.bfloat16)
+    assert torch.equal(ops.colsum(wide, 1152, 64, 1, 1, 1152, twin=tw), ops.colsum(wide, 1152, 64, 1, 1, 1152))
+    assert torch.equal(tw, wide.bfloat16())

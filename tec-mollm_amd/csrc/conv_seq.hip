@@ -432,6 +432,22 @@ __global__ __launch_bounds__(256) void conv_dx_pack_kernel(const float* __restri
 //   weights and read the (zeroed) extra halo step.
 namespace tecm_convseq {
 
+// Sum over the 64 lanes on the DPP network (quad swaps, row mirrors, row broadcasts; the total arrives in lane 63 and is
+// read into a scalar): no LDS crossbar traffic (__shfl_xor is ds_bpermute) in a kernel that lives on its LDS reads.
+__device__ __forceinline__ float wave_total_dpp(float v) {
+  auto step = [](float x, auto ctrl, auto rmask) {
+    constexpr int C = decltype(ctrl)::value, R = decltype(rmask)::value;
+    return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), C, R, 0xF, false));
+  };
+  v = step(v, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xF>{});     // quad_perm [1,0,3,2]
+  v = step(v, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xF>{});     // quad_perm [2,3,0,1]
+  v = step(v, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xF>{});    // row_half_mirror
+  v = step(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xF>{});    // row_mirror: every lane = its row's sum
+  v = step(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{});    // row_bcast15 into rows 1, 3
+  v = step(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xC>{});    // row_bcast31 into rows 2, 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 constexpr int FMAXU = 12;      // units: 3 kernel sizes x Cout / 32 channel blocks (Cout <= 128)
 #ifndef CFW_PD
 #define CFW_PD 4               // weight-prefetch depth of the forward K loops, in k-steps (tools/build_variant.py sweeps it)
@@ -566,36 +582,13 @@ __global__ __launch_bounds__(NTH, 3) void conv_fwd_seq_kernel(const FArgs a) {
     const int tstride = a.N * CT;                          // one time step, in elements (a tile spans < 2^31 of them)
     if (a.stats) {
       // statistics of the values AS STORED: the accumulators are replaced by the rounded y once (the store below converts
-      // exactly), then one pass of shifted sums -- shift = the wave's first value, so that sum((v - s)^2) -
-      // sum(v - s)^2 / n does not cancel when |mean| >> std -- and eight wave reductions per unit
+      // exactly); the sums themselves are formed AFTER the stores have been issued, under their latency
 #pragma unroll
       for (int i = 0; i < MAXT; ++i)
         if (i < ntt) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc[i][e] = (float)(__bf16)(acc[i][e] + bv);
         }
-      float s1[NB] = {0.f, 0.f, 0.f, 0.f}, s2[NB] = {0.f, 0.f, 0.f, 0.f};
-      const float sh = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, acc[0][0])));
-#pragma unroll
-      for (int i = 0; i < MAXT; ++i)
-        if (i < ntt) {
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const float dv = acc[i][e] - sh;
-            s1[e & 3] += dv;
-            s2[e & 3] += dv * dv;
-          }
-        }
-      const float ucnt = (float)(32 * tc);
-#pragma unroll
-      for (int n = 0; n < NB; ++n) {
-        const float t1 = wave_sum(s1[n]), t2 = wave_sum(s2[n]);
-        if (lane == 0) {
-          xst[wave][ui][1 + n] = sh + t1 / ucnt;
-          xst[wave][ui][1 + NB + n] = fmaxf(t2 - t1 * t1 / ucnt, 0.f);
-        }
-      }
-      if (lane == 0) xst[wave][ui][0] = (float)j;
     }
     const float bvs = a.stats ? 0.f : bv;                  // the bias is already inside the rounded accumulators
     if (a.y16) {
@@ -620,6 +613,32 @@ __global__ __launch_bounds__(NTH, 3) void conv_fwd_seq_kernel(const FArgs a) {
             if (n0 + n < a.N) *reinterpret_cast<bf16x2*>(yh + (8 * i + 2 * (e >> 2)) * tstride + n * CT) = pk;
           }
         }
+      }
+      if (a.stats) {
+        // one pass of shifted sums -- shift = the wave's first value, so that sum((v - s)^2) - sum(v - s)^2 / n does not
+        // cancel when |mean| >> std -- and eight wave reductions per unit
+        float s1[NB] = {0.f, 0.f, 0.f, 0.f}, s2[NB] = {0.f, 0.f, 0.f, 0.f};
+        const float sh = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, acc[0][0])));
+#pragma unroll
+        for (int i = 0; i < MAXT; ++i)
+          if (i < ntt) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const float dv = acc[i][e] - sh;
+              s1[e & 3] += dv;
+              s2[e & 3] += dv * dv;
+            }
+          }
+        const float ucnt = (float)(32 * tc);
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+          const float t1 = wave_total_dpp(s1[n]), t2 = wave_total_dpp(s2[n]);
+          if (lane == 0) {
+            xst[wave][ui][1 + n] = sh + t1 / ucnt;
+            xst[wave][ui][1 + NB + n] = fmaxf(t2 - t1 * t1 / ucnt, 0.f);
+          }
+        }
+        if (lane == 0) xst[wave][ui][0] = (float)j;
       }
       continue;
     }

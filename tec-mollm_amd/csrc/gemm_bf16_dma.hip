@@ -1057,8 +1057,11 @@ int tecm_gemm16_dma_try(const TecmGemm& g, hipStream_t st) {
   const char* sel = std::getenv("TECM_BF16_DMA");       // "0": always use the register-staged kernel (A/B diagnostics)
   if (sel && sel[0] == '0') return 0;
   const bool both = (g.io_bf16 & TECM_IO_A_BF16) && (g.io_bf16 & TECM_IO_B_BF16);
-  if (!both || !(g.io_bf16 & TECM_P0_VEC4) || g.split_k > 1 || g.K % 32 != 0 || g.K < DBK || g.M < DBM || g.N < DBN / 2)
-    return 0;
+  // K = 32 (lora_A's d-input) and N = 32 (lora_A's forward) are served by the 32-deep ring geometries only (round 4)
+  const bool k32 = g.K < DBK, n_small = g.N < DBN / 2;
+  if (!both || !(g.io_bf16 & TECM_P0_VEC4) || g.split_k > 1 || g.K % 32 != 0 || g.K < 32 || g.M < DBM || g.N < 32 ||
+      ((k32 || n_small) && g.a_win.enabled) || (n_small && g.N > 32))    // N = 64 (first 1x1 conv): the register-staged
+    return 0;                                                               //   kernel's 64-column tile is faster (114 vs 124 us)
   if (g.a_win.enabled) {
     // a pad-free window view of A whose taps are whole K-tiles (the patch projection's 'b (p l) d -> b p (l d)',
     // modules.py:114): served by the first geometry, whose source pointers move one time step on at every tap boundary
@@ -1074,7 +1077,7 @@ int tecm_gemm16_dma_try(const TecmGemm& g, hipStream_t st) {
   // the 128-column geometry where the 256-column tile would waste more than half of its last n-tile (N = 800);
   // TECM_BF16_DMA = 1 / 2 forces one of the two (A/B diagnostics, tools/dma_ab.sh)
   const int nrem = (int)(g.N % DBN);
-  const bool narrow = sel ? sel[0] == '2' : (nrem >= 1 && nrem <= D2N);
+  const bool narrow = n_small || (sel && !k32 ? sel[0] == '2' : (nrem >= 1 && nrem <= D2N));
   if (narrow) {
     const int t2m = (int)((g.M + D2M - 1) / D2M), t2n = (int)((g.N + D2N - 1) / D2N);
     hipLaunchKernelGGL(gemm_bf16_dma2_kernel, dim3((unsigned)(t2m * t2n)), dim3(D2TH), 0, st, g, t2m, t2n);
@@ -1105,7 +1108,8 @@ int tecm_gemm16_dma_try(const TecmGemm& g, hipStream_t st) {
       TECM_CHECK_LAUNCH("tecm_gemm_bf16/dma6");
       return 1;
     }
-    const bool want16 = sel ? sel[0] == '5' : true;
+    const bool want16 = (sel && !k32) ? sel[0] == '5' : true;
+    if (k32 && !can16) return 0;                           // the 64-deep geometries below cannot take K = 32
     if (can16 && want16) {
       hipLaunchKernelGGL(gemm_bf16_dma5_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(D3TH), 0, st, g, tiles_m, tiles_n);
       TECM_CHECK_LAUNCH("tecm_gemm_bf16/dma5");

@@ -628,6 +628,7 @@ class GPT2StackFn(torch.autograd.Function):
         KE = D + LORA_R
         h = h0.contiguous()
         saved: List[torch.Tensor] = []
+        ctx_lAT: List[torch.Tensor] = []                     # bf16 lora_A^T per layer (bf16 mode), for the backward's dz . A
         for i in range(n_layers):
             (ln1w, ln1b, Wqkv, bqkv, lA, lB, Wo, bo, ln2w, ln2b, Wfc, bfc, Wpr,
              bpr) = params[i * GPT2StackFn.PER_LAYER:(i + 1) * GPT2StackFn.PER_LAYER]
@@ -653,7 +654,10 @@ class GPT2StackFn(torch.autograd.Function):
                 u16d = torch.empty(M, D, device=h.device, dtype=torch.bfloat16) if lspec is not None else None
                 ops.layernorm_fwd(h, D, ln1w, ln1b, None, KE, st1, M, D, y16=u16, ldy16=KE, y16d=u16d, ldy16d=D, drop16d=lspec)
                 a_lora, ld_lora = (u16d, D) if u16d is not None else (u16, KE)
-                gemm(M, LORA_R, D, a_lora, ld_lora, lA, D, u16, KE, c_off=D, bf16=plan.bf16)
+                # lora_A rounded (and transposed for its d-input contraction in the backward): both operands bf16 tensors
+                lA16, lAT16 = ops.weight_bf16(lA, same=True, transposed=True)
+                ctx_lAT.append(lAT16)
+                gemm(M, LORA_R, D, a_lora, ld_lora, lA16, D, u16, KE, c_off=D, bf16=plan.bf16)
                 u_s, ud_s = u16, (u16d if u16d is not None else h.new_empty(0))
             else:
                 u = _empty(M, KE, like=h)                   # [ LN1(h) | z = drop(LN1(h)) A^T ]  (fp32: the LoRA gradients read it)
@@ -714,6 +718,7 @@ class GPT2StackFn(torch.autograd.Function):
             out = _empty(B, T, N, D, like=h)
             ops.layernorm_fwd(h, D, lnfw, lnfb, out, D, stf, M, D)
         ctx.save_for_backward(h, stf, *saved, *params)
+        ctx.lAT16 = ctx_lAT
         ctx.meta = (B, T, N, D, n_layers, plan, len(saved))
         return out
 
@@ -803,7 +808,10 @@ class GPT2StackFn(torch.autograd.Function):
             # bf16 mode, as under autocast) is a SECOND stream the LayerNorm backward adds through lora_dropout's mask -- it
             # used to be accumulated into du by that GEMM, a read-modify-write of the whole M x 768 gradient
             dzA = torch.empty(M, D, device=dh.device, dtype=torch.bfloat16 if (b16 and GRAD16) else torch.float32)
-            gemm(M, D, LORA_R, du, KE, lA, D, dzA, D, b_layout=B_KN, a_off=D, bf16=plan.bf16)
+            if ctx.lAT16 and dzA.dtype == torch.bfloat16 and du.dtype == torch.bfloat16:
+                gemm(M, D, LORA_R, du, KE, ctx.lAT16[i], LORA_R, dzA, D, a_off=D, bf16=plan.bf16)     # [row][k] operands: LDS-DMA
+            else:
+                gemm(M, D, LORA_R, du, KE, lA, D, dzA, D, b_layout=B_KN, a_off=D, bf16=plan.bf16)
             dhn = _empty(M, D, like=dh)
             sp = plan.spec(site_res2(i - 1), D) if i > 0 else None
             dhm = masked_buf(sp, params[(i - 1) * GPT2StackFn.PER_LAYER + 12]) if sp is not None else dhn

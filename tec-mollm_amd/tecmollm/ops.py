@@ -205,9 +205,11 @@ def _kernel_name(g: TecmGemm, use16: bool = False) -> str:
             return "gemm_bf16_dma_kernel"                  # the window route of tecm_gemm16_dma_try
         # mirrors tecm_gemm16_dma_try (csrc/gemm_bf16_dma.hip); the float4-epilogue condition holds for every bf16 call
         sel = os.environ.get("TECM_BF16_DMA", "")[:1]
-        if (both16 and g.split_k <= 1 and g.N % 4 == 0 and g.K % 32 == 0 and g.K >= 64 and g.M >= 256 and g.N >= 128
-                and sel != "0"):
-            narrow = sel == "2" if sel else 1 <= g.N % 256 <= 128      # the 256 x 128 geometry (N = 800)
+        if (both16 and g.a_layout == A_MK and g.b_layout == B_NK and not g.a_win.enabled and not g.b_win.enabled
+                and g.split_k <= 1 and g.N % 4 == 0 and g.K % 32 == 0 and g.K >= 32 and g.M >= 256
+                and (g.N >= 128 or g.N == 32) and sel != "0"):
+            k32, n_small = g.K < 64, g.N < 128
+            narrow = n_small or (sel == "2" if (sel and not k32) else 1 <= g.N % 256 <= 128)   # the 256 x 128 geometry (N = 800)
             if narrow:
                 return "gemm_bf16_dma2_kernel"
             ring = sel == "4"                                                 # the four-slot ring, anti-phase wave groups (A/B)

@@ -33,7 +33,11 @@ from .modules import (LLMBackbone, PredictionHead, SpatialEncoder, SpatioTempora
                       _need_cuda, make_plan)
 
 log = logging.getLogger(__name__)
-_FUSE_HEAD = os.environ.get("TECM_FUSE_HEAD", "1") != "0"     # "0": ln_f and the head as separate stages (A/B diagnostics)
+
+
+def _fuse_head() -> bool:
+    """TECM_FUSE_HEAD=0: ln_f and the head as separate stages (A/B diagnostics)."""
+    return os.environ.get("TECM_FUSE_HEAD", "1") != "0"
 
 _REQUIRED = ("num_nodes", "d_emb", "spatial_in_channels_base", "spatial_out_channels", "spatial_heads",
              "temporal_channel_list", "temporal_strides", "patch_len", "d_llm", "llm_layers", "temporal_seq_len",
@@ -108,7 +112,7 @@ class TEC_MoLLM(nn.Module):
         h0 = self.temporal_encoder.forward_tm(xs, self.c_spatial, wpe, plan, need_dinp=True)
         # 6. GPT-2 blocks with LoRA; 7. dropout + prediction head -> (B, N, L_out)
         # (bf16 mode: ln_f hands the head its operand directly -- dropped, rounded, sequence-major; F_.GPT2StackFn)
-        if int(plan.bf16) == F_.ops.PREC_BF16 and _FUSE_HEAD:
+        if int(plan.bf16) == F_.ops.PREC_BF16 and _fuse_head():
             plan = dataclasses.replace(plan, fuse_head=True)
         hid = self.llm_backbone.forward_tm(h0, plan)
         pred = self.prediction_head.forward_tm(hid, plan)

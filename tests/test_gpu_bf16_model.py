@@ -265,3 +265,14 @@ def test_bf16_device_is_as_close_to_the_oracle_as_the_oracle_is_to_itself(dev):
     assert l2_rel(out, out_o) <= 2.0 * l2_rel(out_s, out_o) + 2e-3
     # ... and the emulation is the better model of what the device computes
     assert d_dev.mean() < d_fo.mean() < d_32.mean(), (d_dev.mean(), d_fo.mean(), d_32.mean())
+
+
+@pytest.mark.parametrize("var", ["TECM_FUSE_HEAD", "TECM_BF16_TN", "TECM_CONV_STATS", "TECM_GN_BWD_SPLIT", "TECM_BF16_DMA"])
+def test_bf16_diagnostic_switches_keep_the_older_kernels_working(dev, var, monkeypatch):
+    """INTEGRATION.md lists environment switches that route a stage back to the kernel it had before round 4 (A/B
+    diagnostics): each of those routes still gives the same step (the 40-sequence bar)."""
+    monkeypatch.setenv(var, "0")
+    cfg = R.default_config(L_in=48, L_out=12, num_nodes=20)
+    res = compare_forward_backward(cfg, B=2, grid=(4, 5), threshold_km=170.0, gat_graphs="per_timestep", seed=31, train=True,
+                                   precision="bf16")
+    assert_parity(res, elem_scale={"*": 1.5})

@@ -551,6 +551,13 @@ def test_bf16_weight_gradient_natural_orientation_kernel(dev, Mo, No, rows, bwin
         assert _rel(C, ref) < TOL, (tn, split)
         outs[(tn, split)] = C
     assert _rel(outs[("1", want)], outs[("0", want)]) < 1e-5
+    # bit-reproducible: fixed summation order inside a block and across the split-K slabs, no race in the LDS ring
+    monkeypatch.setenv("TECM_BF16_TN", "1")
+    for _ in range(3):
+        C2 = torch.full((Mo, No), float("nan"), device=dev)
+        ops.gemm(Mo, No, K, A, lda, Bt, ldb, C2, No, a_layout=ops.A_KM, b_layout=ops.B_KN, a_off=a_off, b_off=b_off, b_win=w,
+                 alpha=alpha, split_k=want, bf16=True)
+        assert torch.equal(C2, outs[("1", want)])
 
 
 @pytest.mark.parametrize("Bq,Lin,N,taps,Cw,Nout", [(2, 12, 211, 4, 128, 768), (1, 8, 300, 2, 64, 256)])

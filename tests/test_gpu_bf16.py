@@ -626,3 +626,24 @@ def test_conv_fwd_hands_the_groupnorm_statistics_over(dev, Bn, Lc, N, cin, ld_in
         ops.groupnorm_gelu_fwd(y, gamma, beta, act1, st1, Bn, Lc, N, Cout, act_stride=stride)
         assert _rel(st1, stats) < 1e-5
         assert float((act1.float() != act.float()).float().mean()) < 2e-3      # rounding flips only
+
+
+def test_bf16_weight_gradient_kernel_is_race_free_at_full_size(dev):
+    """The head's W1 gradient at the B = 8 size (576 x 2304 over 23 288 rows, 243 blocks on a four-slot LDS ring with counted
+    waits): ten launches, bit-identical, and right against fp64 on a sample of the output."""
+    from tecmollm import ops
+    Mo, No, K = 576, 2304, 23288
+    A = _rand(K, Mo, dev=dev, seed=51).bfloat16()
+    Bm = _rand(K, No, dev=dev, seed=52).bfloat16()
+    split = ops.pick_split_k(Mo, No, K, prec=ops.PREC_BF16)
+    first = None
+    for _ in range(10):
+        C = torch.full((Mo, No), float("nan"), device=dev)
+        ops.gemm(Mo, No, K, A, Mo, Bm, No, C, No, a_layout=ops.A_KM, b_layout=ops.B_KN, split_k=split, bf16=True)
+        if first is None:
+            first = C
+        else:
+            assert torch.equal(C, first)
+    rows = torch.arange(0, Mo, 37, device=dev)
+    ref = A[:, rows].double().t() @ Bm.double()
+    assert _rel(first[rows], ref) < TOL

@@ -1611,7 +1611,11 @@ static int colsum_impl(const float* in, int64_t ld, int64_t outer, int64_t inner
   const DropCtxN idc = make_dropn(in_drop);
   if (C % 4 == 0 && C <= 1024 && ld % 4 == 0 && tecm_aligned(in, 16) && tecm_aligned(workspace, 16)) {
     int64_t rb4 = 1024 / nseg;                          // workspace contract: >= 1024 * nseg * C floats
-    if (rb4 > (total + 63) / 64) rb4 = (total + 63) / 64;
+    // at least 16 rows per block.  (Fewer, larger blocks to shrink the second stage were measured at B = 2 -- where the two
+    // stages of the 17 column sums are 0.35 ms of a 5.2 ms step: 512 rows per block 5.20 -> 5.85 ms, 2048 -> 7.9 ms, 16 instead
+    // of 64 -0.03 ms: the first stage lives on its block count.)  TECM_COLSUM_MINROWS overrides (diagnostics).
+    static const int64_t min_rows = [] { const char* e = std::getenv("TECM_COLSUM_MINROWS"); return e ? std::atoll(e) : 16ll; }();
+    if (rb4 > (total + min_rows - 1) / min_rows) rb4 = (total + min_rows - 1) / min_rows;
     if (rb4 < 1) rb4 = 1;
     const int64_t chunk4 = (total + rb4 - 1) / rb4;
     rb4 = (total + chunk4 - 1) / chunk4;

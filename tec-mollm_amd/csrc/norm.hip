@@ -1136,7 +1136,7 @@ __global__ __launch_bounds__(256) void gn_apply_fwd16_kernel(const void* __restr
 //          registers.  Reads y + dact, writes dy: 1.07 GB.
 // Both deterministic (fixed lane -> channel map, per-block partial rows summed by tecm_colsum).
 template <int CPB>
-__global__ __launch_bounds__(256) void gn_bwd_sums16_kernel(const void* __restrict__ dact, int dstride, int L2,
+__global__ __launch_bounds__(256, 4) void gn_bwd_sums16_kernel(const void* __restrict__ dact, int dstride, int L2,
                                                             const void* __restrict__ y, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const float* __restrict__ stats,
                                                             float* __restrict__ sums, float* __restrict__ partials, int B,

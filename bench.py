@@ -251,6 +251,28 @@ _LAYER_SHAPES = [
 ]
 
 
+def _other_site(M: int, n: int, k: int, batch: int, L_in: int) -> str:
+    """Labels for the contractions outside the GPT-2 blocks (reference modules.py:36-41 the strided 1x1 conv, :114-116 the
+    patch projection, :284-290 the head, :177-186 the LoRA matrices), by shape."""
+    S, T = batch * 2911, L_in // 16
+    Mt = S * T
+    big = max(M, n, k)
+    if big == S and M == S:
+        return "head W1 fwd" if k == T * 768 else ("d head input" if n == T * 768 else "head (small)")
+    if k == S:
+        return "d head W1" if (M, n) == (576 * (T // 3 if T % 3 == 0 else 1), T * 768) or n == T * 768 else "d head W2"
+    if M == Mt:
+        return {(768, 512): "patch projection fwd", (512, 768): "d patch input", (32, 768): "lora_A fwd",
+                (768, 32): "d lora_A input"}.get((n, k), "other (token rows)")
+    if k == Mt:
+        return {(768, 512): "d patch W", (2304, 32): "d lora_B", (32, 768): "d lora_A"}.get((M, n), "other weight gradient")
+    if M in (Mt * 4, Mt * 8):
+        return "1x1 conv fwd" if n < k else "d 1x1 conv input"
+    if k in (Mt * 4, Mt * 8):
+        return "d 1x1 conv W"
+    return "other"
+
+
 def _parse_detail(key: str):
     """'kernel M=.. N=.. K=.. win=000 drop=000 split=1 act=0 acc=0 dact=0 res=0 pre=0' -> (kernel, dict)."""
     parts = key.split(" ")
@@ -340,7 +362,7 @@ def roofline_of(agg: dict, step_ms: float, steps: int, args, precision: str, bat
         pk = BF16_MFMA_PEAK_TFLOPS if ("bf16" in kern or "x3" in kern) else F32_MFMA_PEAK_TFLOPS
         fl, by, us = r["flops"] / r["n"], r["bytes"] / r["n"], r["ms"] / r["n"] * 1e3
         t_mfma, t_hbm = fl / (pk * 1e12) * 1e6, by / (HBM_PEAK_GBS * 1e9) * 1e6
-        shapes.append({"site": label or "other", "kernel": kern, "M": int(f["M"]), "N": n_, "K": k_,
+        shapes.append({"site": label or _other_site(int(f["M"]), n_, k_, batch, L_in), "kernel": kern, "M": int(f["M"]), "N": n_, "K": k_,
                        "launches_per_step": round(r["n"] / steps, 2), "avg_us": round(us, 1), "gflop": round(fl / 1e9, 1),
                        "algorithmic_mb": round(by / 1e6, 1), "t_mfma_us": round(t_mfma, 1), "t_hbm_us": round(t_hbm, 1),
                        "bound": "mfma" if t_mfma >= t_hbm else "hbm", "frac_of_bound": round(max(t_mfma, t_hbm) / us, 3),

@@ -702,13 +702,21 @@ __global__ __launch_bounds__(D3TH, 1) void gemm_bf16_dma4_kernel(const TecmGemm 
 // The summation order inside an MFMA differs from the 32x32x16 kernels': results agree to fp32 rounding, not bit for bit.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(D3TH, 1) void gemm_bf16_dma5_kernel(const TecmGemm g, int tiles_m, int tiles_n) {
+// (Round 4: the body is a template on the tile height BM.  BM = 288 -- nine 16-row MFMA tiles per wave instead of eight --
+//  exists for ONE reason: M = 69 864 rows are 273 m-tiles of 256, and with N = 768 (three n-tiles) that is 819 tiles = 3.2
+//  rounds of 256 CUs: the fourth round runs 51 tiles on 256 CUs and costs a full tile time (measured: M = 65 536 332 us,
+//  M = 69 864 407 us at K = 3072).  243 m-tiles of 288 are 729 tiles = three rounds of 1.125x the work: 3.375 against 4.
+//  The host picks per shape: rounds(BM) * BM, smaller wins -- tecm_gemm16_dma_try.)
+template <int BM>
+__device__ __forceinline__ void gemm_bf16_dma5_body(const TecmGemm& g, int tiles_m, int tiles_n, unsigned char* smem_raw) {
   constexpr int WM = 2, WN = 4;
-  constexpr int WTM = D3M / WM, WTN = D3N / WN;        // 128 x 64 per wave
-  constexpr int MT = WTM / 16, NT = WTN / 16;          // 8 x 4 tiles of 16 x 16
-  constexpr int A_ELEMS = D3M * D3K, B_ELEMS = D3N * D3K, TILE_ELEMS = A_ELEMS + B_ELEMS;   // 32 KiB
+  constexpr int WTM = BM / WM, WTN = D3N / WN;         // 128 (144) x 64 per wave
+  constexpr int MT = WTM / 16, NT = WTN / 16;          // 8 (9) x 4 tiles of 16 x 16
+  constexpr int H0 = (MT + 1) / 2, H1 = MT - H0;       // row tiles of the two halves of a K-tile
+  constexpr int A_ELEMS = BM * D3K, B_ELEMS = D3N * D3K, TILE_ELEMS = A_ELEMS + B_ELEMS;   // 32 (34) KiB
   constexpr int PIECE = 16 * D3K;                      // 16 rows of 64 B = 1 KiB
-  __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[D3ST * TILE_ELEMS * 2];
+  constexpr int NPA = BM / 16, NPB = D3N / 16, NP = NPA + NPB, PW = (NP + 7) / 8;   // DMA pieces: per K-tile, per wave
+  static_assert(BM % 32 == 0 && H1 >= 1 && H0 <= 5, "two waves of whole 16-row tiles");
   __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);
   static_assert(D3ST * TILE_ELEMS * 2 >= 8 * 32 * (WTN + 4) * 4, "epilogue slabs fit in the operand ring");
 
@@ -724,7 +732,7 @@ __global__ __launch_bounds__(D3TH, 1) void gemm_bf16_dma5_kernel(const TecmGemm 
   const int gsz = min(tiles_m - first_m, GROUP_M);
   const int in_group = wg - group * per_group;
   const int tm = first_m + in_group % gsz, tn = in_group / gsz;
-  const int64_t m0 = (int64_t)tm * D3M;
+  const int64_t m0 = (int64_t)tm * BM;
   const int64_t n0 = (int64_t)tn * D3N;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -733,13 +741,14 @@ __global__ __launch_bounds__(D3TH, 1) void gemm_bf16_dma5_kernel(const TecmGemm 
 
   const __bf16* Ah = reinterpret_cast<const __bf16*>(g.A);
   const __bf16* Bh = reinterpret_cast<const __bf16*>(g.B);
-  const __bf16* src[4];
-  int dst[4];
+  const __bf16* src[PW];
+  int dst[PW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int p = wave + 8 * i;                        // pieces 0..15 = A rows 16p.., 16..31 = B rows
-    const bool isb = p >= 16;
-    const int row = (isb ? p - 16 : p) * 16 + (lane >> 2);
+  for (int i = 0; i < PW; ++i) {
+    int p = wave + 8 * i;                              // pieces 0..NPA-1 = A rows 16p.., then the B rows
+    if (p >= NP) p -= NP;                              // (never issued: see `full` below; kept in range for the address math)
+    const bool isb = p >= NPA;
+    const int row = (isb ? p - NPA : p) * 16 + (lane >> 2);
     const int chunk = (lane & 3) ^ (3 * ((row >> 3) & 1));
     if (!isb) {
       int64_t gm = m0 + row;
@@ -750,14 +759,21 @@ __global__ __launch_bounds__(D3TH, 1) void gemm_bf16_dma5_kernel(const TecmGemm 
       int64_t gn = n0 + row;
       gn = gn < g.N ? gn : g.N - 1;
       src[i] = Bh + gn * g.ldb + chunk * 8;
-      dst[i] = A_ELEMS + (p - 16) * PIECE;
+      dst[i] = A_ELEMS + (p - NPA) * PIECE;
     }
   }
+  // the first NP - 8 (PW - 1) waves move PW pieces per K-tile, the others PW - 1: their counted waits differ accordingly
+  const bool full = (NP % 8 == 0) || wave < NP - 8 * (PW - 1);
+  auto wait_tiles = [&](auto kc) {                       // all but the youngest K tiles of this wave's DMAs have landed
+    constexpr int KT = decltype(kc)::value;
+    if (full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KT * PW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KT * (PW - 1)) : "memory");
+  };
   auto issue_tile = [&](int slot) {
     __bf16* buf = smem + slot * TILE_ELEMS;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      dma16(src[i], buf + dst[i]);
+    for (int i = 0; i < PW; ++i) {
+      if (i + 1 < PW || full) dma16(src[i], buf + dst[i]);   // wave-uniform: NP is not a multiple of 8 for the 288-row tile
       src[i] += D3K;
     }
   };
@@ -783,28 +799,26 @@ __global__ __launch_bounds__(D3TH, 1) void gemm_bf16_dma5_kernel(const TecmGemm 
     const int row = wn * WTN + j * 16 + fr;
     b_off[j] = A_ELEMS + row * D3K + ((fq ^ (3 * ((row >> 3) & 1))) << 3);
   }
-  auto mfma_half = [&](const bf16x8 (&af)[4], const bf16x8 (&bf)[NT], int i0) {
+  auto mfma_half = [&](const bf16x8 (&af)[H0], const bf16x8 (&bf)[NT], auto half) {
+    constexpr int HB = decltype(half)::value ? H0 : 0, HN = decltype(half)::value ? H1 : H0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < HN; ++i)
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        if (i0 == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-        else acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[4 + i][j], 0, 0, 0);
-      }
+      for (int j = 0; j < NT; ++j) acc[HB + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[HB + i][j], 0, 0, 0);
   };
 
   issue_tile(0);
   if (ntiles > 1) issue_tile(1);
   if (ntiles > 2) issue_tile(2);
-  if (ntiles > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if (ntiles > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  if (ntiles > 2) wait_tiles(std::integral_constant<int, 2>{});
+  else if (ntiles > 1) wait_tiles(std::integral_constant<int, 1>{});
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  bf16x8 fa[2][4], fb[2][NT];
+  bf16x8 fa[2][H0], fb[2][NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) fb[0][j] = *reinterpret_cast<const bf16x8*>(smem + b_off[j]);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) fa[0][i] = *reinterpret_cast<const bf16x8*>(smem + a_off[i]);
+  for (int i = 0; i < H0; ++i) fa[0][i] = *reinterpret_cast<const bf16x8*>(smem + a_off[i]);
   int slot = 0;
   // two K-tiles per iteration so that the B-fragment buffers alternate with compile-time indices
   auto ktile = [&](int t, auto parity) {
@@ -812,10 +826,10 @@ __global__ __launch_bounds__(D3TH, 1) void gemm_bf16_dma5_kernel(const TecmGemm 
     const __bf16* Tc = smem + slot * TILE_ELEMS;
     const int nslot = (slot + 1) & 3;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) fa[1][i] = *reinterpret_cast<const bf16x8*>(Tc + a_off[4 + i]);
-    mfma_half(fa[0], fb[P], 0);
+    for (int i = 0; i < H1; ++i) fa[1][i] = *reinterpret_cast<const bf16x8*>(Tc + a_off[H0 + i]);
+    mfma_half(fa[0], fb[P], std::integral_constant<int, 0>{});
     if (t + 1 < ntiles) {
-      if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      if (t + 2 < ntiles) wait_tiles(std::integral_constant<int, 1>{});
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       if (t + 3 < ntiles) issue_tile((slot + 3) & 3);  // the slot of tile t-1
@@ -823,9 +837,9 @@ __global__ __launch_bounds__(D3TH, 1) void gemm_bf16_dma5_kernel(const TecmGemm 
 #pragma unroll
       for (int j = 0; j < NT; ++j) fb[P ^ 1][j] = *reinterpret_cast<const bf16x8*>(Tn + b_off[j]);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[0][i] = *reinterpret_cast<const bf16x8*>(Tn + a_off[i]);
+      for (int i = 0; i < H0; ++i) fa[0][i] = *reinterpret_cast<const bf16x8*>(Tn + a_off[i]);
     }
-    mfma_half(fa[1], fb[P], 4);
+    mfma_half(fa[1], fb[P], std::integral_constant<int, 1>{});
     slot = nslot;
   };
   for (int t = 0; t < ntiles; t += 2) {
@@ -871,8 +885,31 @@ __global__ __launch_bounds__(D3TH, 1) void gemm_bf16_dma5_kernel(const TecmGemm 
   const EpiCol ecol = epi_col(g, n0 + wn * WTN + lcol);
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (g.bias && ecol.ok) bias4 = *reinterpret_cast<const float4*>(g.bias + ecol.n);
-  tecm_gemm::epi_fast_dispatch<WTM / 32, 32 / RPI, RPI, STG_LD, true>(fmode, g, odc, stg, lrow, lcol, m0 + wm * WTM, ecol, bias4,
-                                                                  stage_slab);
+  tecm_gemm::epi_fast_dispatch<MT / 2, 32 / RPI, RPI, STG_LD, true>(fmode, g, odc, stg, lrow, lcol, m0 + wm * WTM, ecol, bias4,
+                                                                stage_slab);
+  if constexpr (MT % 2 == 1) {                           // the ninth row tile: a half slab of 16 rows
+    auto stage_last = [&](auto) {
+      static_for<NT>([&](auto jc) {
+        constexpr int jn = decltype(jc)::value;
+        static_for<4>([&](auto ec) {
+          constexpr int e = decltype(ec)::value;
+          stg[(4 * fq + e) * STG_LD + jn * 16 + fr] = acc[MT - 1][jn][e];
+        });
+      });
+    };
+    tecm_gemm::epi_fast_dispatch<1, 16 / RPI, RPI, STG_LD, true>(fmode, g, odc, stg, lrow, lcol, m0 + wm * WTM + (MT - 1) * 16, ecol,
+                                                              bias4, stage_last);
+  }
+}
+
+__global__ __launch_bounds__(D3TH, 1) void gemm_bf16_dma5_kernel(const TecmGemm g, int tiles_m, int tiles_n) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[D3ST * (D3M + D3N) * D3K * 2];
+  gemm_bf16_dma5_body<D3M>(g, tiles_m, tiles_n, smem_raw);
+}
+// the same on 288-row tiles (see above): 139 264 B of LDS
+__global__ __launch_bounds__(D3TH, 1) void gemm_bf16_dma5w_kernel(const TecmGemm g, int tiles_m, int tiles_n) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[D3ST * (288 + D3N) * D3K * 2];
+  gemm_bf16_dma5_body<288>(g, tiles_m, tiles_n, smem_raw);
 }
 
 
@@ -1108,9 +1145,22 @@ int tecm_gemm16_dma_try(const TecmGemm& g, hipStream_t st) {
       TECM_CHECK_LAUNCH("tecm_gemm_bf16/dma6");
       return 1;
     }
-    const bool want16 = (sel && !k32) ? sel[0] == '5' : true;
+    const bool want16 = (sel && !k32) ? (sel[0] == '5' || sel[0] == '8') : true;
     if (k32 && !can16) return 0;                           // the 64-deep geometries below cannot take K = 32
     if (can16 && want16) {
+      // tile height: 256 rows, or 288 where that saves a mostly empty last round of blocks on the 256 CUs (N = 768 at
+      // M = 69 864: 819 tiles = 3.2 rounds of 256-row tiles, 729 = 2.85 rounds of 288-row ones); TECM_BF16_DMA = 5 / 8 force one
+      auto cost = [&](int64_t bm) {
+        const int64_t t = ((g.M + bm - 1) / bm) * tiles_n;
+        return ((t + 255) / 256) * bm;
+      };
+      const bool tall = sel && sel[0] == '8' ? true : (sel && sel[0] == '5' ? false : cost(288) * 100 < cost(DBM) * 95);
+      if (tall) {
+        const int tm288 = (int)((g.M + 287) / 288);
+        hipLaunchKernelGGL(gemm_bf16_dma5w_kernel, dim3((unsigned)(tm288 * tiles_n)), dim3(D3TH), 0, st, g, tm288, tiles_n);
+        TECM_CHECK_LAUNCH("tecm_gemm_bf16/dma5w");
+        return 1;
+      }
       hipLaunchKernelGGL(gemm_bf16_dma5_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(D3TH), 0, st, g, tiles_m, tiles_n);
       TECM_CHECK_LAUNCH("tecm_gemm_bf16/dma5");
       return 1;

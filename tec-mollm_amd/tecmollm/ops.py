@@ -217,9 +217,12 @@ def _kernel_name(g: TecmGemm, use16: bool = False) -> str:
                 (1 if g.residual else 0) + (1 if g.dact_src else 0) + (1 if g.accumulate else 0) <= 1
             if can16 and sel in ("6", "7"):                                   # four-wave blocks, two per CU (A/B)
                 return "gemm_bf16_dma6_kernel<256,128,2,2>" if sel == "6" else "gemm_bf16_dma6_kernel<128,256,1,4>"
-            want16 = sel == "5" if sel else True                              # the ring with 16x16x32 MFMAs
+            want16 = sel in ("5", "8") if (sel and not k32) else True          # the ring with 16x16x32 MFMAs
             if can16 and want16:
-                return "gemm_bf16_dma5_kernel"
+                tn_ = (g.N + 255) // 256
+                cost = lambda bm: ((((g.M + bm - 1) // bm) * tn_ + 255) // 256) * bm     # rounds of blocks on 256 CUs x tile height
+                tall = True if sel == "8" else (False if sel == "5" else cost(288) * 100 < cost(256) * 95)
+                return "gemm_bf16_dma5w_kernel" if tall else "gemm_bf16_dma5_kernel"
             return "gemm_bf16_dma4_kernel" if ring else ("gemm_bf16_dma3_kernel" if sel == "3" else "gemm_bf16_dma_kernel")
         # mirrors tecm_gemm16_tn_try (csrc/gemm_bf16_tn.hip): weight gradients from bf16 tensors in their natural orientation
         if (both16 and g.a_layout == A_KM and g.b_layout == B_KN and g.split_k >= 2 and not g.a_win.enabled

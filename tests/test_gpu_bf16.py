@@ -209,7 +209,7 @@ def test_bf16_preactivation_is_rounded_before_the_activation(dev, M, N, K):
         ops.gemm(M, N, K, A16.float(), K, B16.float(), K, c, N, act=ops.ACT_GELU_TANH, preact=(pre16, N))
 
 
-@pytest.mark.parametrize("geometry", ["5", "6", "7"], ids=["ring", "4w256x128", "4w128x256"])
+@pytest.mark.parametrize("geometry", ["5", "6", "7", "8"], ids=["ring", "4w256x128", "4w128x256", "ring288"])
 @pytest.mark.parametrize("M,N,K", [(257, 800, 2304), (1031, 2304, 800), (4099, 768, 3072), (513, 3072, 768), (300, 256, 64)])
 def test_bf16_dma_16x16x32_geometry_agrees_to_fp32_rounding(dev, M, N, K, geometry, monkeypatch):
     """gemm_bf16_dma5_kernel (v_mfma_f32_16x16x32_bf16 on the four-slot ring; TECM_BF16_DMA=5, diagnostics): another
@@ -237,6 +237,10 @@ def test_bf16_dma_16x16x32_geometry_agrees_to_fp32_rounding(dev, M, N, K, geomet
         assert torch.isfinite(g_).all() and _rel(g_, w_) < 2e-6
     diff = (got[0].float() - want[0].float()).abs()
     assert bool((diff <= want[0].float().abs() * 2.0 ** -7 + 1e-6).all())
+    if geometry == "8":                                  # the 288-row tile sums every element in the 256-row tile's order
+        monkeypatch.setenv("TECM_BF16_DMA", "5")
+        for g_, w_ in zip(got, run()):
+            assert torch.equal(g_, w_)
 
 
 def test_bf16_dma_ring_kernel_is_race_free_over_repeated_full_size_launches(dev, monkeypatch):

@@ -1154,7 +1154,8 @@ int tecm_gemm16_dma_try(const TecmGemm& g, hipStream_t st) {
         const int64_t t = ((g.M + bm - 1) / bm) * tiles_n;
         return ((t + 255) / 256) * bm;
       };
-      const bool tall = sel && sel[0] == '8' ? true : (sel && sel[0] == '5' ? false : cost(288) * 100 < cost(DBM) * 95);
+      const char* tl = std::getenv("TECM_BF16_TALL");      // "0": never (A/B diagnostics)
+      const bool tall = sel && sel[0] == '8' ? true : ((sel && sel[0] == '5') || (tl && tl[0] == '0') ? false : cost(288) * 100 < cost(DBM) * 95);
       if (tall) {
         const int tm288 = (int)((g.M + 287) / 288);
         hipLaunchKernelGGL(gemm_bf16_dma5w_kernel, dim3((unsigned)(tm288 * tiles_n)), dim3(D3TH), 0, st, g, tm288, tiles_n);

@@ -221,7 +221,8 @@ def _kernel_name(g: TecmGemm, use16: bool = False) -> str:
             if can16 and want16:
                 tn_ = (g.N + 255) // 256
                 cost = lambda bm: ((((g.M + bm - 1) // bm) * tn_ + 255) // 256) * bm     # rounds of blocks on 256 CUs x tile height
-                tall = True if sel == "8" else (False if sel == "5" else cost(288) * 100 < cost(256) * 95)
+                tall = True if sel == "8" else (False if (sel == "5" or os.environ.get("TECM_BF16_TALL", "")[:1] == "0")
+                                                else cost(288) * 100 < cost(256) * 95)
                 return "gemm_bf16_dma5w_kernel" if tall else "gemm_bf16_dma5_kernel"
             return "gemm_bf16_dma4_kernel" if ring else ("gemm_bf16_dma3_kernel" if sel == "3" else "gemm_bf16_dma_kernel")
         # mirrors tecm_gemm16_tn_try (csrc/gemm_bf16_tn.hip): weight gradients from bf16 tensors in their natural orientation

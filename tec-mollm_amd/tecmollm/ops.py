@@ -135,7 +135,7 @@ def gemm(M: int, N: int, K: int, A: torch.Tensor, lda: int, B: torch.Tensor, ldb
 
 PREC_FP32, PREC_BF16, PREC_BF16X3, PREC_BF16X6 = 0, 1, 2, 3
 IO_A_BF16, IO_B_BF16, IO_C_BF16, IO_PRE_BF16 = 1, 2, 4, 8       # TecmGemm.io_bf16
-GROUP_M = 0          # m-tiles per L2 super-tile of the fp32 GEMM (0 = the kernel's default, 8); tools/ sweep it
+GROUP_M = int(os.environ.get("TECM_GROUP_M", "0"))   # m-tiles per L2 super-tile (0 = each kernel's default); tools/ sweep it
 BF16_MIN_N = 64
 
 

@@ -9,11 +9,12 @@ synthetic (B,48,2911,10) -> (B,12,2911,1) batches).
 A step = forward + HuberLoss + backward + (RCCL all-reduce of the flat 12.3 MB gradient, the per-rank parameter
 checksums riding in its tail) + clip(1.0) + AdamW + cosine-warm-restart scheduler, training mode (every dropout
 site active), inputs resident in HBM.  Weak scaling: every rank processes `--batch` (default 8) samples;
-value = all samples / max-over-ranks time.  Rank 0 prints ONE JSON line carrying `roofline` (dominant kernel,
-measured with events on the launch stream inside the timed region) and, at N=1, `cpu_baseline` (the CPU oracle's
-train step timed on the host cores of this box) and `configs_extra` (BASELINE configs[2] = bf16 and the configs[4]
-per-GPU shape L_in=96 / L_out=24, each with its own roofline).  N > 1: `config.dist` carries the event-timed all-reduce
-(`allreduce_ms`) and the per-rank step times.
+value = all samples / max-over-ranks time.  Rank 0 prints ONE JSON line (< 4 KB: the driver parses the last stdout line)
+carrying `roofline` (dominant kernel, measured with events on the launch stream) and, at N=1, `cpu_baseline` (the CPU
+oracle's train step timed on the host cores of this box) and `configs_extra` (BASELINE configs[2] = bf16 and the
+configs[4] per-GPU shape L_in=96 / L_out=24, each with its roofline summary).  N > 1: `config.dist` carries the
+event-timed all-reduce (`allreduce_ms`).  Per-call-site GEMM tables, the non-GEMM block and per-rank lists go to
+`bench_detail.json` (--detail-json) next to this script.
 """
 from __future__ import annotations
 
@@ -38,6 +39,98 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16
 HBM_PEAK_GBS = 8000.0
 
 
+LINE_BUDGET = 4096          # bytes of the LAST stdout line; the driver keeps ~8 KB of stdout tail and parses that line
+
+
+def _compact_roofline(r):
+    """The scalar roofline summary the headline line carries; per-shape and non-GEMM tables go to the side file."""
+    if not r:
+        return r, None
+    keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "launches", "avg_launch_ms", "share_of_step",
+            "all_gemm_share_of_step")
+    out = {k: r[k] for k in keep if k in r}
+    t = r.get("traffic")
+    out["traffic"] = t["hbm_bytes_per_launch"] if isinstance(t, dict) else t
+    if isinstance(t, dict):
+        out["traffic_source"] = t.get("source")
+    st = r.get("step")
+    if st:
+        out["step"] = {k: st[k] for k in ("algorithmic_tflops", "peak", "frac_of_peak") if k in st}
+    detail = {k: r[k] for k in ("shapes", "non_gemm", "timing", "traffic", "step") if r.get(k) is not None}
+    return out, detail
+
+
+def compact_line(line: dict):
+    """(headline, detail): `headline` is the ONE JSON object printed as the last stdout line -- headline scalars, a scalar
+    roofline summary, cpu_baseline, parity and each configs_extra leg as scalars + its roofline.{kernel, frac, step} --
+    and always serialises to fewer than LINE_BUDGET bytes; `detail` carries everything that was cut (per-call-site GEMM
+    tables, the non-GEMM block, per-rank lists, long sample descriptions) and is written next to the script."""
+    head = dict(line)
+    detail = {"headline_of": {k: line.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step")}}
+    head["roofline"], d = _compact_roofline(line.get("roofline"))
+    if d:
+        detail["roofline"] = d
+    cb = line.get("cpu_baseline")
+    if cb:
+        head["cpu_baseline"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in cb.items()
+                                if k in ("value", "unit", "cores", "kind", "median_step_s", "sample")}
+        head["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:160]
+        detail["cpu_baseline"] = cb
+    par = line.get("parity")
+    if par:
+        head["parity"] = {k: float(f"{par[k]:.4g}") for k in ("rmse_vs_ref", "max_rel_err", "r2_vs_ref", "ref_rms") if k in par}
+        detail["parity"] = par
+    cfg = dict(line.get("config") or {})
+    di = cfg.get("dist")
+    if di:
+        detail["dist"] = di
+        d2 = {k: v for k, v in di.items() if not isinstance(v, dict)}
+        ar = di.get("allreduce_ms")
+        if ar:
+            d2["allreduce_ms"] = {k: ar[k] for k in ("mean_over_ranks", "max_over_ranks", "bytes", "launches") if k in ar}
+        sr = di.get("step_ms_per_rank")
+        if sr:
+            d2["step_ms_per_rank"] = {k: sr[k] for k in ("min_over_ranks", "max_over_ranks", "slowest_single_step") if k in sr}
+        cfg["dist"] = d2
+    head["config"] = cfg
+    for group in ("configs_extra", "other_precisions"):
+        legs = line.get(group)
+        if not legs:
+            continue
+        head[group], detail[group] = {}, {}
+        for name, leg in legs.items():
+            h = {k: v for k, v in leg.items() if k not in ("roofline", "workload")}
+            h["workload"] = str(leg.get("workload", ""))[:96]
+            r, d = _compact_roofline(leg.get("roofline"))
+            if r:
+                h["roofline"] = {k: r[k] for k in ("kernel", "achieved", "peak", "frac", "avg_launch_ms", "share_of_step", "step") if k in r}
+            head[group][name] = h
+            detail[group][name] = dict(leg)
+    text = json.dumps(head)
+    if len(text) >= LINE_BUDGET:                           # last resort, never reached with today's fields: drop legs
+        for group in ("other_precisions", "configs_extra"):
+            if group in head and len(json.dumps(head)) >= LINE_BUDGET:
+                head[group] = {k: {kk: vv for kk, vv in v.items() if kk in ("samples_per_s", "ms_per_step", "dtype")}
+                               for k, v in head[group].items()}
+    return head, detail
+
+
+def emit(line: dict, detail_path=None):
+    """Write the detail side file, then print the compact headline as the last stdout line."""
+    head, detail = compact_line(line)
+    path = detail_path or os.environ.get("TECM_BENCH_DETAIL", os.path.join(ROOT, "bench_detail.json"))
+    try:
+        with open(path, "w") as f:
+            json.dump(detail, f, indent=1)
+        head["detail"] = os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
+    except OSError as e:                                   # a read-only checkout must not cost the headline
+        head["detail"] = f"not written: {e.__class__.__name__}"
+    text = json.dumps(head)
+    assert len(text) < LINE_BUDGET, f"bench line is {len(text)} bytes; the driver parses at most ~{LINE_BUDGET}"
+    print(text, flush=True)
+    return head
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -60,6 +153,9 @@ def parse():
                     help="skip configs_extra (the bf16 and L_in=96 legs that follow the main run at N=1 with default flags)")
     ap.add_argument("--emulation-modes", action="store_true",
                     help="also time the opt-in bf16x6 / bf16x3 modes (context only; not part of the default run)")
+    ap.add_argument("--detail-json", default=None,
+                    help="where the per-shape / non-GEMM tables go (default: bench_detail.json next to this script); "
+                         "the last stdout line stays under 4 KB")
     ap.add_argument("--data", choices=["fixed", "window"], default="fixed",
                     help="fixed: one resident batch (default).  window: every step's batch is drawn by the device "
                          "window sampler (tecm_window_batch) from a resident synthetic series, as train.py:57-65 "
@@ -649,7 +745,7 @@ def main():
                 line["other_precisions"] = {m: extra_config(cfg, args, dev, m, ei, ew, PRECISION_TEXT[m],
                                                             with_roofline=False, steps=5)
                                             for m in ("bf16x6", "bf16x3")}
-        print(json.dumps(line), flush=True)
+        emit(line, args.detail_json)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -582,3 +582,41 @@ _Zkernel:
     for bad in (early_use, copied, smem, across):
         with pytest.raises(RuntimeError):
             ge.audit_hand_issued_lds_reads(bad, "bad")
+
+def test_bench_line_stays_under_the_drivers_parse_budget():
+    """The driver parses the LAST stdout line of bench.py out of ~8 KB of kept tail.  Round 4's line (committed as
+    profiles/r04_bench_default.json: 24 KB with per-shape tables) was cut -> parsed: null.  compact_line() must turn that
+    very line -- and an 8-rank one with per-rank lists -- into < 4 KB carrying every contract key, with the tables moved
+    to the detail object."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_default.json")))
+    assert len(json.dumps(full)) > 20000
+    head, detail = bench.compact_line(full)
+    text = json.dumps(head)
+    assert len(text) < bench.LINE_BUDGET == 4096
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity", "configs_extra"):
+        assert head[k] == full[k] or k in ("roofline", "cpu_baseline", "parity", "configs_extra", "config"), k
+    rf = head["roofline"]
+    assert rf["frac"] == full["roofline"]["frac"] and rf["traffic"] == full["roofline"]["traffic"]["hbm_bytes_per_launch"]
+    assert rf["step"]["frac_of_peak"] == full["roofline"]["step"]["frac_of_peak"] and "shapes" not in rf and "non_gemm" not in rf
+    assert head["cpu_baseline"]["cores"] == 16 and head["cpu_baseline"]["kind"] == "port"
+    assert head["configs_extra"]["bf16"]["roofline"]["frac"] == full["configs_extra"]["bf16"]["roofline"]["frac"]
+    assert detail["roofline"]["shapes"] == full["roofline"]["shapes"]
+    assert detail["configs_extra"]["L96"]["roofline"]["non_gemm"] == full["configs_extra"]["L96"]["roofline"]["non_gemm"]
+    # an 8-rank line: per-rank lists must not ride in the headline
+    eight = {k: v for k, v in full.items() if k not in ("configs_extra", "cpu_baseline", "parity")}
+    eight["n_gpus"] = 8
+    eight["config"] = dict(full["config"], dist={
+        "backend": "nccl", "world_size": 8, "allreduce_of_ones": 8.0, "launcher": "torchrun", "param_checksum_min_eq_max": True,
+        "allreduce_ms": {"mean_over_ranks": 0.5, "max_over_ranks": 0.9, "per_rank_mean": [0.5] * 8, "bytes": 12327984,
+                         "launches": 10, "note": "x" * 200},
+        "step_ms_per_rank": {"mean": [64.0] * 8, "min_over_ranks": 63.9, "max_over_ranks": 64.2, "slowest_single_step": 64.9}})
+    h8, d8 = bench.compact_line(eight)
+    assert len(json.dumps(h8)) < 4096 and "per_rank_mean" not in json.dumps(h8)
+    assert h8["config"]["dist"]["allreduce_ms"]["bytes"] == 12327984 and h8["config"]["dist"]["world_size"] == 8
+    assert d8["dist"]["allreduce_ms"]["per_rank_mean"] == [0.5] * 8

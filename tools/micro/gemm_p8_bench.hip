@@ -1,0 +1,168 @@
+// Stand-alone check + timing of the eight-phase bf16 K loop (csrc/gemm_bf16_p8_loop.h) with a bare fp32 store epilogue:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I tec-mollm_amd/csrc tools/micro/gemm_p8_bench.hip -o tools/micro/gemm_p8_bench
+//   tools/micro/gemm_p8_bench [M N K]...      (default: 4096^3, 8192^3 and the GPT-2 shapes of the B = 8 step)
+// Operands: uniform random in [-1, 1) (never zeros: the clock a GPU holds depends on the data).  Every shape is checked
+// on 192 sampled rows (all columns) against a plain fp32-accumulate kernel, and screened for races by comparing 12
+// launches bit for bit.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <type_traits>
+#include "gemm_bf16_p8_loop.h"
+
+using namespace tecm_p8;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
+
+template <bool NOEPI>
+__global__ __launch_bounds__(NTH, 1) void p8_plain_kernel(Operands o, float* C, int64_t ldc, int tiles_m, int tiles_n, int group_m) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];
+  const int nwg = tiles_m * tiles_n;
+  const int id = blockIdx.x;
+  const int xcd = id & 7, local = id >> 3;
+  const int q8 = nwg >> 3, r8 = nwg & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
+  const int per_group = group_m * tiles_n;
+  const int group = wg / per_group;
+  const int first_m = group * group_m;
+  const int gsz = min(tiles_m - first_m, group_m);
+  const int in_group = wg - group * per_group;
+  const int tm = first_m + in_group % gsz, tn = in_group / gsz;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+  kloop(o, m0, n0, smem, acc);
+  if constexpr (NOEPI) {
+  float keep = 0.f;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) keep += acc[i][j][e];
+  if (keep == 12345.678f) C[0] = keep;
+  return;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 2, wc = wave & 3, fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int64_t m = m0 + wr * 128 + 16 * i + 4 * fq + e, n = n0 + wc * 64 + 16 * j + fr;
+        if (m < o.M && n < o.N) C[m * ldc + n] = acc[i][j][e];
+      }
+}
+
+__global__ void ref_rows_kernel(Operands o, const int* rows, int nrows, float* out) {
+  const int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int r = blockIdx.y;
+  if (n >= o.N || r >= nrows) return;
+  const __bf16* a = o.A + (int64_t)rows[r] * o.lda;
+  const __bf16* b = o.B + n * o.ldb;
+  float s = 0.f;
+  for (int k = 0; k < o.K; ++k) s += (float)a[k] * (float)b[k];
+  out[(int64_t)r * o.N + n] = s;
+}
+
+__global__ void fill_kernel(__bf16* p, int64_t n, uint64_t seed) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    uint64_t z = (uint64_t)i * 0x9E3779B97F4A7C15ull + seed;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+    p[i] = (__bf16)((float)(z >> 40) * (2.0f / 16777216.0f) - 1.0f);
+  }
+}
+
+static int run(int64_t M, int64_t N, int K, int group_m) {
+  __bf16 *A, *B; float *C, *C2, *ref; int* rows_d;
+  CK(hipMalloc(&A, M * K * 2)); CK(hipMalloc(&B, N * K * 2)); CK(hipMalloc(&C, M * N * 4)); CK(hipMalloc(&C2, M * N * 4));
+  fill_kernel<<<2048, 256>>>(A, M * K, 1); fill_kernel<<<2048, 256>>>(B, N * K, 2);
+  CK(hipMemset(C, 0xff, M * N * 4));
+  Operands o{A, B, K, K, M, N, K};
+  const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
+  auto launch = [&](float* dst) { hipLaunchKernelGGL(p8_plain_kernel<false>, dim3(tiles_m * tiles_n), dim3(NTH), 0, 0, o, dst, N, tiles_m, tiles_n, group_m); };
+  launch(C);
+  CK(hipDeviceSynchronize());
+  // ---- reference rows: first / last rows, tile edges, and a spread
+  const int NR = 192;
+  std::vector<int> rows(NR);
+  for (int i = 0; i < NR; ++i) rows[i] = (int)(((int64_t)i * 2654435761u) % M);
+  rows[0] = 0; rows[1] = (int)M - 1; rows[2] = 255; rows[3] = 256; rows[4] = (int)(M - 1) / 256 * 256; rows[5] = 127; rows[6] = 128; rows[7] = 63; rows[8] = 64;
+  CK(hipMalloc(&rows_d, NR * 4)); CK(hipMalloc(&ref, (int64_t)NR * N * 4));
+  CK(hipMemcpy(rows_d, rows.data(), NR * 4, hipMemcpyHostToDevice));
+  ref_rows_kernel<<<dim3((unsigned)((N + 255) / 256), NR), 256>>>(o, rows_d, NR, ref);
+  CK(hipDeviceSynchronize());
+  std::vector<float> hr((size_t)NR * N), hc(N);
+  CK(hipMemcpy(hr.data(), ref, (size_t)NR * N * 4, hipMemcpyDeviceToHost));
+  double worst = 0, scale = 0;
+  for (int r = 0; r < NR; ++r) {
+    CK(hipMemcpy(hc.data(), C + (int64_t)rows[r] * N, N * 4, hipMemcpyDeviceToHost));
+    for (int64_t n = 0; n < N; ++n) {
+      double d = fabs((double)hc[n] - hr[(size_t)r * N + n]);
+      if (!(d <= worst)) worst = d;                      // NaN-propagating
+      scale = fmax(scale, fabs((double)hr[(size_t)r * N + n]));
+    }
+  }
+  const bool ok = worst <= 2e-5 * scale * sqrt((double)K / 64);
+  // ---- race screen: 12 launches, bit for bit
+  int diff = 0;
+  std::vector<float> h1((size_t)M * N), h2((size_t)M * N);
+  CK(hipMemcpy(h1.data(), C, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+  for (int it = 0; it < 12; ++it) {
+    CK(hipMemset(C2, 0xff, M * N * 4));
+    launch(C2);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(h2.data(), C2, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+    if (memcmp(h1.data(), h2.data(), (size_t)M * N * 4) != 0) ++diff;
+  }
+  // ---- timing
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 5; ++i) launch(C);
+  const int iters = 30;
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < iters; ++i) launch(C);
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  const double us = ms * 1e3 / iters, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
+  // K loop alone (accumulators kept live, nothing stored)
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(p8_plain_kernel<true>, dim3(tiles_m * tiles_n), dim3(NTH), 0, 0, o, C, N, tiles_m, tiles_n, group_m);
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(p8_plain_kernel<true>, dim3(tiles_m * tiles_n), dim3(NTH), 0, 0, o, C, N, tiles_m, tiles_n, group_m);
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  const double us0 = ms * 1e3 / iters, tf0 = 2.0 * M * N * K / (us0 * 1e-6) / 1e12;
+  printf("M=%lld N=%lld K=%d group_m=%d  %.1f us  %.1f TFLOP/s | K loop alone %.1f us %.1f TFLOP/s | max|err|=%.3g (scale %.3g) %s  race-screen %d/12 differ\n",
+         (long long)M, (long long)N, K, group_m, us, tf, us0, tf0, worst, scale, ok ? "OK" : "WRONG", diff);
+  fflush(stdout);
+  hipFree(A); hipFree(B); hipFree(C); hipFree(C2); hipFree(ref); hipFree(rows_d);
+  return ok && diff == 0 ? 0 : 1;
+}
+
+int main(int argc, char** argv) {
+  int bad = 0;
+  const int gm = getenv("P8_GROUP_M") ? atoi(getenv("P8_GROUP_M")) : 4;
+  if (argc >= 4) {
+    for (int i = 1; i + 2 < argc; i += 3) bad += run(atoll(argv[i]), atoll(argv[i + 1]), atoi(argv[i + 2]), gm);
+    return bad;
+  }
+  bad += run(512, 512, 128, gm);
+  bad += run(1000, 700, 192, gm);
+  bad += run(4096, 4096, 4096, gm);
+  bad += run(8192, 8192, 8192, gm);
+  bad += run(69864, 3072, 768, gm);
+  bad += run(69864, 768, 3072, gm);
+  bad += run(69864, 768, 768, gm);
+  bad += run(69864, 2304, 832, gm);
+  return bad;
+}

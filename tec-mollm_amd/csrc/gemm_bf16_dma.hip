@@ -1088,6 +1088,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma6_kernel(const TecmGemm g
 
 }  // namespace tecm_gemm16
 
+int tecm_gemm16_p8_try(const TecmGemm& g, hipStream_t st);      // gemm_bf16_p8.hip
+
 // Returns the number of K splits (1) when the DMA kernel served the call, 0 when the call is not eligible.
 int tecm_gemm16_dma_try(const TecmGemm& g, hipStream_t st) {
   using namespace tecm_gemm16;
@@ -1110,6 +1112,12 @@ int tecm_gemm16_dma_try(const TecmGemm& g, hipStream_t st) {
     hipLaunchKernelGGL(gemm_bf16_dma_kernel, dim3((unsigned)(wtm * wtn)), dim3(DNTH), 0, st, g, wtm, wtn);
     TECM_CHECK_LAUNCH("tecm_gemm_bf16/dma-window");
     return 1;
+  }
+  // round 5: the eight-phase geometry (gemm_bf16_p8.hip) wherever it is eligible (it declines n-tiles that are mostly
+  // padding, N = 800, unless forced); TECM_BF16_P8 = 0 or any TECM_BF16_DMA selection keeps the older geometries
+  {
+    const int streams = (g.residual ? 1 : 0) + (g.dact_src ? 1 : 0) + (g.accumulate ? 1 : 0);
+    if (!sel && !g.c_win.enabled && !g.rowbias && streams <= 1 && tecm_gemm16_p8_try(g, st)) return 1;
   }
   // the 128-column geometry where the 256-column tile would waste more than half of its last n-tile (N = 800);
   // TECM_BF16_DMA = 1 / 2 forces one of the two (A/B diagnostics, tools/dma_ab.sh)

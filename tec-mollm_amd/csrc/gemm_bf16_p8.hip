@@ -1,0 +1,118 @@
+// bf16 GEMM, eighth geometry (round 5): the eight-phase K loop of gemm_bf16_p8_loop.h (256 x 256 x 64 tile, half-tile
+// LDS-DMA ring kept in flight across raw barriers, two wave groups half a phase apart) behind the straight-line
+// epilogue of the ring kernels (gemm_bf16_dma.hip, fifth geometry: same wave tile 128 x 64 = 8 x 4 tiles of 16 x 16,
+// same C/D map, so the parking of the accumulators and epi_fast_dispatch are used as they are).  Serves the plain
+// MK x NK contractions with both operands bf16 tensors: 7 of the 8 big GPT-2 GEMMs of a layer in bf16 mode (BASELINE
+// configs[2]; reference call sites modules.py:205-209, arithmetic train.py:68).
+//
+// Measured (round 5, M = 69 864, random operands; fifth geometry -> this): K loop alone N=3072 K=768 362 -> 252-257 us,
+// N=768 K=3072 398 -> 284 us; 8192^3 with a bare store epilogue 1.11 -> 1.31 PFLOP/s (K loop alone 1.53).
+// The summation order is the fifth geometry's per MFMA but K is walked 64 at a time in quadrant order: results agree
+// with it to fp32 rounding (test_bf16_p8_geometry_agrees_to_fp32_rounding), and launches are bit-reproducible.
+#include <cstdlib>
+#include "gemm_bf16_impl.h"
+#include "gemm_bf16_p8_loop.h"
+
+namespace tecm_gemm16 {
+
+__global__ __launch_bounds__(tecm_p8::NTH, 1) void gemm_bf16_p8_kernel(const TecmGemm g, int tiles_m, int tiles_n) {
+  // (names qualified on purpose: tecm_gemm16 has its own BM / BN / BK, which would hide tecm_p8's behind a using-directive)
+  constexpr int BM = tecm_p8::BM, BN = tecm_p8::BN, MT = tecm_p8::MT, NT = tecm_p8::NT, LDS_BYTES = tecm_p8::LDS_BYTES;
+  constexpr int WTM = 128, WTN = 64;
+  static_assert(BM == 256 && BN == 256 && MT * 16 == WTM && NT * 16 == WTN, "wave tile 128 x 64 of a 256 x 256 block tile");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[LDS_BYTES];
+  static_assert(LDS_BYTES >= 8 * 32 * (WTN + 4) * 4, "epilogue slabs fit in the operand ring");
+
+  // block -> tile map: XCD-contiguous runs, GROUP_M m-tiles per L2 super-tile (as the other geometries)
+  const int nwg = tiles_m * tiles_n;
+  const int id = blockIdx.x;
+  const int xcd = id & 7, local = id >> 3;
+  const int q8 = nwg >> 3, r8 = nwg & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
+  const int GROUP_M = g._p1 > 0 ? g._p1 : 4;
+  const int per_group = GROUP_M * tiles_n;
+  const int group = wg / per_group;
+  const int first_m = group * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int in_group = wg - group * per_group;
+  const int tm = first_m + in_group % gsz, tn = in_group / gsz;
+  const int64_t m0 = (int64_t)tm * BM;
+  const int64_t n0 = (int64_t)tn * BN;
+
+  tecm_p8::f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+  const tecm_p8::Operands o{reinterpret_cast<const __bf16*>(g.A), reinterpret_cast<const __bf16*>(g.B), g.lda, g.ldb, g.M, g.N, (int)g.K};
+  tecm_p8::kloop(o, m0, n0, smem_raw, acc);
+  __syncthreads();                                      // every wave has left the K loop: the ring becomes staging
+#ifdef DMA_ABLATE_NOEPI                                  // diagnostics (tools/build_variant.py): K loop without the epilogue
+  {
+    float keep = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) keep += acc[i][j][e];
+    if (keep == 12345.678f) reinterpret_cast<float*>(g.C)[0] = keep;
+    return;
+  }
+#endif
+
+  // ---- epilogue: gemm_impl.h's straight-line form over this wave's private staging rows (16x16 C/D map:
+  // row = 4 (lane >> 4) + reg, col = lane & 15)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+  constexpr int STG_LD = WTN + 4;
+  const DropCtx odc = make_drop(g.out_drop);
+  float* stg = reinterpret_cast<float*>(smem_raw) + wave * (32 * STG_LD);
+  auto stage_slab = [&](auto ic) {                     // 32 accumulator rows = tile rows 2 i, 2 i + 1
+    constexpr int i = decltype(ic)::value;
+    static_for<2>([&](auto tc) {
+      constexpr int ti = decltype(tc)::value;
+      static_for<NT>([&](auto jc) {
+        constexpr int jn = decltype(jc)::value;
+        static_for<4>([&](auto ec) {
+          constexpr int e = decltype(ec)::value;
+          stg[(16 * ti + 4 * fq + e) * STG_LD + jn * 16 + fr] = acc[2 * i + ti][jn][e];
+        });
+      });
+    });
+  };
+  const int fmode = tecm_gemm::epi_fast_mode(g);         // >= 0: checked on the host (tecm_gemm16_p8_try)
+  constexpr int LPR = WTN / 4, RPI = 64 / LPR;
+  const int lcol = (lane % LPR) * 4, lrow = lane / LPR;
+  const EpiCol ecol = epi_col(g, n0 + wn * WTN + lcol);
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (g.bias && ecol.ok) bias4 = *reinterpret_cast<const float4*>(g.bias + ecol.n);
+  tecm_gemm::epi_fast_dispatch<MT / 2, 32 / RPI, RPI, STG_LD, true>(fmode, g, odc, stg, lrow, lcol, m0 + wm * WTM, ecol, bias4,
+                                                                stage_slab);
+}
+
+}  // namespace tecm_gemm16
+
+// 1 when this geometry served the call, 0 when the call is not eligible (the caller falls through to the ring kernels).
+// Eligibility beyond the ring kernels' (checked by the caller: both operands bf16, plain views, float4 epilogue, one
+// optional input stream): K >= 128 in whole 32-column halves, tiles of 256 rows, both operands addressable with 32-bit
+// byte offsets, and no mostly empty last n-tile below N = 768.
+int tecm_gemm16_p8_try(const TecmGemm& g, hipStream_t st) {
+  using namespace tecm_gemm16;
+  const char* sel = std::getenv("TECM_BF16_P8");         // "0": never (A/B diagnostics), "1": also where the default declines
+  if (sel && sel[0] == '0') return 0;
+  const bool force = sel && sel[0] == '1';
+  if (g.K < 128 || g.K % 32 != 0 || g.M < tecm_p8::BM || g.N < 128) return 0;
+  if ((g.M * g.lda + 64) * 2 >= (int64_t(1) << 32) || (g.N * g.ldb + 64) * 2 >= (int64_t(1) << 32)) return 0;
+  // a last n-tile that is mostly padding is only worth it from N = 768 on (N = 800, d c_attn: 290 us here against 344 on
+  // the 128-column geometry; N = 576 / 384 / 128, the head and the 1x1 convs: 174 / 120 / 128 us against 147 / 88 / 102)
+  const int nrem = (int)(g.N % tecm_p8::BN);
+  if (!force && nrem >= 1 && nrem <= 128 && g.N < 768) return 0;
+  const int tiles_m = (int)((g.M + tecm_p8::BM - 1) / tecm_p8::BM), tiles_n = (int)((g.N + tecm_p8::BN - 1) / tecm_p8::BN);
+  hipLaunchKernelGGL(gemm_bf16_p8_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(tecm_p8::NTH), 0, st, g, tiles_m, tiles_n);
+  TECM_CHECK_LAUNCH("tecm_gemm_bf16/p8");
+  return 1;
+}

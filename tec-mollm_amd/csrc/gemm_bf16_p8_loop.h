@@ -50,8 +50,9 @@ constexpr int MT = 8, NT = 4;                         // accumulator tiles of 16
 
 struct Operands {
   const __bf16* A; const __bf16* B;                   // [M][lda], [N][ldb], bf16, 16-byte aligned rows
-  int64_t lda, ldb, M, N; int K;                      // K % 64 == 0, K >= 128; byte offsets of both operands < 4 GiB
-};
+  int64_t lda, ldb, M, N; int K;                      // K % 32 == 0, K >= 128; byte offsets of both operands < 4 GiB
+};                                                    // (K % 64 == 32, c_attn with its 32 LoRA columns: the last K-tile is
+                                                      //  half deep -- its DMAs re-read the valid half, its MFMAs stop at k = 32)
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void bar() {
@@ -66,10 +67,16 @@ __device__ __forceinline__ void kloop(const Operands& o, int64_t m0, int64_t n0,
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int fr = lane & 15, fq = lane >> 4;
-  const int T = o.K / BK, S = 4 * T;
+  const int T = (o.K + BK - 1) / BK, S = 4 * T;
+  const bool ktail = (o.K % BK) != 0;
 
   // ---- DMA sources: per kind (A0, B0, B1, A1) and piece (2) a 32-bit byte offset from the operand base
-  uint32_t soff[4][2];
+  uint32_t soff[4][2], tadj[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {                       // half-deep last tile: chunks 4..7 lie beyond K -> fetch chunk - 4 again
+    const int lr = 16 * wave + 8 * i + (lane >> 3);
+    tadj[i] = (((lane & 7) ^ ((lr >> 1) & 7)) >= 4) ? 64u : 0u;
+  }
 #pragma unroll
   for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -91,14 +98,15 @@ __device__ __forceinline__ void kloop(const Operands& o, int64_t m0, int64_t n0,
   const char* Ab = reinterpret_cast<const char*>(o.A);
   const char* Bb = reinterpret_cast<const char*>(o.B);
   int kA0 = 0, kB0 = 0, kB1 = 0, kA1 = 0;              // bytes along K already issued, per kind (wave-uniform)
-  auto issue = [&](auto kc, int slot_bytes) {
+  auto issue = [&](auto kc, int slot_bytes, bool tail_tile = false) {
     constexpr int k = decltype(kc)::value;
+    const uint32_t tm = tail_tile ? 0xffffffffu : 0u;
     constexpr bool isA = (k == 0 || k == 3);
     int& kk = k == 0 ? kA0 : (k == 1 ? kB0 : (k == 2 ? kB1 : kA1));
     const char* base = (isA ? Ab : Bb) + kk;
     unsigned char* dst = smem + slot_bytes + k * HALF_BYTES + wave * 2048;
-    __builtin_amdgcn_global_load_lds((glb_void*)(base + soff[k][0]), (lds_void*)dst, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((glb_void*)(base + soff[k][1]), (lds_void*)(dst + 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_void*)(base + (soff[k][0] - (tadj[0] & tm))), (lds_void*)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_void*)(base + (soff[k][1] - (tadj[1] & tm))), (lds_void*)(dst + 1024), 16, 0, 0);
     kk += BK * 2;
   };
   using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
@@ -128,23 +136,25 @@ __device__ __forceinline__ void kloop(const Operands& o, int64_t m0, int64_t n0,
       for (int j = 0; j < 2; ++j)
         fb[j][ks] = *reinterpret_cast<const bf16x8*>(smem + slot_bytes + kind * HALF_BYTES + boff[ks] + j * 2048);
   };
-  auto quadrant = [&](auto hac, auto hbc, const bf16x8 (&fb)[2][2]) {
+  auto quadrant = [&](auto hac, auto hbc, const bf16x8 (&fb)[2][2], bool half_deep) {
     constexpr int HA = decltype(hac)::value, HB = decltype(hbc)::value;
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int ks = 0; ks < 2; ++ks) {
+      if (ks == 1 && half_deep) break;                  // wave-uniform
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[4 * HA + i][2 * HB + j] =
               __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[j][ks], acc[4 * HA + i][2 * HB + j], 0, 0, 0);
+    }
     __builtin_amdgcn_s_setprio(0);
   };
 
   // ---- prologue: six half-tiles (K-tile 0, A0/B0 of K-tile 1), wait for A0, B0 of tile 0
   issue(K0{}, 0); issue(K1{}, 0); issue(K2{}, 0); issue(K3{}, 0);
-  issue(K0{}, BUF_BYTES); issue(K1{}, BUF_BYTES);
+  issue(K0{}, BUF_BYTES, ktail && T == 2); issue(K1{}, BUF_BYTES, ktail && T == 2);
   wait_vm<8>();
   bar();
   if (wr == 1) bar();                                   // the second wave group runs one barrier (half a phase) behind
@@ -153,33 +163,35 @@ __device__ __forceinline__ void kloop(const Operands& o, int64_t m0, int64_t n0,
     constexpr int cur = decltype(dc)::value * BUF_BYTES, oth = BUF_BYTES - cur;
     const int g = 4 * t;
     const bool last = t + 1 == T;
+    const bool hd = last && ktail;                       // this tile is the half-deep one
+    const bool tl1 = ktail && t + 2 == T, tl2 = ktail && t + 3 == T;   // ... or the next / next-but-one is
     // phase 0: c[0][0]
     read_b(fb0, cur, 1);
     __builtin_amdgcn_sched_barrier(0);
     read_a(cur, 0);
-    if (g + 6 < S) issue(K2{}, oth);
+    if (g + 6 < S) issue(K2{}, oth, tl1);
     if (!last) wait_vm<8>(); else wait_vm<2>();
     bar();
-    quadrant(K0{}, K0{}, fb0);
+    quadrant(K0{}, K0{}, fb0, hd);
     bar();
     // phase 1: c[0][1]
     read_b(fb1, cur, 2);
-    if (g + 7 < S) issue(K3{}, oth);
+    if (g + 7 < S) issue(K3{}, oth, tl1);
     if (!last) wait_vm<8>(); else wait_vm<0>();
     bar();
-    quadrant(K0{}, K1{}, fb1);
+    quadrant(K0{}, K1{}, fb1, hd);
     bar();
     // phase 2: c[1][1]
     read_a(cur, 3);
-    if (g + 8 < S) issue(K0{}, cur);
+    if (g + 8 < S) issue(K0{}, cur, tl2);
     bar();
-    quadrant(K1{}, K1{}, fb1);
+    quadrant(K1{}, K1{}, fb1, hd);
     bar();
     // phase 3: c[1][0]
-    if (g + 9 < S) issue(K1{}, cur);
+    if (g + 9 < S) issue(K1{}, cur, tl2);
     if (t + 2 < T) wait_vm<8>(); else if (!last) wait_vm<4>();
     bar();
-    quadrant(K1{}, K0{}, fb0);
+    quadrant(K1{}, K0{}, fb0, hd);
     bar();
   };
   for (int t = 0; t < T; t += 2) {

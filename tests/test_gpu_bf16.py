@@ -271,11 +271,69 @@ def test_bf16_dma_ring_kernel_is_race_free_over_repeated_full_size_launches(dev,
         for o in outs:
             ops.gemm(M, N, K, A16, K, B16, K, o, N, bias=bias, bf16=True)
         torch.cuda.synchronize()
+        assert all("gemm_bf16_p8_kernel" in name for name in ops.summarize_gemm_timing(rec))
+        ops.disable_gemm_timing()
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0])
+        assert _rel(outs[0], want) < 2e-6
+        # and the ring kernel it replaced (TECM_BF16_P8 = 0)
+        monkeypatch.setenv("TECM_BF16_P8", "0")
+        rec = ops.enable_gemm_timing()
+        for o in outs:
+            ops.gemm(M, N, K, A16, K, B16, K, o, N, bias=bias, bf16=True)
+        torch.cuda.synchronize()
         assert all("dma5" in name for name in ops.summarize_gemm_timing(rec))
         ops.disable_gemm_timing()
         for o in outs[1:]:
             assert torch.equal(o, outs[0])
         assert _rel(outs[0], want) < 2e-6
+        monkeypatch.delenv("TECM_BF16_P8")
+
+
+@pytest.mark.parametrize("M,N,K", [(257, 768, 128), (1031, 2304, 800), (4099, 768, 3072), (513, 3072, 768), (300, 256, 160),
+                                   (256, 800, 2304), (70000, 768, 768)])
+def test_bf16_p8_geometry_agrees_to_fp32_rounding(dev, M, N, K, monkeypatch):
+    """gemm_bf16_p8_kernel (round 5: 256 x 256 x 64 eight-phase K loop, half-tile LDS-DMA ring across raw barriers, wave
+    groups half a phase apart; csrc/gemm_bf16_p8_loop.h) against the two-slot 32x32x16 kernel: another summation order,
+    so fp32 outputs agree to 2e-6 of the largest value and bf16 outputs to one ulp.  Shapes: ragged M and N tiles, the
+    shortest K (two K-tiles: the prologue IS the pipeline), K % 64 == 32 (the half-deep last tile of c_attn + LoRA, also
+    with an odd tile count 160 = 2.5 tiles), N = 800 forced through it (TECM_BF16_P8 = 1), and 274 m-tiles (more blocks
+    than CUs); epilogues: GELU + bf16 C + pre-activation, residual + dropout, GELU'."""
+    from tecmollm import ops
+    A16, B16 = _rand(M, K, dev=dev, seed=1).bfloat16(), _rand(N, K, dev=dev, seed=2, scale=0.05).bfloat16()
+    bias, res, pre_src = _rand(N, dev=dev, seed=4), _rand(M, N, dev=dev, seed=5), _rand(M, N, dev=dev, seed=6)
+
+    def run(expect):
+        rec = ops.enable_gemm_timing()
+        c16, pre = torch.empty(M, N, device=dev, dtype=torch.bfloat16), torch.full((M, N), float("nan"), device=dev)
+        ops.gemm(M, N, K, A16, K, B16, K, c16, N, bias=bias, act=ops.ACT_GELU_TANH, preact=(pre, N), bf16=True)
+        c = torch.full((M, N), float("nan"), device=dev)
+        ops.gemm(M, N, K, A16, K, B16, K, c, N, bias=bias, out_drop=ops.drop(0.1, 77, N), residual=(res, N), bf16=True)
+        d = torch.full((M, N), float("nan"), device=dev)
+        ops.gemm(M, N, K, A16, K, B16, K, d, N, act=ops.ACT_GELU_TANH, dact_src=(pre_src, N), bf16=True)
+        torch.cuda.synchronize()
+        names = set(ops.summarize_gemm_timing(rec))
+        ops.disable_gemm_timing()
+        assert all(expect in n for n in names), names
+        return c16, pre, c, d
+
+    monkeypatch.setenv("TECM_BF16_DMA", "1")
+    want = run("gemm_bf16_dma_kernel")
+    monkeypatch.delenv("TECM_BF16_DMA")
+    monkeypatch.setenv("TECM_BF16_P8", "1")
+    got = run("gemm_bf16_p8_kernel")
+    for g_, w_ in zip(got[1:], want[1:]):
+        assert torch.isfinite(g_).all() and _rel(g_, w_) < 2e-6
+    diff = (got[0].float() - want[0].float()).abs()
+    assert bool((diff <= want[0].float().abs() * 2.0 ** -7 + 1e-6).all())
+    again = run("gemm_bf16_p8_kernel")                   # bit-reproducible
+    for g_, w_ in zip(got, again):
+        assert torch.equal(g_, w_)
+    # against an fp64 product of the same bf16 operands (an independent reference, not another kernel of this library)
+    ref = A16.double() @ B16.double().t()
+    d2 = torch.empty(M, N, device=dev)
+    ops.gemm(M, N, K, A16, K, B16, K, d2, N, bf16=True)
+    assert _rel(d2, ref) < 1e-5
 
 
 @pytest.mark.parametrize("Bn,L,N,Cin,Cout,k", [(2, 48, 5, 24, 64, 3), (2, 24, 7, 64, 128, 7), (1, 48, 300, 24, 64, 5)])

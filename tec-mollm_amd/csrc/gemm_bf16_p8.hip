@@ -19,9 +19,9 @@ __global__ __launch_bounds__(tecm_p8::NTH, 1) void gemm_bf16_p8_kernel(const Tec
   // (names qualified on purpose: tecm_gemm16 has its own BM / BN / BK, which would hide tecm_p8's behind a using-directive)
   constexpr int BM = tecm_p8::BM, BN = tecm_p8::BN, MT = tecm_p8::MT, NT = tecm_p8::NT, LDS_BYTES = tecm_p8::LDS_BYTES;
   constexpr int WTM = 128, WTN = 64;
+  static_assert(LDS_BYTES >= 8 * 32 * (WTN + 4) * 4 && tecm_p8::BMAP == 1, "epilogue slabs fit in the operand ring");
   static_assert(BM == 256 && BN == 256 && MT * 16 == WTM && NT * 16 == WTN, "wave tile 128 x 64 of a 256 x 256 block tile");
   __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[LDS_BYTES];
-  static_assert(LDS_BYTES >= 8 * 32 * (WTN + 4) * 4, "epilogue slabs fit in the operand ring");
 
   // block -> tile map: XCD-contiguous runs, GROUP_M m-tiles per L2 super-tile (as the other geometries)
   const int nwg = tiles_m * tiles_n;
@@ -48,7 +48,6 @@ __global__ __launch_bounds__(tecm_p8::NTH, 1) void gemm_bf16_p8_kernel(const Tec
       for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
   const tecm_p8::Operands o{reinterpret_cast<const __bf16*>(g.A), reinterpret_cast<const __bf16*>(g.B), g.lda, g.ldb, g.M, g.N, (int)g.K};
   tecm_p8::kloop(o, m0, n0, smem_raw, acc);
-  __syncthreads();                                      // every wave has left the K loop: the ring becomes staging
 #ifdef DMA_ABLATE_NOEPI                                  // diagnostics (tools/build_variant.py): K loop without the epilogue
   {
     float keep = 0.f;
@@ -62,29 +61,33 @@ __global__ __launch_bounds__(tecm_p8::NTH, 1) void gemm_bf16_p8_kernel(const Tec
     return;
   }
 #endif
-
-  // ---- epilogue: gemm_impl.h's straight-line form over this wave's private staging rows (16x16 C/D map:
-  // row = 4 (lane >> 4) + reg, col = lane & 15)
+  __syncthreads();                                      // every wave has left the K loop: the ring becomes staging
+  // ---- epilogue: gemm_impl.h's straight-line form over this wave's private staging rows.  Accumulator map (BMAP 1,
+  // gemm_bf16_p8_loop.h): lane (fr, fq) holds 16 consecutive columns 16 fq .. of row 16 i + fr, so a slab of 32 rows is
+  // parked with 8 ds_write_b128 per lane (conflict-free: 8 consecutive lanes = 8 rows at a pitch of 68 floats).
+  // (Round 5, measured and not kept: storing row-wise straight from the registers, no LDS -- 16-byte pieces at a 32- or
+  //  64-byte stride per instruction: fp32 C 392 -> 431..1367 us, bf16 C 356 -> 344..503 us over both column maps and
+  //  store policies at N = 3072 / K = 768; the coalescer wants whole contiguous row segments per instruction.)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 2, wn = wave & 3;
   const int fr = lane & 15, fq = lane >> 4;
   constexpr int STG_LD = WTN + 4;
   const DropCtx odc = make_drop(g.out_drop);
   float* stg = reinterpret_cast<float*>(smem_raw) + wave * (32 * STG_LD);
-  auto stage_slab = [&](auto ic) {                     // 32 accumulator rows = tile rows 2 i, 2 i + 1
+  auto stage_slab = [&](auto ic) {                     // 32 accumulator rows = row tiles 2 i, 2 i + 1
     constexpr int i = decltype(ic)::value;
     static_for<2>([&](auto tc) {
       constexpr int ti = decltype(tc)::value;
       static_for<NT>([&](auto jc) {
         constexpr int jn = decltype(jc)::value;
-        static_for<4>([&](auto ec) {
-          constexpr int e = decltype(ec)::value;
-          stg[(16 * ti + 4 * fq + e) * STG_LD + jn * 16 + fr] = acc[2 * i + ti][jn][e];
-        });
+        // (written as the float4 the straight-line reader loads: a store through another vector type is a different
+        //  TBAA type, and the compiler may then move the reader's loads across it)
+        const tecm_p8::f32x4 v = acc[2 * i + ti][jn];
+        *reinterpret_cast<float4*>(&stg[(16 * ti + fr) * STG_LD + 16 * fq + 4 * jn]) = make_float4(v[0], v[1], v[2], v[3]);
       });
     });
   };
-  const int fmode = tecm_gemm::epi_fast_mode(g);         // >= 0: checked on the host (tecm_gemm16_p8_try)
+  const int fmode = tecm_gemm::epi_fast_mode(g);         // >= 0: checked on the host (tecm_gemm16_dma_try's can16)
   constexpr int LPR = WTN / 4, RPI = 64 / LPR;
   const int lcol = (lane % LPR) * 4, lrow = lane / LPR;
   const EpiCol ecol = epi_col(g, n0 + wn * WTN + lcol);

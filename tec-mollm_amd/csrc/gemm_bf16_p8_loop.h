@@ -7,9 +7,10 @@
 //
 // Geometry
 //   * block = 512 threads = 8 waves as 2 (m) x 4 (n); wave (wr, wc) owns C rows wr*128 .. +128, columns wc*64 .. +64
-//     (128 accumulator registers) as 2 x 2 quadrants of 64 x 32: quadrant (hA, hB) = rows +hA*64, columns +hB*32.
+//     (128 accumulator registers) as 2 x 2 quadrants of 64 rows x 32 columns: quadrant (hA, hB) = rows +hA*64, and the
+//     columns c of the wave's 64 with (c >> 3) & 1 == hB (see the accumulator map at kloop).
 //   * half-tile A_h = the 64-row halves hA = h of BOTH wave rows (128 LDS rows of 64 k = 128 B each), B_h likewise the
-//     32-column halves hB = h of the four wave columns: every wave reads 64 (A) / 32 (B) rows of a half-tile, and a
+//     32-column sets hB = h of the four wave columns: every wave reads 64 (A) / 32 (B) rows of a half-tile, and a
 //     half-tile is consumed by exactly one or two phases.  LDS: 2 K-tile buffers x 4 half-tiles x 16 KiB = 128 KiB.
 //   * a half-tile is 16 pieces of 8 rows x 128 B, one global_load_lds_dwordx4 wave-instruction each (full 128-B lines
 //     from HBM/L2), wave w moves pieces 2w, 2w+1.  The DMA writes wave-uniform base + lane * 16, so the image is linear
@@ -46,6 +47,10 @@ constexpr int BM = 256, BN = 256, BK = 64, NTH = 512;
 constexpr int HALF_BYTES = 128 * BK * 2;              // 16 KiB
 constexpr int BUF_BYTES = 4 * HALF_BYTES;             // one K-tile: A0, B0, B1, A1
 constexpr int LDS_BYTES = 2 * BUF_BYTES;              // 128 KiB
+#ifndef P8_MAP
+#define P8_MAP 1
+#endif
+constexpr int BMAP = P8_MAP;                          // which of the wave's 64 columns a B fragment row holds (see kloop)
 constexpr int MT = 8, NT = 4;                         // accumulator tiles of 16 x 16 per wave: rows 16 i, columns 16 j
 
 struct Operands {
@@ -61,7 +66,11 @@ __device__ __forceinline__ void bar() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// acc[i][j][e] = C[m0 + wr*128 + 16 i + 4 (lane >> 4) + e][n0 + wc*64 + 16 j + (lane & 15)]
+// Accumulator map (the B fragment is the MFMA's row operand, and the B rows are dealt to fragment rows so that):
+//   BMAP 1: acc[i][j][e] = C[m0 + wr*128 + 16 i + (lane & 15)][n0 + wc*64 + 16 (lane >> 4) + 4 j + e]
+//   BMAP 0: acc[i][j][e] = C[m0 + wr*128 + 16 i + (lane & 15)][n0 + wc*64 + 16 j + 4 (lane >> 4) + e]
+// -- lane (fr, fq) holds, for each of its 8 row tiles i, the 16 consecutive columns 16 fq .. 16 fq + 15 of row 16 i + fr:
+// the epilogue works row-wise straight from the registers (64 B fp32 / 32 B bf16 per lane and row), no LDS staging.
 __device__ __forceinline__ void kloop(const Operands& o, int64_t m0, int64_t n0, unsigned char* smem, f32x4 (&acc)[MT][NT]) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -90,7 +99,11 @@ __device__ __forceinline__ void kloop(const Operands& o, int64_t m0, int64_t n0,
         gm = gm < o.M ? gm : o.M - 1;                  // clamped rows feed accumulator rows that are never stored
         soff[k][i] = (uint32_t)((gm * o.lda + chunk * 8) * 2);
       } else {
-        int64_t gn = n0 + (lr >> 5) * 64 + h * 32 + (lr & 31);
+        // LDS row lr of B_h = wave column lr >> 5, MFMA tile jl = (lr >> 4) & 1 of the half, fragment row r16 = lr & 15;
+        // it holds column (r16 >> 2) * 16 + (2 h + jl) * 4 + (r16 & 3) of the wave's 64, so that a lane's 4 j x 4 e
+        // accumulator values are 16 CONSECUTIVE columns of one row (see the accumulator map above kloop)
+        const int r16 = lr & 15, jt = 2 * h + ((lr >> 4) & 1);
+        int64_t gn = n0 + (lr >> 5) * 64 + (BMAP == 1 ? (r16 >> 2) * 16 + jt * 4 + (r16 & 3) : jt * 16 + r16);
         gn = gn < o.N ? gn : o.N - 1;
         soff[k][i] = (uint32_t)((gn * o.ldb + chunk * 8) * 2);
       }
@@ -147,7 +160,7 @@ __device__ __forceinline__ void kloop(const Operands& o, int64_t m0, int64_t n0,
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[4 * HA + i][2 * HB + j] =
-              __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[j][ks], acc[4 * HA + i][2 * HB + j], 0, 0, 0);
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][ks], fa[i][ks], acc[4 * HA + i][2 * HB + j], 0, 0, 0);
     }
     __builtin_amdgcn_s_setprio(0);
   };

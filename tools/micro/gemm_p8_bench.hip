@@ -55,12 +55,12 @@ __global__ __launch_bounds__(NTH, 1) void p8_plain_kernel(Operands o, float* C, 
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int64_t m = m0 + wr * 128 + 16 * i + 4 * fq + e, n = n0 + wc * 64 + 16 * j + fr;
-        if (m < o.M && n < o.N) C[m * ldc + n] = acc[i][j][e];
-      }
+    for (int j = 0; j < NT; ++j) {
+      const int64_t m = m0 + wr * 128 + 16 * i + fr, n = n0 + wc * 64 + 16 * fq + 4 * j;
+      if (m < o.M && n + 3 < o.N) *reinterpret_cast<f32x4*>(C + m * ldc + n) = acc[i][j];
+      else if (m < o.M)
+        for (int e = 0; e < 4; ++e) if (n + e < o.N) C[m * ldc + n + e] = acc[i][j][e];
+    }
 }
 
 __global__ void ref_rows_kernel(Operands o, const int* rows, int nrows, float* out) {

@@ -100,7 +100,8 @@ def compact_line(line: dict):
         head[group], detail[group] = {}, {}
         for name, leg in legs.items():
             h = {k: v for k, v in leg.items() if k not in ("roofline", "workload")}
-            h["workload"] = str(leg.get("workload", ""))[:96]
+            if "workload" in leg:
+                h["workload"] = str(leg["workload"])[:96]
             r, d = _compact_roofline(leg.get("roofline"))
             if r:
                 h["roofline"] = {k: r[k] for k in ("kernel", "achieved", "peak", "frac", "avg_launch_ms", "share_of_step", "step") if k in r}
@@ -153,6 +154,10 @@ def parse():
                     help="skip configs_extra (the bf16 and L_in=96 legs that follow the main run at N=1 with default flags)")
     ap.add_argument("--emulation-modes", action="store_true",
                     help="also time the opt-in bf16x6 / bf16x3 modes (context only; not part of the default run)")
+    ap.add_argument("--loop", choices=["native", "reference"], default="native",
+                    help="native: tecmollm.train.TrainStep (flat buffers, fused clip + AdamW).  reference: the statements of "
+                         "the reference's own loop body (train.py:57-112) around the drop-in model -- autocast(bf16), "
+                         "gradient_checkpointing_enable() per step, GradScaler, torch AdamW, clip_grad_norm_, loss.item()")
     ap.add_argument("--detail-json", default=None,
                     help="where the per-shape / non-GEMM tables go (default: bench_detail.json next to this script); "
                          "the last stdout line stays under 4 KB")
@@ -492,7 +497,88 @@ def shape_pass(ts, batch_fn, ei, ew, steps: int = 3):
     return agg, steps
 
 
-def extra_config(cfg, args, dev, mode, ei, ew, workload, L_in=None, L_out=None, with_roofline=True, steps=10):
+def reference_loop(cfg, args, dev, ei, ew, B, steps=10, warmup=3, autocast=True, skip=()):
+    """samples/s of the REFERENCE's training-loop body (train.py:57-112, :358-372, statement for statement) around the
+    drop-in model: `torch.autocast(bf16)` (precision "auto" follows it), the per-step gradient_checkpointing_enable()
+    call (a no-op here by design), GradScaler scale / unscale_ / step / update, clip_grad_norm_(model.parameters()),
+    torch.optim.AdamW over the trainable parameters, CosineAnnealingWarmRestarts, loss.item() and empty_cache() every
+    step, accumulation_steps = 1.  What a reference user gets WITHOUT adopting tecmollm.train.TrainStep.
+    `skip` (tools/ref_loop_breakdown.py only; the bench runs the body whole) leaves out named statements -- "empty_cache",
+    "item", "scaler", "clip" -- to price them."""
+    from torch.optim.lr_scheduler import CosineAnnealingWarmRestarts
+    from src.model.tec_mollm import TEC_MoLLM
+    from tecmollm.synthetic import synthetic_batch
+    mc = dict(cfg, gat_graphs=args.gat, include_wte=False, load_pretrained_gpt2=False, precision="auto")
+    torch.manual_seed(0)
+    model = TEC_MoLLM(mc)
+    with torch.no_grad():
+        for blk in model.llm_backbone.trunk.h:
+            blk.attn.c_attn.lora_B.default.weight.normal_(std=0.02)
+    model = model.to(dev).train()
+    optimizer = torch.optim.AdamW(filter(lambda p: p.requires_grad, model.parameters()), lr=1e-4, weight_decay=1e-2)
+    scheduler = CosineAnnealingWarmRestarts(optimizer, T_0=10, T_mult=2, eta_min=1e-7)
+    loss_fn = torch.nn.HuberLoss(delta=1.0)
+    scaler = torch.amp.GradScaler("cuda")
+    accumulation_steps = 1
+    L_in, L_out, H, W = cfg["temporal_seq_len"], cfg["prediction_horizon"], 41, 71
+    x0, tf0, y0 = synthetic_batch(B, L_in, 2911, args.c_in, L_out, seed=1234)
+    batch = {"x": x0.view(B, L_in, H, W, args.c_in).to(dev), "x_time_features": tf0[:, :, 0, :].contiguous().to(dev),
+             "y": y0.view(B, L_out, H, W).permute(0, 2, 3, 1).contiguous().to(dev)}        # (B, H, W, L_out) as the dataset yields
+    total_loss = 0.0
+
+    def body(i):
+        nonlocal total_loss
+        x, y, time_features = batch["x"].to(dev), batch["y"].to(dev), batch["x_time_features"].to(dev)
+        Bq, L, Hh, Ww, C = x.shape
+        x = x.view(Bq, L, Hh * Ww, C)
+        time_features = time_features.unsqueeze(-2).expand(Bq, L, Hh * Ww, -1)
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=autocast):
+            model.llm_backbone.model.gradient_checkpointing_enable()
+            output = model(x, time_features, ei, ew)
+            y_reshaped = y.permute(0, 3, 1, 2).reshape(Bq, -1, Hh * Ww, 1)
+            loss = loss_fn(output, y_reshaped)
+            loss = loss / accumulation_steps
+        if "scaler" in skip:
+            loss.backward()
+        else:
+            scaler.scale(loss).backward()
+        del x, y, time_features, output, y_reshaped
+        if "empty_cache" not in skip:
+            torch.cuda.empty_cache()
+        if (i + 1) % accumulation_steps == 0:
+            if "scaler" not in skip:
+                scaler.unscale_(optimizer)
+            if "clip" not in skip:
+                torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
+            if "scaler" in skip:
+                optimizer.step()
+            else:
+                scaler.step(optimizer)
+                scaler.update()
+            optimizer.zero_grad()
+            scheduler.step()
+        if "item" not in skip:
+            total_loss += loss.item() * accumulation_steps
+
+    optimizer.zero_grad()
+    for i in range(warmup):
+        body(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        body(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    res = {"samples_per_s": round(steps * B / dt, 2), "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps, "batch": B,
+           "dtype": "bf16" if autocast else "f32", "final_loss": round(total_loss / (steps + warmup), 5),
+           "workload": "the reference's loop body (train.py:57-112) around the drop-in model: autocast bf16, GradScaler, "
+                       "torch AdamW + clip_grad_norm_, loss.item() + empty_cache() per step"}
+    del model, optimizer
+    torch.cuda.empty_cache()
+    return res
+
+
+def extra_config(cfg, args, dev, mode, ei, ew, workload, L_in=None, L_out=None, with_roofline=True, steps=10, batch=None):
     """samples/s of one more BASELINE configuration, measured after the main run with its own roofline:
     mode "bf16" = autocast semantics (BASELINE configs[2]); L_in / L_out = the stress shape of configs[4] on one GPU;
     "bf16x6" / "bf16x3" (only with --emulation-modes) = fp32 emulated by six / three bf16 MFMAs per product."""
@@ -511,7 +597,7 @@ def extra_config(cfg, args, dev, mode, ei, ew, workload, L_in=None, L_out=None, 
             blk.attn.c_attn.lora_B.default.weight.normal_(std=0.02)
     model = model.to(dev)
     model.train(not args.eval_mode)
-    B = args.batch
+    B = batch or args.batch
     x, tf, y = synthetic_batch(B, a2.L_in, 2911, args.c_in, a2.L_out, seed=1234)
     x, y = x.to(dev), y.to(dev)
     tf = tf[:, :, 0, :].contiguous().to(dev).unsqueeze(-2).expand(B, a2.L_in, 2911, 4)
@@ -614,6 +700,18 @@ def main():
     from tecmollm.synthetic import grid_graph, synthetic_batch
 
     cfg = make_config(args)
+    if args.loop == "reference":                                    # diagnostics: the reference's loop body alone (N = 1)
+        if world != 1:
+            raise SystemExit("--loop reference is a single-GPU measurement")
+        eig, ewg = grid_graph()
+        r = reference_loop(cfg, args, dev, eig.to(dev), ewg.to(dev), args.batch, steps=args.steps, warmup=args.warmup,
+                           autocast=args.precision != "fp32")
+        print(json.dumps({"metric": "train samples/sec", "value": r["samples_per_s"], "unit": "samples/s", "n_gpus": 1,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": r["dtype"],
+                          "data": "synthetic", "config": {"workload": r["workload"], "global_batch": args.batch,
+                                                          "parallelism": "dp1", "loop": "reference"}}), flush=True)
+        return
     mc = dict(cfg, gat_graphs=args.gat, include_wte=False, load_pretrained_gpt2=False, precision=args.precision)
     torch.manual_seed(0)                                           # identical weights on every rank ...
     model = TEC_MoLLM(mc)
@@ -741,6 +839,18 @@ def main():
                                     f"BASELINE configs[4] per-GPU shape: B={B}, L_in=96, L_out=24 (6 tokens per "
                                     f"sequence, head 4608 -> 1152 -> 24), N=2911, F={args.c_in}, fp32, full "
                                     f"fwd+bwd+AdamW, GATv2 {args.gat}, dropout on", L_in=96, L_out=24)}
+            # the reference's own loop body around the drop-in model (what train.py gets without adopting TrainStep),
+            # at B = 8 and at the reference's per-GPU batch B = 2 (scripts/train_2gpu.sh:4-12), beside the native
+            # TrainStep at the same batch: `ratio` = reference-loop rate / native rate
+            ref_loop = {}
+            for bq in (B, 2):
+                r = reference_loop(cfg, args, dev, ei, ew, bq)
+                nat = line["configs_extra"]["bf16"] if bq == B else \
+                    extra_config(cfg, args, dev, "bf16", ei, ew, f"native TrainStep, bf16, B={bq}", with_roofline=False, batch=bq)
+                ref_loop[f"B{bq}"] = {"samples_per_s": r["samples_per_s"], "ms_per_step": r["ms_per_step"],
+                                      "native_samples_per_s": nat["samples_per_s"], "native_ms_per_step": nat["ms_per_step"],
+                                      "ratio": round(r["samples_per_s"] / nat["samples_per_s"], 3)}
+            line["configs_extra"]["reference_loop_bf16"] = ref_loop
             if args.emulation_modes:
                 line["other_precisions"] = {m: extra_config(cfg, args, dev, m, ei, ew, PRECISION_TEXT[m],
                                                             with_roofline=False, steps=5)

@@ -159,8 +159,16 @@ class Rounding:
     tensor whose readers are bf16 contractions only, so rounding at the store and rounding in the reader are the same
     arithmetic -- with the exceptions written next to the call sites below (`dx=` / `dw=` flags)."""
 
-    def __init__(self, fwd=None, bwd=None, name="fp32"):
+    def __init__(self, fwd=None, bwd=None, name="fp32", conv_policy=None):
         self.fwd, self.bwd, self.name = fwd, bwd, name
+        # conv_policy(L, Cout, Cin) -> (acts16, y16): which conv-block tensors are STORED as bf16 (see conv_block).  None =
+        # torch.autocast's own semantics: a bf16 Conv1d returns a bf16 tensor, always.  An implementation that keeps some of
+        # them fp32 for some shapes (the HIP path at L_in = 336) hands its policy in from the TEST (tests/parity.py:
+        # device_rounding); the oracle holds no copy of any kernel's eligibility rules.
+        self.conv_policy = conv_policy
+
+    def with_conv_policy(self, conv_policy) -> "Rounding":
+        return Rounding(self.fwd, self.bwd, self.name, conv_policy)
 
     def __repr__(self):
         return f"Rounding({self.name})"
@@ -209,15 +217,6 @@ class _GradStoreRounded(torch.autograd.Function):
 
 def grad_stored(t: torch.Tensor, q: "Rounding") -> torch.Tensor:
     return t if q.bwd is None else _GradStoreRounded.apply(t, q.bwd)
-
-
-def conv_acts_bf16(L: int, Cout: int) -> bool:
-    """Mirror of the device policy (tecmollm/ops.py:gn_reg_ok, ConvBlockFn): the conv block keeps its activations behind
-    the GroupNorm -- and the gradient at the 1x1 conv's input -- as bf16 tensors only when the register-resident norm
-    kernels serve the sequence (L * 3*Cout/4 quads over 4 or 8 waves, at most 9 per lane) and Cout >= 64; longer
-    sequences (L_in = 336) keep fp32 tensors whose readers round in their loaders."""
-    quads = L * (3 * Cout // 4)
-    return Cout >= 64 and any(quads % (64 * w) == 0 and quads // (64 * w) <= 9 for w in (4, 8))
 
 
 class _MatMul(torch.autograd.Function):
@@ -277,35 +276,24 @@ def conv1d(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, q: Rounding = F
     return _Conv1d.apply(x, w, stride, padding, q.fwd, q.bwd, q.bwd) + bias.view(1, -1, 1)
 
 
-def conv_y_bf16(L: int, Cout: int, ld_in: int) -> bool:
-    """Mirror of the device policy (ConvBlockFn: y16): in bf16 mode the conv output y is STORED as the bf16 tensor a bf16
-    Conv1d returns under autocast wherever the sequence-tile forward kernel writes it (tecm_conv_fwd_supported: L % 8 == 0,
-    Cout <= 128, ld_in % 8 == 0, (min(L, 48) + 7) * 4 rows of an odd number of 16-byte slots within 64 KiB) and the
-    all-bf16 norm kernels read it (tecm_gn_y16_supported: L * 3*Cout/8 <= 2304)."""
-    if not conv_acts_bf16(L, Cout) or L % 8 or Cout % 32 or Cout > 128 or ld_in % 8 or ld_in > 128:
-        return False
-    slots = ld_in * 2 // 16
-    slots += 1 - slots % 2
-    return (min(L, 48) + 7) * 4 * slots * 16 <= 65536 and L * (3 * Cout // 8) <= 2304
-
-
 # ------------------------------------------------------------------- stage a-4/a-5
 def conv_block(x: torch.Tensor, p: Params, idx: int, stride: int, q: Rounding = FP32) -> torch.Tensor:
     """Multi_Scale_Conv_Block.forward, modules.py:43-60: x (S, C_in, L).
     bf16 mode: all four convolutions and their dX / dW contractions have >= 64 output columns or read the bf16-resident
     dy (block 0's dX has 24 columns but its A operand is the bf16 dy), so every one is a bf16 contraction."""
     outs = []
+    cout = p[f"{P_CONV}{idx}.convs.0.0.weight"].shape[0]
+    acts16, y16 = q.conv_policy(x.shape[-1], cout, x.shape[1]) if q.conv_policy is not None else (True, True)
     for j, k in enumerate((3, 5, 7)):
         pre = f"{P_CONV}{idx}.convs.{j}."
         y = conv1d(x, p[pre + "0.weight"], p[pre + "0.bias"], q, padding=(k - 1) // 2)
-        cin = x.shape[1]
-        if conv_y_bf16(x.shape[-1], y.shape[1], 24 if cin == 22 else cin):
+        if y16:
             y = stored(y, q)                                 # autocast's Conv1d output IS a bf16 tensor; the norm is fp32
         y = F.group_norm(y, 1, p[pre + "1.weight"], p[pre + "1.bias"], eps=1e-5)
         outs.append(F.gelu(y))
     cat = torch.cat(outs, dim=1)
-    if conv_acts_bf16(x.shape[-1], outs[0].shape[1]):
-        cat = grad_stored(cat, q)                            # the device stores d cat as the bf16 tensor its GEMM writes
+    if acts16:
+        cat = grad_stored(cat, q)                            # the bf16 gradient a bf16 Conv1d returns for its input
     pre = f"{P_CONV}{idx}.final_conv."
     return conv1d(cat, p[pre + "weight"], p[pre + "bias"], q, stride=stride)
 

@@ -263,6 +263,16 @@ __device__ __forceinline__ void attention_bwd_body(const float* __restrict__ qkv
 // arrays with runtime bounds, i.e. scratch: 6.0 ms per launch at B = 2, L_in = 336 against 1.2 ms for the forward), and
 // the guards keep the scheduler from interleaving query rows (a guard-free T = 21 instance hoisted the loads of all
 // rows and spilled 856 VGPRs).
+// The mask of this kernel is drawn through an out-of-line call.  With the round-5 hash inlined (16 VALU instructions instead of
+// 70) hipcc 7.2 allocates this body differently -- 114 spilled VGPRs instead of 81 for the fp32 instance -- and the kernel
+// then returns NON-REPRODUCIBLE garbage from T = 16 on, dropout on or off (tools/scratch/att_debug.py: three launches,
+// three answers; T = 13 fine), while the identical source with the hash behind a call is exact and bit-reproducible at every
+// T.  The body sits at the edge of the 512-register file by design (see above); which side of that edge the allocator
+// lands on must not depend on an inlining decision, so the call is spelled out.  test_attention_fwd_bwd[13..32] is the guard.
+__device__ __attribute__((noinline)) float att_drop_mult_call(uint64_t seed, uint64_t idx, uint32_t thresh, float inv_keep) {
+  return tecm_drop_mult(seed, idx, thresh, inv_keep);
+}
+
 template <int TM, bool Q16, bool D16 = false>
 __global__ __launch_bounds__(256, 1) void attention_bwd_kernel_qstream(const float* __restrict__ qkv,
                                                                        const float* __restrict__ dctx,
@@ -316,7 +326,7 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel_qstream(const flo
       for (int j = 0; j <= i; ++j) {
         pr[j] *= inv;
         float m = 1.0f;
-        if (dr.thresh) m = tecm_drop_mult(dr.seed, (uint64_t)(((item * T + i) * T) + j), dr.thresh, dr.inv);
+        if (dr.thresh) m = att_drop_mult_call(dr.seed, (uint64_t)(((item * T + i) * T) + j), dr.thresh, dr.inv);
         const float dpt = group16_sum(dot4(go, v[j]));
         fma4(dv[j], pr[j] * m, go);
         dp[j] = dpt * m;

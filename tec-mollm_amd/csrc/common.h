@@ -33,15 +33,23 @@ void tecm_set_error(const char* fmt, ...);
 static inline bool tecm_aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 // ------------------------------------------------------------------ counter-based dropout mask
-// keep(seed, idx): splitmix64 finaliser of (seed + idx*golden); top 24 bits compared with p*2^24.
-// Pure function => forward and backward agree without storing masks.  Mirrored bit-for-bit by
-// tecmollm/rng.py for the parity tests with dropout enabled.
+// keep(seed, idx): a 32-bit avalanche mixer ("lowbias32": xorshift 16 / * 0x7feb352d / xorshift 15 / * 0x846ca68b /
+// xorshift 16) of  lo(idx) + lo(seed) + hi(seed) * 0x9E3779B1 + (hi(idx) & 0xffffff) * 0x9E3779  (mod 2^32: the high
+// words move the stream by odd multiples, the seed's part is loop-invariant, the index's is a full-rate 24-bit multiply
+// that is zero below 2^32 elements); top 24 bits compared with p*2^24.  Pure function => forward and backward agree
+// without storing masks.  Mirrored bit-for-bit by tecmollm/rng.py for the parity tests with dropout enabled.
+// (Round 5: this replaces the splitmix64 finaliser of rounds 1-4 -- three 64-bit multiplications = twelve quarter-rate
+//  32-bit multiplies per element, about 70 VALU issue slots against 16 now; in the GEMM epilogues that draw a mask per
+//  output element the hash cost more than the GELU.  The seeds stay splitmix64-derived per site, tecmollm/ops.py.)
 __host__ __device__ __forceinline__ uint32_t tecm_hash24(uint64_t seed, uint64_t idx) {
-  uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  return (uint32_t)(z >> 40);
+  uint32_t x = (uint32_t)idx + ((uint32_t)(idx >> 32) & 0xffffffu) * 0x9E3779u;
+  x += (uint32_t)seed + (uint32_t)(seed >> 32) * 0x9E3779B1u;
+  x ^= x >> 16;
+  x *= 0x7feb352du;
+  x ^= x >> 15;
+  x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x >> 8;
 }
 __host__ __device__ __forceinline__ uint32_t tecm_drop_thresh(float p) { return (uint32_t)(p * 16777216.0f); }
 // returns the multiplier to apply: 0 or 1/(1-p)

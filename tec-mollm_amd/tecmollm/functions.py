@@ -279,6 +279,29 @@ class GatFn(torch.autograd.Function):
 
 
 # ============================================================================ stage a-4
+def conv_block_acts16(Lc: int, N: int, Cout: int) -> bool:
+    """bf16 mode: does a conv block keep the activations behind its GroupNorm (and the gradient at the 1x1 conv's input) in
+    HBM as bf16?  Only where the register-resident norm kernels -- the ones that read / write bf16 -- serve the sequence."""
+    return Cout >= 64 and ops.gn_reg_ok(Lc, N, Cout)
+
+
+def conv_block_y16(Lc: int, N: int, Cout: int, ld_in: int) -> bool:
+    """bf16 mode: is the three-branch conv output y itself written as bf16 (by the sequence-tile forward kernel from a bf16
+    input, read by the all-bf16 norm kernels)?  ld_in = channel pitch of the block's input tensor (spatial_ld(C) for block 0)."""
+    CT = 3 * Cout
+    return (conv_block_acts16(Lc, N, Cout) and ld_in % 8 == 0 and ops.conv_fwd_seq_ok(Lc, Cout, ld_in, f32=False)
+            and ops.gn_y16_ok(Lc, N, Cout) and ops.uses_bf16(CT, Cout, Cout, CT, b_layout=B_KN))
+
+
+def conv_storage_policy(N: int):
+    """(L, Cout, Cin) -> (acts16, y16): the two functions above as ONE callable keyed the way the oracle sees a conv block
+    (tests hand it to oracle.ref_cpu.Rounding.with_conv_policy; block 0's input is the padded spatial output)."""
+    def policy(L: int, Cout: int, Cin: int):
+        ld_in = CP if Cin == C_FEAT else Cin                  # block 0 reads the spatial output: 22 channels at a pitch of 24
+        return conv_block_acts16(L, N, Cout), conv_block_y16(L, N, Cout, ld_in)
+    return policy
+
+
 class ConvBlockFn(torch.autograd.Function):
     """Multi_Scale_Conv_Block.forward (modules.py:43-60): three Conv1d(k=3,5,7)+GroupNorm(1)+GELU branches,
     channel concat, Conv1d(k=1, stride).  inp is (B, Lc, N, ld_in) time-major with `cin` real channels
@@ -298,7 +321,7 @@ class ConvBlockFn(torch.autograd.Function):
         # bf16 mode: the activations behind the norm and (backward) dy live in HBM as bf16 -- they are only ever read by
         # bf16 contractions, which would round them in their loaders (same bits, half the bytes).  The conv output y
         # stays fp32 (the norm kernels got slower, not faster, reading 8-byte quads).
-        r16 = int(bf16) == ops.PREC_BF16 and Cout >= 64 and ops.gn_reg_ok(Lc, N, Cout)
+        r16 = int(bf16) == ops.PREC_BF16 and conv_block_acts16(Lc, N, Cout)
         adt = torch.bfloat16 if r16 else torch.float32
         side16 = r16
         packs = []
@@ -310,8 +333,7 @@ class ConvBlockFn(torch.autograd.Function):
         # bf16 mode: y itself is the bf16 tensor a bf16 Conv1d returns under autocast (train.py:68) -- written as such by the
         # sequence-tile kernel, read by the all-bf16 norm kernels forward and backward (half the bytes, three times over) --
         # wherever those kernels serve the sequence and the 1x1 conv's d-input GEMM returns the bf16 gradient they take
-        y16 = r16 and fwd_seq and seq_in.dtype == torch.bfloat16 and ops.gn_y16_ok(Lc, N, Cout) \
-            and ops.uses_bf16(CT, Cout, Cout, CT, b_layout=B_KN)
+        y16 = r16 and fwd_seq and seq_in.dtype == torch.bfloat16 and conv_block_y16(Lc, N, Cout, ld_in)
         y = torch.empty(B, Lc, N, CT, device=inp.device, dtype=torch.bfloat16 if y16 else torch.float32)
         # bias | gamma | beta of the three branches as the 3*Cout vectors the kernels read: one launch, not three cats
         bgb = ops.pack_vectors([b3, b5, b7, g3, g5, g7, be3, be5, be7])
@@ -532,6 +554,7 @@ class PatchEmbedFn(torch.autograd.Function):
 
 # ============================================================================ stage a-6
 _NK_CACHE: dict = {}
+_KEXT_GEN: dict = {}           # data_ptr of a cached K-extended c_attn operand -> number of lora_fold rewrites (GPT2StackFn)
 
 
 def _frozen_copy(W: torch.Tensor, kind: str) -> Optional[torch.Tensor]:
@@ -628,7 +651,8 @@ class GPT2StackFn(torch.autograd.Function):
         KE = D + LORA_R
         h = h0.contiguous()
         saved: List[torch.Tensor] = []
-        ctx_lAT: List[torch.Tensor] = []                     # bf16 lora_A^T per layer (bf16 mode), for the backward's dz . A
+        ctx_lAT: List[Optional[torch.Tensor]] = []           # per layer: bf16 lora_A^T (bf16 mode) for the backward's dz . A, or None
+        ctx_gen: List[int] = []                              # per layer: generation of the shared K-extended operand (see wcat)
         for i in range(n_layers):
             (ln1w, ln1b, Wqkv, bqkv, lA, lB, Wo, bo, ln2w, ln2b, Wfc, bfc, Wpr,
              bpr) = params[i * GPT2StackFn.PER_LAYER:(i + 1) * GPT2StackFn.PER_LAYER]
@@ -665,12 +689,18 @@ class GPT2StackFn(torch.autograd.Function):
                 ops.layernorm_fwd(h, D, ln1w, ln1b, u, KE, st1, M, D)
                 gemm(M, LORA_R, D, u, KE, lA, D, u, KE, c_off=D, a_drop=lspec, bf16=plan.bf16)
                 u_s, ud_s = u, h.new_empty(0)
+                ctx_lAT.append(None)
             # [ W ; (alpha/r) B^T ]  K-extended c_attn, backward operand ([KE][F3]) and forward operand ([F3][KE]): the
             # frozen 768 x 2304 part of both is cached per parameter version (_frozen_copy), ONE launch refreshes the 32
             # LoRA rows / columns of both from lora_B.  (The buffers are the cache's: they are rewritten by the next
-            # forward of this layer, i.e. after the backward that reads `wcat` has run.)
+            # forward of this layer, normally after the backward that reads `wcat` has run.  The rewrite goes through a raw
+            # pointer, behind torch's version counter, so every fold bumps a generation number of the buffer and the backward
+            # checks it: a second forward of the same frozen base weight with an outstanding backward -- two adapters over
+            # one base, retain_graph across an optimizer step -- raises instead of differentiating against the wrong B.)
             wcat = _frozen_copy(Wqkv, "kext_kn16" if b16 else "kext_kn32")
             ops.lora_fold(lB.detach(), LORA_SCALE, wcat, wcatT, D)
+            _KEXT_GEN[wcat.data_ptr()] = _KEXT_GEN.get(wcat.data_ptr(), 0) + 1
+            ctx_gen.append(_KEXT_GEN[wcat.data_ptr()])
             # bf16 mode: qkv is written as bf16 by the c_attn GEMM (what a Linear's output is under autocast) and read as
             # such by the attention kernels, forward and backward: 644 -> 322 MB per layer, three times over
             qkv = torch.empty(M, F3, device=h.device, dtype=torch.bfloat16 if (a16 and QKV16) else torch.float32)
@@ -719,6 +749,7 @@ class GPT2StackFn(torch.autograd.Function):
             ops.layernorm_fwd(h, D, lnfw, lnfb, out, D, stf, M, D)
         ctx.save_for_backward(h, stf, *saved, *params)
         ctx.lAT16 = ctx_lAT
+        ctx.kext_gen = ctx_gen
         ctx.meta = (B, T, N, D, n_layers, plan, len(saved))
         return out
 
@@ -758,6 +789,10 @@ class GPT2StackFn(torch.autograd.Function):
             (ln1w, ln1b, Wqkv, bqkv, lA, lB, Wo, bo, ln2w, ln2b, Wfc, bfc, Wpr,
              bpr) = params[i * GPT2StackFn.PER_LAYER:(i + 1) * GPT2StackFn.PER_LAYER]
             h, u, ud, st1, wcat, qkv, h2, st2, a = saved[i * 9:(i + 1) * 9]
+            if _KEXT_GEN.get(wcat.data_ptr()) != ctx.kext_gen[i]:
+                raise _lib_error(f"GPT-2 block {i}: the K-extended c_attn operand [W ; 2 B^T] was rewritten by a later forward "
+                                "of the same frozen base weight before this backward ran (shared cache buffer); run each "
+                                "forward's backward before the next forward of that layer")
             F3, F4 = Wqkv.shape[1], Wfc.shape[1]
             # MLP:  h3 = h2 + drop(gelu(u2 Wfc + b) Wpr + b)
             Wpr_b, Wfc_b = _bwd_weight(Wpr, plan.bf16), _bwd_weight(Wfc, plan.bf16)
@@ -808,7 +843,7 @@ class GPT2StackFn(torch.autograd.Function):
             # bf16 mode, as under autocast) is a SECOND stream the LayerNorm backward adds through lora_dropout's mask -- it
             # used to be accumulated into du by that GEMM, a read-modify-write of the whole M x 768 gradient
             dzA = torch.empty(M, D, device=dh.device, dtype=torch.bfloat16 if (b16 and GRAD16) else torch.float32)
-            if ctx.lAT16 and dzA.dtype == torch.bfloat16 and du.dtype == torch.bfloat16:
+            if ctx.lAT16[i] is not None and dzA.dtype == torch.bfloat16 and du.dtype == torch.bfloat16:
                 gemm(M, D, LORA_R, du, KE, ctx.lAT16[i], LORA_R, dzA, D, a_off=D, bf16=plan.bf16)     # [row][k] operands: LDS-DMA
             else:
                 gemm(M, D, LORA_R, du, KE, lA, D, dzA, D, b_layout=B_KN, a_off=D, bf16=plan.bf16)

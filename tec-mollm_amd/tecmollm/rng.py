@@ -4,18 +4,23 @@ from __future__ import annotations
 
 import numpy as np
 
-_G = np.uint64(0x9E3779B97F4A7C15)
-_M1 = np.uint64(0xBF58476D1CE4E5B9)
-_M2 = np.uint64(0x94D049BB133111EB)
+_M1 = np.uint32(0x7FEB352D)
+_M2 = np.uint32(0x846CA68B)
 
 
 def hash24(seed: int, idx: np.ndarray) -> np.ndarray:
+    idx = idx.astype(np.uint64)
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     with np.errstate(over="ignore"):
-        z = np.uint64(seed) + idx.astype(np.uint64) * _G
-        z = (z ^ (z >> np.uint64(30))) * _M1
-        z = (z ^ (z >> np.uint64(27))) * _M2
-        z = z ^ (z >> np.uint64(31))
-    return (z >> np.uint64(40)).astype(np.uint32)
+        x = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        x = x + ((idx >> np.uint64(32)) & np.uint64(0xFFFFFF)).astype(np.uint32) * np.uint32(0x9E3779)
+        x = x + np.uint32(((seed & 0xFFFFFFFF) + (seed >> 32) * 0x9E3779B1) & 0xFFFFFFFF)
+        x = x ^ (x >> np.uint32(16))
+        x = x * _M1
+        x = x ^ (x >> np.uint32(15))
+        x = x * _M2
+        x = x ^ (x >> np.uint32(16))
+    return (x >> np.uint32(8)).astype(np.uint32)
 
 
 def keep_mult(seed: int, idx: np.ndarray, p: float) -> np.ndarray:

@@ -49,6 +49,19 @@ ATOL_RMS_BF16 = 1e-2
 # inputs are perturbed by the fp32-mode deviation between the two implementations (1e-6).
 RTOL_BF16_MODEL = 2e-2
 ATOL_RMS_BF16_MODEL = 6e-2
+# The 40-SEQUENCE test problems (B = 2 x N = 20: 120 tokens, every parameter gradient a sum over 120-1 920 rows) sit ON that
+# noise floor, and which tensor is worst moves with the data / mask seed.  Round 5 (new dropout-mask hash, so every
+# realisation changed) measured 20 train-mode steps (L_in = 48 and 96, seeds 31..40, profiles/r05_bf16_seed_sweep.txt):
+#   element-wise bar, worst tensor per run: 0.91 .. 1.46 of the standard bar (lora_B 11 times, a conv weight 6 times, an
+#     embedding table, the patch projection, lin_r once each -- no tensor is worst systematically);
+#   max-norm, tensors outside the GATv2 stage: 1.2e-2 .. 2.05e-2;  GATv2 stage (att, bias, lin_l / lin_r: their gradients pass
+#     through LeakyReLU'(x_l[j] + x_r[i]), a 0.2 <-> 1 jump wherever bf16-noise-sized differences flip a sign): up to 3.4e-2.
+# These problems therefore get ONE stated set of wider bars (`assert_parity(small40=True)`), nothing else does: N = 135 and
+# N = 2911 keep the standard bars, and the self-calibrated test (test_gpu_bf16_model.py) is the noise-independent statement.
+SMALL40_ELEM_SCALE = 1.6
+SMALL40_RTOL = 2.5e-2
+SMALL40_RTOL_GAT = 5e-2
+GAT_TENSORS = KINK_TENSORS[-4:] + ("spatial_encoder.gat_conv.att", "spatial_encoder.gat_conv.bias")
 
 
 def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
@@ -95,6 +108,14 @@ def build_model(cfg: dict, params: Dict[str, torch.Tensor], device, gat_graphs: 
     missing, unexpected = model.load_state_dict(params, strict=True), None
     del missing, unexpected
     return model.to(device)
+
+
+def device_rounding(num_nodes: int) -> "R.Rounding":
+    """The bf16-emulating oracle with the DEVICE's storage policy for the conv-block tensors handed in (which of them are
+    bf16 tensors in HBM for a given sequence length: tecmollm.functions.conv_storage_policy, the same two functions
+    ConvBlockFn calls).  R.BF16 alone = autocast's semantics (always bf16); the two differ at L_in = 336 only."""
+    from tecmollm import functions as F_
+    return R.BF16.with_conv_policy(F_.conv_storage_policy(num_nodes))
 
 
 def oracle_step(cfg, params, x, tf, ei, y, graphs_with_edges,
@@ -217,7 +238,7 @@ def compare_forward_backward(cfg: dict, B: int, grid: Tuple[int, int], threshold
     assert precision in ("fp32", "bf16")
     b16 = precision == "bf16"
     rtol, atol = (RTOL_BF16_MODEL, ATOL_RMS_BF16_MODEL) if b16 else (RTOL, ATOL_RMS)
-    out_ref, loss_ref, grads_ref = oracle_step(cfg, params, x, tf, ei, y, gwe, masks, q=R.BF16 if b16 else R.FP32)
+    out_ref, loss_ref, grads_ref = oracle_step(cfg, params, x, tf, ei, y, gwe, masks, q=device_rounding(N) if b16 else R.FP32)
 
     model = build_model(cfg, params, device, gat_graphs, precision=precision)
     model.train(train)
@@ -260,18 +281,26 @@ def compare_forward_backward(cfg: dict, B: int, grid: Tuple[int, int], threshold
     return res
 
 
-def assert_parity(res: dict, tol: Optional[float] = None, kink: bool = False, elem_scale: Optional[dict] = None) -> None:
+def assert_parity(res: dict, tol: Optional[float] = None, kink: bool = False, elem_scale: Optional[dict] = None,
+                  small40: bool = False) -> None:
     """The bar of every full-step test.  fp32: forward, loss and all gradients within 1e-3 in the max norm AND
     element-wise |a-b| <= 1e-3*|b| + 5e-4*rms(b).  kink=True (full-size graph only): the tensors of KINK_TENSORS get
     the absolute term ATOL_RMS_KINK; without it they meet the same bar as everything else.
     bf16 (res["precision"]): the same two bars at RTOL_BF16_MODEL / ATOL_RMS_BF16_MODEL against the bf16-emulating
     oracle (why not tighter: see the constants).  elem_scale = {tensor name: factor}: the element-wise bar of the named
-    gradient tensors times that factor, everything else unchanged."""
+    gradient tensors times that factor, everything else unchanged.  small40=True (bf16, the 40-sequence problems only): the
+    SMALL40_* bars above -- element-wise x1.6 for every gradient, max-norm 2.5e-2 (GATv2-stage tensors 5e-2)."""
     b16 = res.get("precision") == "bf16"
     tol = tol if tol is not None else (RTOL_BF16_MODEL if b16 else RTOL)
     brief = {k: v for k, v in res.items() if k != "per_param"}
     assert res["fwd_rel"] < tol and res["loss_rel"] < tol, brief
-    assert res["grad_rel_max"] < tol, brief
+    if small40:
+        assert b16, "small40 is a bf16-mode bar"
+        for k, (e, _, _) in res["per_param"].items():
+            assert e < (SMALL40_RTOL_GAT if k in GAT_TENSORS else SMALL40_RTOL), (k, e, brief)
+        elem_scale = dict({"*": SMALL40_ELEM_SCALE}, **(elem_scale or {}))
+    else:
+        assert res["grad_rel_max"] < tol, brief
     assert res["fwd_elem"] < 1.0, brief
     if elem_scale:              # named tensors whose element-wise bar a test widens by a stated factor (and says why)
         for k, (_, ee, _) in res["per_param"].items():

@@ -8,7 +8,8 @@ import pytest
 import torch
 
 from oracle import ref_cpu as R
-from tests.parity import assert_close, assert_parity, build_model, compare_forward_backward, elem_err, oracle_step, rel_err
+from tests.parity import (assert_close, assert_parity, build_model, compare_forward_backward, device_rounding, elem_err,
+                          oracle_step, rel_err)
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
@@ -344,7 +345,7 @@ def test_bf16_forward_matches_bf16_emulating_oracle(dev):
     from tests.parity import ATOL_RMS_BF16_MODEL, RTOL_BF16_MODEL
     cfg = R.default_config(L_in=48, L_out=12, num_nodes=20)
     p, x, tf, y, ei = _bf16_inputs(cfg, 2, (4, 5), seed=11)
-    ref = R.forward(x, tf, ei, p, cfg, None, q=R.BF16)
+    ref = R.forward(x, tf, ei, p, cfg, None, q=device_rounding(cfg["num_nodes"]))
     model = build_model(dict(cfg, precision="bf16"), p, dev, "per_timestep").eval()
     with torch.no_grad():
         out = model(x.to(dev), tf.to(dev), ei.to(dev))
@@ -379,9 +380,26 @@ def test_bf16_autocast_selects_bf16_and_full_step_tracks_fp32_oracle(dev):
     # tensors are stored as bf16 -- tools/diag_y16.py over three seeds, round 4 -- so the fp32 oracle is no further away
     # here; what the emulating oracle removes is bias, and the stage-level tests of test_gpu_bf16_model.py measure that)
     from tests.parity import RTOL_BF16_MODEL
-    _, _, grads_16 = oracle_step(cfg, p, x, tf, ei, y, None, q=R.BF16)
+    _, _, grads_16 = oracle_step(cfg, p, x, tf, ei, y, None, q=device_rounding(cfg["num_nodes"]))
     worst16 = max(rel_err(named[k].grad, g) for k, g in grads_16.items() if g.abs().max() > 0)
-    assert worst16 < RTOL_BF16_MODEL, (worst16, worst)
+    assert worst16 < RTOL_BF16_MODEL and worst16 < worst + 5e-3, (worst16, worst)   # ... and no farther than the fp32 oracle (+ noise)
+
+
+def test_second_forward_before_backward_of_the_same_layer_is_refused(dev):
+    """The K-extended c_attn operand [W ; 2 B^T] the backward reads lives in a per-parameter cache buffer that the next
+    forward of the same layer rewrites through a raw pointer (torch's version counter cannot see it).  A backward whose
+    operand was overwritten meanwhile must raise, not differentiate against the wrong lora_B."""
+    from tecmollm import TecmError
+    cfg = R.default_config(L_in=16, L_out=12, num_nodes=6, llm_layers=1)
+    p = R.init_params(cfg, seed=23)
+    x, tf, y = R.synthetic_batch(1, 16, 6, cfg["spatial_in_channels_base"], 12, seed=5)
+    ei, _ = R.grid_graph(2, 3, threshold_km=2000.0)
+    model = build_model(cfg, p, dev, "per_timestep").eval()
+    out1 = model(x.to(dev), tf.to(dev), ei.to(dev))
+    out2 = model(x.to(dev), tf.to(dev), ei.to(dev))              # same layer, same cache buffer: generation moves on
+    out2.sum().backward()                                         # the latest forward's backward is fine
+    with pytest.raises(TecmError, match="rewritten by a later forward"):
+        out1.sum().backward()
 
 
 def test_frozen_weight_transposes_follow_the_parameter(dev):

@@ -184,7 +184,28 @@ def test_rng_mirror_statistics_and_determinism():
     assert np.allclose(a[a != 0], 1 / 0.9)
     b = rng.keep_mult(12346, idx, 0.1)
     assert abs(((a == 0) & (b == 0)).mean() - 0.01) < 0.003          # independent across seeds
-    assert rng.hash24(0, np.array([0], np.uint64))[0] == 0           # splitmix64(0) finaliser of 0 is 0
+    assert rng.hash24(0, np.array([0], np.uint64))[0] == 0           # the mixer maps 0 to 0
+
+    # known answers from an independent pure-Python statement of the mixer (csrc/common.h:tecm_hash24)
+    def ref(seed, idx):
+        m = 0xFFFFFFFF
+        x = ((idx & m) + ((idx >> 32) & 0xFFFFFF) * 0x9E3779 + (seed & m) + (seed >> 32) * 0x9E3779B1) & m
+        x ^= x >> 16
+        x = (x * 0x7FEB352D) & m
+        x ^= x >> 15
+        x = (x * 0x846CA68B) & m
+        x ^= x >> 16
+        return x >> 8
+    for seed, i in ((0, 1), (12345, 0), (0x9E3779B97F4A7C15, 7), (2 ** 64 - 1, 2 ** 32 + 5), (77, 2 ** 40 + 123456789)):
+        assert int(rng.hash24(seed, np.array([i], np.uint64))[0]) == ref(seed, i)
+    # the high words matter: an index 2^32 further on, or a seed differing in its high word only, is another stream
+    lo = rng.keep_mult(12345, idx, 0.1)
+    assert not np.array_equal(lo, rng.keep_mult(12345, idx + np.uint64(1 << 32), 0.1))
+    c = rng.keep_mult(12345 + (1 << 32), idx, 0.1)
+    assert not np.array_equal(lo, c) and abs(((lo == 0) & (c == 0)).mean() - 0.01) < 0.003
+    # no serial structure a dropout mask would care about: neighbours along a row and across rows of 768 / 3072 columns
+    for lag in (1, 2, 4, 768, 3072):
+        assert abs(((a[:-lag] == 0) & (a[lag:] == 0)).mean() - 0.01) < 0.003, lag
 
 
 def test_clip_matches_torch_clip_grad_norm():

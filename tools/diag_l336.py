@@ -1,5 +1,6 @@
 import sys, os
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tec-mollm_amd")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tec-mollm_amd"))
 from oracle import ref_cpu as R
 from tests.parity import compare_forward_backward
 for seed in (36, 37, 38):

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of bf16 LDS-DMA GEMM geometries with the step's own residencies (bf16 pre-activation as the step stores it).
-# SELS="5 6 7" GROUPS="0 2 4" bash tools/dma_ab2.sh        (run on the GPU box)
+# SELS="5 6 7" GMS="0 2 4" bash tools/dma_ab2.sh        (run on the GPU box; GMS = GROUP_M values, GROUPS is a bash special)
 cd $GRAFT_REPO_ROOT
 for sel in ${SELS:-5 6}; do
  for gm in ${GMS:-0}; do

@@ -173,6 +173,14 @@ typedef struct TecmSpatial {
 #define TECM_BAD_YEAR 4
 #define TECM_BAD_SEASON 8
 int tecm_spatial_fwd(const TecmSpatial* d, void* stream);
+/* The same stage in a second formulation for the configuration TEC_MoLLM.forward runs (tec_mollm.py:84-94 with the
+ * block-uniform time features of train.py:65, flags == 0, out_ld == 24, Cin 6 or 10): one 256-thread block per (tile,
+ * graph) item, 37 KiB of LDS, four blocks per CU; the input transforms split into a graph-independent node part, a
+ * per-graph vector (both computed by a set-up launch into `ws`) and a Cin-wide per-row part (csrc/spatial_fwd2.hip).
+ * tecm_spatial_fwd2_ws_floats: floats of workspace the call needs, or 0 when this formulation does not serve `d` (then
+ * use tecm_spatial_fwd).  Results agree with tecm_spatial_fwd to fp32 summation order. */
+int64_t tecm_spatial_fwd2_ws_floats(const TecmSpatial* d);
+int tecm_spatial_fwd2(const TecmSpatial* d, float* ws, void* stream);
 
 typedef struct TecmSpatialGrads {
   const float* dout;                      /* (B, L, N, C) */

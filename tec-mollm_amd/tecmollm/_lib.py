@@ -146,6 +146,8 @@ EXPORTS = {
     "tecm_gemm_bf16x3": (C.c_int, [C.POINTER(TecmGemm), C.c_void_p]),
     "tecm_gemm_bf16x6": (C.c_int, [C.POINTER(TecmGemm), C.c_void_p]),
     "tecm_spatial_fwd": (C.c_int, [C.POINTER(TecmSpatial), C.c_void_p]),
+    "tecm_spatial_fwd2_ws_floats": (C.c_int64, [C.POINTER(TecmSpatial)]),
+    "tecm_spatial_fwd2": (C.c_int, [C.POINTER(TecmSpatial), c_f32p, C.c_void_p]),
     "tecm_spatial_bwd": (C.c_int, [C.POINTER(TecmSpatial), C.POINTER(TecmSpatialGrads), C.c_void_p]),
     "tecm_spatial_bwd_blocks": (C.c_int, [C.POINTER(TecmSpatial)]),
     "tecm_groupnorm_gelu_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32,

@@ -93,7 +93,14 @@ class SpatialFn(torch.autograd.Function):
         d.out = out.data_ptr()
         errs = devcheck.error_word(x.device)
         errs.poll()                                     # a bad time index reported by an earlier forward (no sync)
-        check(lib().tecm_spatial_fwd(C.byref(d), stream_ptr()), "tecm_spatial_fwd")
+        # round 5: the high-occupancy formulation (csrc/spatial_fwd2.hip) wherever it serves the call -- block-uniform time
+        # features, the fused stage as TEC_MoLLM.forward runs it; TECM_SPATIAL_V2=0 keeps the persistent kernel (A/B)
+        nws = lib().tecm_spatial_fwd2_ws_floats(C.byref(d)) if os.environ.get("TECM_SPATIAL_V2", "1")[:1] != "0" else 0
+        if nws > 0:
+            ws = torch.empty(nws, device=x.device, dtype=torch.float32)
+            check(lib().tecm_spatial_fwd2(C.byref(d), ws.data_ptr(), stream_ptr()), "tecm_spatial_fwd2")
+        else:
+            check(lib().tecm_spatial_fwd(C.byref(d), stream_ptr()), "tecm_spatial_fwd")
         errs.post()
         ctx.save_for_backward(x, tf, node_tab, tod_tab, doy_tab, year_tab, season_tab, Wl, bl, Wr, br, att, bias)
         ctx.meta, ctx.heads, ctx.R, ctx.plan = meta, heads, graphs_with_edges, plan

@@ -390,7 +390,7 @@ def latest_profile_json(precision: str, args):
     """The newest committed PMC traffic summary of this configuration (profiles/rNN_pmc_traffic_<prec>_B8.json)."""
     if args.batch != 8 or args.L_in != 48 or args.gat != "per_timestep" or precision not in ("fp32", "bf16"):
         return None, None
-    for tag in ("r04", "r03", "r02", "r01"):
+    for tag in ("r05", "r04", "r03", "r02", "r01"):
         rel = os.path.join("profiles", f"{tag}_pmc_traffic_{precision}_B8.json")
         try:
             with open(os.path.join(ROOT, rel)) as f:

@@ -67,6 +67,50 @@ def test_spatial_fwd_bwd_matches_oracle(dev, mode, grid, thr):
         assert_close(a, b, n)
 
 
+@pytest.mark.parametrize("train", [False, True], ids=["eval", "train"])
+@pytest.mark.parametrize("mode", ["reference", "per_timestep"])
+@pytest.mark.parametrize("grid,thr,cin", [((3, 4), 170.0, 6), ((9, 15), 150.0, 6), ((12, 30), 150.0, 10)])
+def test_spatial_forward_second_formulation_matches_the_first(dev, grid, thr, cin, mode, train, monkeypatch):
+    """csrc/spatial_fwd2.hip (round 5: one (tile, graph) item per block, transforms split into node part + per-graph vector
+    + Cin-wide per-row part) against csrc/spatial_fwd.hip on the same call: same tiles, same mask indices, another
+    summation order in the transforms -- fp32 rounding apart.  Both graph modes, both feature widths (F = 6 / d_emb = 16,
+    F = 10 / d_emb = 12), several tiles (N = 360), dropout of the attention coefficients on and off; and the selection:
+    per-node time features stay on the first kernel."""
+    from tecmollm import functions as F_
+    from tecmollm import ops
+    N = grid[0] * grid[1]
+    cfg = R.default_config(num_nodes=N, c_in=cin, d_emb=22 - cin)
+    p, x, tf, ei = _spatial_inputs(cfg, 2, 5, grid, seed=13, thr=thr)
+    plan = F_.DropPlan(True, 0.1, 4711) if train else None
+    R_graphs = 1 if mode == "reference" else 10
+    rec = []
+    real = F_.lib
+
+    class Spy:                                              # which entry point served the call
+        def __getattr__(self, name):
+            fn = getattr(real(), name)
+            if name in ("tecm_spatial_fwd", "tecm_spatial_fwd2"):
+                rec.append(name)
+            return fn
+    monkeypatch.setattr(F_, "lib", lambda: Spy())
+    out2, _, _ = _run_spatial(p, x, tf, ei, dev, R_graphs, plan=plan)
+    monkeypatch.setenv("TECM_SPATIAL_V2", "0")
+    out1, _, _ = _run_spatial(p, x, tf, ei, dev, R_graphs, plan=plan)
+    assert rec == ["tecm_spatial_fwd2", "tecm_spatial_fwd"], rec
+    assert torch.isfinite(out2).all() and float(out2[..., 22:].abs().max()) == 0.0
+    assert float((out2 - out1).abs().max()) < 2e-6 * float(out1.abs().max())
+    if train:
+        ev, _, _ = _run_spatial(p, x, tf, ei, dev, R_graphs)
+        assert float((out2 - ev).abs().max()) > 1e-3          # the mask really is applied
+    # per-node time features: not served by the second formulation
+    monkeypatch.delenv("TECM_SPATIAL_V2")
+    rec.clear()
+    g = torch.Generator().manual_seed(6)
+    tfn = torch.stack([torch.randint(0, hi, (2, 5, N), generator=g) for hi in (12, 366, 13, 4)], -1).float()
+    _run_spatial(p, x, tfn, ei, dev, R_graphs, tf_dev=tfn.to(dev))
+    assert rec == ["tecm_spatial_fwd"], rec
+
+
 def test_spatial_general_time_features_per_node(dev):
     """time_features that really vary over N (not a stride-0 view) take the per-node path."""
     grid = (4, 5)

@@ -468,6 +468,14 @@ typedef struct {
   int32_t _pad;
 } TecmAdamW;
 int tecm_adamw_clip_step(const TecmAdamW* a, void* stream);
+/* The parameter-divergence check that rides in the step's ONE gradient all-reduce (DDP's implicit invariant, train.py:353-354:
+ * every rank holds the same parameters).  tecm_checksum_tail: f64 sum of `param[0..n)` (fixed order: identical bits on ranks
+ * with identical parameters), split into two floats, written into slots 2*rank, 2*rank+1 of `tail` (2*world floats: the tail
+ * of the flat gradient buffer), every other slot zeroed; `ws` >= 256 doubles of scratch.  After the SUM all-reduce
+ * tecm_checksum_verify ORs `bit` into the device error word when any rank's pair differs from rank 0's.  Three launches for
+ * what were eleven torch-dispatched ones (tecmollm/train.py). */
+int tecm_checksum_tail(const float* param, int64_t n, float* tail, int32_t world, int32_t rank, double* ws, void* stream);
+int tecm_checksum_verify(const float* tail, int32_t world, int32_t* err_word, int32_t bit, void* stream);
 
 /* (3) evaluation metrics on device (src/evaluation/metrics.py:10-89, :119-183): per prediction horizon h
  * accumulate, over all (sample, node) pairs of one batch, the sufficient statistics of

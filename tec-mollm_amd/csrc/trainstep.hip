@@ -159,7 +159,52 @@ __global__ __launch_bounds__(256) void window_y_kernel(TecmWindowBatch w) {
   }
 }
 
+// ------------------------------------------------------------------ data-parallel parameter checksum (train.py:353-354)
+// Every rank writes an f64 checksum of its parameters, split into two floats, into ITS two slots of the tail of the flat
+// gradient buffer before the step's one all-reduce; after the SUM every rank holds everybody's and compares.
+constexpr int CSUM_BLOCKS = 256;
+__global__ __launch_bounds__(256) void checksum_partial_kernel(const float* __restrict__ p, int64_t n, double* __restrict__ ws) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc += (double)p[i];
+  acc = block_sum_f64(acc, red);
+  if (threadIdx.x == 0) ws[blockIdx.x] = acc;
+}
+__global__ __launch_bounds__(256) void checksum_tail_kernel(const double* __restrict__ ws, int nws, float* __restrict__ tail,
+                                                            int world, int rank) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nws; i += 256) acc += ws[i];
+  acc = block_sum_f64(acc, red);
+  const float hi = (float)acc, lo = (float)(acc - (double)hi);
+  for (int i = threadIdx.x; i < 2 * world; i += 256) tail[i] = i == 2 * rank ? hi : (i == 2 * rank + 1 ? lo : 0.f);
+}
+__global__ void checksum_verify_kernel(const float* __restrict__ tail, int world, int32_t* err_word, int32_t bit) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < world && (tail[2 * i] != tail[0] || tail[2 * i + 1] != tail[1])) atomicOr(err_word, bit);   // NaN != NaN: flagged
+}
+
 }  // namespace
+
+extern "C" int tecm_checksum_tail(const float* param, int64_t n, float* tail, int32_t world, int32_t rank, double* ws,
+                                  void* stream) {
+  TECM_REQUIRE(param && tail && ws && n > 0 && world >= 1 && rank >= 0 && rank < world, TECM_E_ARG,
+               "tecm_checksum_tail: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = (int)((n + 255) / 256 < CSUM_BLOCKS ? (n + 255) / 256 : CSUM_BLOCKS);
+  hipLaunchKernelGGL(checksum_partial_kernel, dim3(nb), dim3(256), 0, st, param, n, ws);
+  TECM_CHECK_LAUNCH("tecm_checksum_tail/partial");
+  hipLaunchKernelGGL(checksum_tail_kernel, dim3(1), dim3(256), 0, st, ws, nb, tail, world, rank);
+  TECM_CHECK_LAUNCH("tecm_checksum_tail/tail");
+  return TECM_OK;
+}
+
+extern "C" int tecm_checksum_verify(const float* tail, int32_t world, int32_t* err_word, int32_t bit, void* stream) {
+  TECM_REQUIRE(tail && err_word && world >= 1, TECM_E_ARG, "tecm_checksum_verify: bad arguments");
+  hipLaunchKernelGGL(checksum_verify_kernel, dim3((world + 63) / 64), dim3(64), 0, (hipStream_t)stream, tail, world, err_word, bit);
+  TECM_CHECK_LAUNCH("tecm_checksum_verify");
+  return TECM_OK;
+}
 
 extern "C" int tecm_adamw_clip_step(const TecmAdamW* a, void* stream) {
   TECM_REQUIRE(a, TECM_E_ARG, "tecm_adamw_clip_step: null descriptor");

@@ -201,6 +201,8 @@ EXPORTS = {
     "tecm_dropout_apply": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int64,
                                      C.c_int32, C.POINTER(TecmDrop), C.c_void_p]),
     "tecm_adamw_clip_step": (C.c_int, [C.POINTER(TecmAdamW), C.c_void_p]),
+    "tecm_checksum_tail": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "tecm_checksum_verify": (C.c_int, [c_f32p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "tecm_metrics_accumulate": (C.c_int, [C.POINTER(TecmMetrics), C.c_void_p]),
     "tecm_window_batch": (C.c_int, [C.POINTER(TecmWindowBatch), C.c_void_p]),
 }

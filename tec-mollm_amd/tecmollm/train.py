@@ -108,6 +108,7 @@ class TrainStep:
         # reports it as dist.allreduce_ms so that a scaling curve can separate communication from compute
         self.time_collective = bool(time_collective) and world_size > 1
         self._coll_events: list = []
+        self._csum_ws = None                           # 256 doubles of scratch for tecm_checksum_tail (allocated on first use)
         self._coll_host_s: list = []
 
     def collective_ms(self) -> List[float]:
@@ -185,6 +186,23 @@ class TrainStep:
             return
         n = self.flat_grad.numel()
         tail = self.flat_grad_ext[n:]
+        if self.native and tail.is_cuda:
+            # three launches on the step's stream instead of eleven torch-dispatched ones (f64 sum, casts, zero_, stack, slice
+            # copy | compare, any, cast, multiply, bitwise_or_): csrc/trainstep.hip
+            from . import devcheck
+            from ._lib import check, lib, stream_ptr
+            if self._csum_ws is None:
+                self._csum_ws = torch.empty(256, device=tail.device, dtype=torch.float64)
+            fp = self.optimizer.flat_param
+            check(lib().tecm_checksum_tail(fp.data_ptr(), fp.numel(), tail.data_ptr(), self.world_size, self.rank,
+                                           self._csum_ws.data_ptr(), stream_ptr()), "tecm_checksum_tail")
+            dist.all_reduce(self.flat_grad_ext, op=dist.ReduceOp.SUM, group=self.group)
+            errs = devcheck.error_word(tail.device)
+            errs.poll()
+            check(lib().tecm_checksum_verify(tail.data_ptr(), self.world_size, errs.ptr(), devcheck.RANKS_DIVERGED,
+                                             stream_ptr()), "tecm_checksum_verify")
+            errs.post()
+            return
         c = self._param_checksum()
         hi = c.float()
         lo = (c - hi.double()).float()

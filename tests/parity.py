@@ -62,6 +62,12 @@ SMALL40_ELEM_SCALE = 1.6
 SMALL40_RTOL = 2.5e-2
 SMALL40_RTOL_GAT = 5e-2
 GAT_TENSORS = KINK_TENSORS[-4:] + ("spatial_encoder.gat_conv.att", "spatial_encoder.gat_conv.bias")
+# ... and the 24-SEQUENCE problems of the configuration sweep (B = 2 x N = 12: 72 token rows at L_in = 48;
+# tests/test_gpu_config_sweep.py) sit higher still: 32 bf16 steps over 16 configurations (profiles/r05_config_sweep.txt) --
+# worst element per run 0.87 .. 1.56 of the standard bar (round 4, other masks: 0.86 .. 1.94), max-norm 1.2e-2 .. 2.3e-2
+# (round 4: .. 3.0e-2).  `assert_parity(small24=True)`; fp32 stays on the standard bars in every configuration (<= 0.05).
+SMALL24_ELEM_SCALE = 2.0
+SMALL24_RTOL = 3e-2
 
 
 def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
@@ -282,23 +288,25 @@ def compare_forward_backward(cfg: dict, B: int, grid: Tuple[int, int], threshold
 
 
 def assert_parity(res: dict, tol: Optional[float] = None, kink: bool = False, elem_scale: Optional[dict] = None,
-                  small40: bool = False) -> None:
+                  small40: bool = False, small24: bool = False) -> None:
     """The bar of every full-step test.  fp32: forward, loss and all gradients within 1e-3 in the max norm AND
     element-wise |a-b| <= 1e-3*|b| + 5e-4*rms(b).  kink=True (full-size graph only): the tensors of KINK_TENSORS get
     the absolute term ATOL_RMS_KINK; without it they meet the same bar as everything else.
     bf16 (res["precision"]): the same two bars at RTOL_BF16_MODEL / ATOL_RMS_BF16_MODEL against the bf16-emulating
     oracle (why not tighter: see the constants).  elem_scale = {tensor name: factor}: the element-wise bar of the named
     gradient tensors times that factor, everything else unchanged.  small40=True (bf16, the 40-sequence problems only): the
-    SMALL40_* bars above -- element-wise x1.6 for every gradient, max-norm 2.5e-2 (GATv2-stage tensors 5e-2)."""
+    SMALL40_* bars above -- element-wise x1.6 for every gradient, max-norm 2.5e-2 (GATv2-stage tensors 5e-2); small24=True
+    (the 24-sequence problems of the configuration sweep): x2.0 and 3e-2."""
     b16 = res.get("precision") == "bf16"
     tol = tol if tol is not None else (RTOL_BF16_MODEL if b16 else RTOL)
     brief = {k: v for k, v in res.items() if k != "per_param"}
     assert res["fwd_rel"] < tol and res["loss_rel"] < tol, brief
-    if small40:
-        assert b16, "small40 is a bf16-mode bar"
+    if small40 or small24:
+        assert b16, "small40 / small24 are bf16-mode bars"
+        rt, es = (SMALL24_RTOL, SMALL24_ELEM_SCALE) if small24 else (SMALL40_RTOL, SMALL40_ELEM_SCALE)
         for k, (e, _, _) in res["per_param"].items():
-            assert e < (SMALL40_RTOL_GAT if k in GAT_TENSORS else SMALL40_RTOL), (k, e, brief)
-        elem_scale = dict({"*": SMALL40_ELEM_SCALE}, **(elem_scale or {}))
+            assert e < (SMALL40_RTOL_GAT if k in GAT_TENSORS else rt), (k, e, brief)
+        elem_scale = dict({"*": es}, **(elem_scale or {}))
     else:
         assert res["grad_rel_max"] < tol, brief
     assert res["fwd_elem"] < 1.0, brief

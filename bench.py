@@ -847,9 +847,14 @@ def main():
                 r = reference_loop(cfg, args, dev, ei, ew, bq)
                 nat = line["configs_extra"]["bf16"] if bq == B else \
                     extra_config(cfg, args, dev, "bf16", ei, ew, f"native TrainStep, bf16, B={bq}", with_roofline=False, batch=bq)
+                # ... and the same body without its per-step torch.cuda.empty_cache() (train.py:81): that one statement returns
+                # the step's activations to the driver and buys them back, 6-190 ms depending on the allocator's state
+                r2 = reference_loop(cfg, args, dev, ei, ew, bq, skip=("empty_cache",))
                 ref_loop[f"B{bq}"] = {"samples_per_s": r["samples_per_s"], "ms_per_step": r["ms_per_step"],
                                       "native_samples_per_s": nat["samples_per_s"], "native_ms_per_step": nat["ms_per_step"],
-                                      "ratio": round(r["samples_per_s"] / nat["samples_per_s"], 3)}
+                                      "ratio": round(r["samples_per_s"] / nat["samples_per_s"], 3),
+                                      "ms_per_step_without_empty_cache": r2["ms_per_step"],
+                                      "ratio_without_empty_cache": round(r2["samples_per_s"] / nat["samples_per_s"], 3)}
             line["configs_extra"]["reference_loop_bf16"] = ref_loop
             if args.emulation_modes:
                 line["other_precisions"] = {m: extra_config(cfg, args, dev, m, ei, ew, PRECISION_TEXT[m],

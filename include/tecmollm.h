@@ -198,6 +198,13 @@ typedef struct TecmSpatialGrads {
   const int32_t* src_ptr; const int32_t* src_col; const int32_t* src_ptr_off;
 } TecmSpatialGrads;
 int tecm_spatial_bwd(const TecmSpatial* d, const TecmSpatialGrads* g, void* stream);
+/* The same backward in the second formulation (csrc/spatial_bwd2.hip) for the configuration tecm_spatial_fwd2 serves: blocks
+ * of 256 threads over (tile, chunk of graphs), ~45 KiB of LDS, three per CU.  Same TecmSpatialGrads contract (tables by
+ * atomics into zeroed buffers, one row of `partials` per block in the same column layout) with
+ * num_blocks = tecm_spatial_bwd2_blocks(d) (0 = not served: use tecm_spatial_bwd) and a workspace of
+ * tecm_spatial_fwd2_ws_floats(d) floats that the call fills itself. */
+int tecm_spatial_bwd2_blocks(const TecmSpatial* d);
+int tecm_spatial_bwd2(const TecmSpatial* d, const TecmSpatialGrads* g, float* ws, void* stream);
 /* Number of blocks (= rows of TecmSpatialGrads.partials) tecm_spatial_bwd will launch for `d`; negative = TECM_E_*. */
 int tecm_spatial_bwd_blocks(const TecmSpatial* d);
 

@@ -150,6 +150,8 @@ EXPORTS = {
     "tecm_spatial_fwd2": (C.c_int, [C.POINTER(TecmSpatial), c_f32p, C.c_void_p]),
     "tecm_spatial_bwd": (C.c_int, [C.POINTER(TecmSpatial), C.POINTER(TecmSpatialGrads), C.c_void_p]),
     "tecm_spatial_bwd_blocks": (C.c_int, [C.POINTER(TecmSpatial)]),
+    "tecm_spatial_bwd2_blocks": (C.c_int, [C.POINTER(TecmSpatial)]),
+    "tecm_spatial_bwd2": (C.c_int, [C.POINTER(TecmSpatial), C.POINTER(TecmSpatialGrads), c_f32p, C.c_void_p]),
     "tecm_groupnorm_gelu_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32,
                                           C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_void_p]),
     "tecm_gn_y16_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),

@@ -142,7 +142,11 @@ class SpatialFn(torch.autograd.Function):
         dout = dout.contiguous()
         d = SpatialFn._desc(x, tf, node_tab, tod_tab, doy_tab, year_tab, season_tab, Wl, bl, Wr, br, att, bias, meta,
                             ctx.heads, ctx.R, ctx.plan, B, L, N, Cin, Demb)
-        nblocks = lib().tecm_spatial_bwd_blocks(C.byref(d))     # persistent blocks over contiguous (tile, graph) ranges
+        # round 5: the second formulation (csrc/spatial_bwd2.hip) wherever it serves the call; TECM_SPATIAL_V2=0 / TECM_SPATIAL_BWD2=0
+        # keep the persistent kernel (A/B)
+        v2 = os.environ.get("TECM_SPATIAL_V2", "1")[:1] != "0" and os.environ.get("TECM_SPATIAL_BWD2", "1")[:1] != "0"
+        nb2 = lib().tecm_spatial_bwd2_blocks(C.byref(d)) if v2 else 0
+        nblocks = nb2 if nb2 > 0 else lib().tecm_spatial_bwd_blocks(C.byref(d))   # rows of the partial-sum buffer
         if nblocks <= 0:
             check(nblocks, "tecm_spatial_bwd_blocks")
         Cc = C_FEAT
@@ -162,7 +166,11 @@ class SpatialFn(torch.autograd.Function):
         g.t_chunk, g.num_blocks = 0, nblocks
         g.src_ptr, g.src_col = meta.src_ptr.data_ptr(), meta.src_col.data_ptr()
         g.src_ptr_off = meta.src_ptr_off.data_ptr()
-        check(lib().tecm_spatial_bwd(C.byref(d), C.byref(g), stream_ptr()), "tecm_spatial_bwd")
+        if nb2 > 0:
+            ws = torch.empty(lib().tecm_spatial_fwd2_ws_floats(C.byref(d)), device=x.device, dtype=torch.float32)
+            check(lib().tecm_spatial_bwd2(C.byref(d), C.byref(g), ws.data_ptr(), stream_ptr()), "tecm_spatial_bwd2")
+        else:
+            check(lib().tecm_spatial_bwd(C.byref(d), C.byref(g), stream_ptr()), "tecm_spatial_bwd")
         s = colsum(partials, pld, nblocks, 1, 1, pld)[0]
         o = 0
         dWl = s[o:o + Cc * Cc].view(Cc, Cc); o += Cc * Cc

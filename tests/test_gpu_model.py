@@ -111,6 +111,41 @@ def test_spatial_forward_second_formulation_matches_the_first(dev, grid, thr, ci
     assert rec == ["tecm_spatial_fwd"], rec
 
 
+@pytest.mark.parametrize("train", [False, True], ids=["eval", "train"])
+@pytest.mark.parametrize("mode", ["reference", "per_timestep"])
+@pytest.mark.parametrize("grid,thr,cin", [((3, 4), 170.0, 6), ((12, 30), 150.0, 10)])
+def test_spatial_backward_second_formulation_matches_the_first(dev, grid, thr, cin, mode, train, monkeypatch):
+    """csrc/spatial_bwd2.hip against csrc/spatial_bwd.hip on the same call: all eleven parameter gradients (five embedding
+    tables, lin_l / lin_r weight and bias, att, bias) agree to fp32 summation order -- both graph modes, both feature widths,
+    several tiles and graph chunks (N = 360, 10 graphs), dropout of the attention coefficients on and off."""
+    from tecmollm import functions as F_
+    N = grid[0] * grid[1]
+    cfg = R.default_config(num_nodes=N, c_in=cin, d_emb=22 - cin)
+    p, x, tf, ei = _spatial_inputs(cfg, 2, 5, grid, seed=17, thr=thr)
+    plan = F_.DropPlan(True, 0.1, 4711) if train else None
+    R_graphs = 1 if mode == "reference" else 10
+    gout = torch.randn(2, 5, N, 24, generator=torch.Generator().manual_seed(3)).to(dev)
+    gout[..., 22:] = 0
+    rec = []
+    real = F_.lib
+
+    class Spy:
+        def __getattr__(self, name):
+            if name in ("tecm_spatial_bwd", "tecm_spatial_bwd2"):
+                rec.append(name)
+            return getattr(real(), name)
+    monkeypatch.setattr(F_, "lib", lambda: Spy())
+    out, ps, names = _run_spatial(p, x, tf, ei, dev, R_graphs, plan=plan)
+    g2 = torch.autograd.grad(out, ps, gout)
+    monkeypatch.setenv("TECM_SPATIAL_BWD2", "0")
+    out, ps, names = _run_spatial(p, x, tf, ei, dev, R_graphs, plan=plan)
+    g1 = torch.autograd.grad(out, ps, gout)
+    assert rec == ["tecm_spatial_bwd2", "tecm_spatial_bwd"], rec
+    for n, a, b in zip(names, g2, g1):
+        assert torch.isfinite(a).all(), n
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-7, (n, float((a - b).abs().max()), float(b.abs().max()))
+
+
 def test_spatial_general_time_features_per_node(dev):
     """time_features that really vary over N (not a stride-0 view) take the per-node path."""
     grid = (4, 5)

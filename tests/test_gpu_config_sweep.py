@@ -20,7 +20,8 @@ from tests.parity import assert_parity, compare_forward_backward  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 # (tools/config_sweep.py walks the full matrix -- eight sequence lengths, four (precision, mode) pairs: profiles/r05_config_sweep.txt;
-#  the test keeps the lengths that take different kernel routes and three pairs, to stay inside a minute of GPU time)
+#  the test keeps the lengths that take different kernel routes and the two train-mode pairs -- eval is the same kernels
+#  with the mask multiply off -- to stay well inside a minute of GPU time)
 CASES = [(f"L{L_in}_{L_out}", dict(L_in=L_in, L_out=L_out), {}) for L_in, L_out in
          ((16, 4), (40, 12), (80, 12), (96, 24), (8, 2))] + [
     ("ch128_256", dict(), {"temporal_channel_list": [128, 256]}),
@@ -41,7 +42,7 @@ def dev():
     return torch.device("cuda")
 
 
-@pytest.mark.parametrize("prec,train", [("fp32", True), ("bf16", False), ("bf16", True)], ids=["fp32-train", "bf16-eval", "bf16-train"])
+@pytest.mark.parametrize("prec,train", [("fp32", True), ("bf16", True)], ids=["fp32-train", "bf16-train"])
 @pytest.mark.parametrize("name,kw,over", CASES, ids=[c[0] for c in CASES])
 def test_full_step_over_model_configurations(dev, name, kw, over, prec, train):
     cfg = R.default_config(num_nodes=12, **kw)

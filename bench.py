@@ -158,6 +158,8 @@ def parse():
                     help="native: tecmollm.train.TrainStep (flat buffers, fused clip + AdamW).  reference: the statements of "
                          "the reference's own loop body (train.py:57-112) around the drop-in model -- autocast(bf16), "
                          "gradient_checkpointing_enable() per step, GradScaler, torch AdamW, clip_grad_norm_, loss.item()")
+    ap.add_argument("--graph", action="store_true",
+                    help="record the micro-batch once (hipGraph) and replay it: TrainStep.step_graphed; needs --warmup >= 2")
     ap.add_argument("--detail-json", default=None,
                     help="where the per-shape / non-GEMM tables go (default: bench_detail.json next to this script); "
                          "the last stdout line stays under 4 KB")
@@ -745,9 +747,12 @@ def main():
                 dist.barrier()
         torch.cuda.synchronize()
 
+    step = ts.step_graphed if args.graph else ts.step
+    if args.graph and args.warmup < 2:
+        raise SystemExit("--graph needs --warmup >= 2 (one eager step, one that records)")
     for _ in range(args.warmup):
         xb, tfb, yb = batch(False)
-        ts.step(xb, tfb, ei, ew, yb)
+        step(xb, tfb, ei, ew, yb)
     barrier()
     ts.reset_collective_timing()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -755,7 +760,7 @@ def main():
     marks[0].record()
     for i in range(args.steps):
         xb, tfb, yb = batch(True)
-        loss = ts.step(xb, tfb, ei, ew, yb)
+        loss = step(xb, tfb, ei, ew, yb)
         marks[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
@@ -811,6 +816,7 @@ def main():
                        "global_batch": B * world, "parallelism": f"dp{world}", "final_loss": round(float(loss), 5),
                        "peak_hbm_gb_per_gpu": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
                        "data_feed": args.data, "host_graph_build_s": round(host_graph_s, 3),
+                       "launch": "hipGraph replay (TrainStep.step_graphed)" if args.graph else "eager",
                        "step_ms_min_max": [round(min(step_ms), 3), round(max(step_ms), 3)]},
             "roofline": roof,
         }

@@ -33,7 +33,7 @@ extern "C" {
 #define TECM_E_LAUNCH (-3)     /* hipGetLastError() != hipSuccess after the launch       */
 #define TECM_E_LDS (-4)        /* problem does not fit the 160 KiB LDS budget            */
 
-#define TECM_ABI_VERSION 16
+#define TECM_ABI_VERSION 17
 int tecm_abi_version(void);
 /* Human-readable text for the last error on this thread (host pointer, never NULL). */
 const char* tecm_last_error(void);
@@ -62,6 +62,10 @@ typedef struct TecmDrop {      /* keep-mask spec; p == 0 disables */
   int32_t _pad;
   uint64_t seed;
   int64_t ld;                  /* idx = row*ld + col */
+  /* NULL, or a device word ADDED to `seed` by the kernel when it starts: a training step whose launches were recorded
+   * once (hipGraph) draws fresh masks at every replay by advancing that one word (tecm_seed_advance) -- the seeds in the
+   * recorded kernel arguments never change.  The forward and the backward of a step read the same value. */
+  const uint64_t* seed_dev;
 } TecmDrop;
 
 enum { TECM_A_MK = 0, TECM_A_KM = 1 };   /* A stored [m][k] (k contiguous) or [k][m] (m contiguous) */
@@ -483,6 +487,10 @@ int tecm_adamw_clip_step(const TecmAdamW* a, void* stream);
  * what were eleven torch-dispatched ones (tecmollm/train.py). */
 int tecm_checksum_tail(const float* param, int64_t n, float* tail, int32_t world, int32_t rank, double* ws, void* stream);
 int tecm_checksum_verify(const float* tail, int32_t world, int32_t* err_word, int32_t bit, void* stream);
+/* *word += inc on the stream (one thread).  The step's dropout word (TecmDrop::seed_dev): recorded as the first node of a
+ * captured training step, it gives every replay its own masks -- what the reference gets from torch's generator advancing
+ * under F.dropout (modules.py:307, modeling_gpt2.py attn/resid/embd dropout, train.py:68-93). */
+int tecm_seed_advance(uint64_t* word, uint64_t inc, void* stream);
 
 /* (3) evaluation metrics on device (src/evaluation/metrics.py:10-89, :119-183): per prediction horizon h
  * accumulate, over all (sample, node) pairs of one batch, the sufficient statistics of

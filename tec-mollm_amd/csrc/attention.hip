@@ -15,6 +15,7 @@ struct DropA {
   uint64_t seed;
   uint32_t thresh;
   float inv;
+  const uint64_t* sdev;        // TecmDrop::seed_dev: added to seed when the kernel starts
 };
 
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
@@ -48,6 +49,7 @@ __device__ __forceinline__ void store_ctx(float* ctx, int ctx_bf16, int64_t off,
 template <int TT, bool Q16>
 __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ ctx,
                                                             int ctx_bf16, int B, int Trt, int N, int H, int D, DropA dr) {
+  dr.seed = tecm_seed_now(dr.seed, dr.sdev);
   const int T = TT > 0 ? TT : Trt;
   const int sub = threadIdx.x & 15;
   const int64_t item = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
@@ -129,6 +131,7 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restr
 template <int TM, bool Q16>
 __global__ __launch_bounds__(256) void attention_fwd_kernel_kv(const float* __restrict__ qkv, float* __restrict__ ctx,
                                                                int ctx_bf16, int B, int T, int N, int H, int D, DropA dr) {
+  dr.seed = tecm_seed_now(dr.seed, dr.sdev);
   const int sub = threadIdx.x & 15;
   const int64_t item = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
   const int64_t items = (int64_t)B * N * H;
@@ -188,6 +191,7 @@ template <int TT, bool Q16, bool D16 = false>
 __device__ __forceinline__ void attention_bwd_body(const float* __restrict__ qkv, const float* __restrict__ dctx,
                                                    float* __restrict__ dqkv, int dqkv_bf16, int B, int Trt, int N, int H,
                                                    int D, DropA dr) {
+  dr.seed = tecm_seed_now(dr.seed, dr.sdev);
   const int T = TT > 0 ? TT : Trt;
   const int sub = threadIdx.x & 15;
   const int64_t item = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
@@ -278,6 +282,7 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel_qstream(const flo
                                                                        const float* __restrict__ dctx,
                                                                        float* __restrict__ dqkv, int dqkv_bf16, int B, int T,
                                                                        int N, int H, int D, DropA dr) {
+  dr.seed = tecm_seed_now(dr.seed, dr.sdev);
   const int sub = threadIdx.x & 15;
   const int64_t item = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
   const int64_t items = (int64_t)B * N * H;
@@ -378,6 +383,7 @@ int check(const char* who, const void* a, const void* b, const void* c, int B, i
 DropA make_dropa(const TecmDrop* d) {
   DropA r;
   r.seed = d ? d->seed : 0;
+  r.sdev = d ? d->seed_dev : nullptr;
   r.thresh = (d && d->p > 0.f) ? tecm_drop_thresh(d->p) : 0u;
   r.inv = (d && d->p > 0.f) ? 1.0f / (1.0f - d->p) : 1.0f;
   return r;

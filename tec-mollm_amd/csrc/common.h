@@ -51,6 +51,10 @@ __host__ __device__ __forceinline__ uint32_t tecm_hash24(uint64_t seed, uint64_t
   x ^= x >> 16;
   return x >> 8;
 }
+// the seed a kernel draws with: the recorded one plus the step's device word (TecmDrop::seed_dev, tecmollm.h)
+__device__ __forceinline__ uint64_t tecm_seed_now(uint64_t seed, const uint64_t* seed_dev) {
+  return seed_dev ? seed + *seed_dev : seed;
+}
 __host__ __device__ __forceinline__ uint32_t tecm_drop_thresh(float p) { return (uint32_t)(p * 16777216.0f); }
 // returns the multiplier to apply: 0 or 1/(1-p)
 __device__ __forceinline__ float tecm_drop_mult(uint64_t seed, uint64_t idx, uint32_t thresh, float inv_keep) {

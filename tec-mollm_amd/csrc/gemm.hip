@@ -50,6 +50,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const TecmGemm g, in
 __global__ __launch_bounds__(256) void erf_post_kernel(float* __restrict__ C, int64_t ldc, const float* __restrict__ src,
                                                        int64_t lds, int64_t M, int32_t N, tecm_gemm::DropCtx odc) {
   const int64_t total = M * N;
+  odc.seed = tecm_seed_now(odc.seed, odc.sdev);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t m = i / N;
     const int32_t n = (int32_t)(i - m * N);

@@ -68,10 +68,12 @@ struct DropCtx {
   int64_t ld;
   uint32_t thresh;
   float inv;
+  const uint64_t* sdev;        // host-made contexts only: the kernel adds *sdev to seed when it starts (tecm_seed_now)
 };
 inline DropCtx make_drop_host(const TecmDrop& d) {
   DropCtx c;
   c.seed = d.seed;
+  c.sdev = d.seed_dev;
   c.ld = d.ld;
   c.thresh = d.p > 0.f ? tecm_drop_thresh(d.p) : 0u;
   c.inv = d.p > 0.f ? 1.0f / (1.0f - d.p) : 1.0f;
@@ -79,7 +81,8 @@ inline DropCtx make_drop_host(const TecmDrop& d) {
 }
 __device__ __forceinline__ DropCtx make_drop(const TecmDrop& d) {
   DropCtx c;
-  c.seed = d.seed;
+  c.seed = tecm_seed_now(d.seed, d.seed_dev);
+  c.sdev = nullptr;
   c.ld = d.ld;
   c.thresh = d.p > 0.f ? tecm_drop_thresh(d.p) : 0u;
   c.inv = d.p > 0.f ? 1.0f / (1.0f - d.p) : 1.0f;

@@ -128,7 +128,9 @@ template <bool OUT16, bool DUAL = false>
 __global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restrict__ src, int64_t lds_, void* __restrict__ dst_,
                                                             int64_t ldd, int64_t rows, int32_t cols4, uint64_t seed,
                                                             int64_t dld, uint32_t thresh, float inv,
+                                                            const uint64_t* __restrict__ sdev,
                                                             __bf16* __restrict__ dst2 = nullptr, int64_t ldd2 = 0) {
+  seed = tecm_seed_now(seed, sdev);
   const int64_t total = rows * cols4;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int64_t r = i / cols4;
@@ -274,13 +276,13 @@ extern "C" int tecm_dropout_apply(const float* src, int64_t ld_src, void* dst, i
   hipStream_t st = (hipStream_t)stream;
   if (dst2_bf16)
     hipLaunchKernelGGL((dropout_apply_kernel<false, true>), grid, dim3(256), 0, st, src, ld_src, dst, ld_dst, rows, cols / 4,
-                       drop->seed, drop->ld, th, inv, static_cast<__bf16*>(dst2_bf16), ld_dst2);
+                       drop->seed, drop->ld, th, inv, drop->seed_dev, static_cast<__bf16*>(dst2_bf16), ld_dst2);
   else if (dst_bf16)
     hipLaunchKernelGGL((dropout_apply_kernel<true, false>), grid, dim3(256), 0, st, src, ld_src, dst, ld_dst, rows, cols / 4,
-                       drop->seed, drop->ld, th, inv, (__bf16*)nullptr, (int64_t)0);
+                       drop->seed, drop->ld, th, inv, drop->seed_dev, (__bf16*)nullptr, (int64_t)0);
   else
     hipLaunchKernelGGL((dropout_apply_kernel<false, false>), grid, dim3(256), 0, st, src, ld_src, dst, ld_dst, rows, cols / 4,
-                       drop->seed, drop->ld, th, inv, (__bf16*)nullptr, (int64_t)0);
+                       drop->seed, drop->ld, th, inv, drop->seed_dev, (__bf16*)nullptr, (int64_t)0);
   TECM_CHECK_LAUNCH("tecm_dropout_apply");
   return TECM_OK;
 }

@@ -16,10 +16,13 @@ struct DropCtxN {
   int64_t ld;
   uint32_t thresh;
   float inv;
+  const uint64_t* sdev;        // TecmDrop::seed_dev: added to seed when the kernel starts (seed_now below)
 };
+__device__ __forceinline__ void seed_now(DropCtxN& c) { c.seed = tecm_seed_now(c.seed, c.sdev); }
 __host__ __device__ inline DropCtxN make_dropn(const TecmDrop* d) {
   DropCtxN c;
   c.seed = d ? d->seed : 0;
+  c.sdev = d ? d->seed_dev : nullptr;
   c.ld = d ? d->ld : 0;
   c.thresh = (d && d->p > 0.f) ? tecm_drop_thresh(d->p) : 0u;
   c.inv = (d && d->p > 0.f) ? 1.0f / (1.0f - d->p) : 1.0f;
@@ -35,6 +38,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                                                             void* __restrict__ y16d, int64_t ldy16d, DropCtxN dd,
                                                             float* __restrict__ stats, int64_t M, int D, float eps,
                                                             int permT, int permN) {
+  seed_now(dd);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * 4 + wave;
   if (row >= M) return;
@@ -130,6 +134,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             float* __restrict__ dxm, int dxm_bf16, DropCtxN odc,
                                                             float* __restrict__ partials, int64_t M, int D, LnAdd ad,
                                                             LnDyMap dm = LnDyMap{}) {
+  seed_now(odc);
+  seed_now(ad.drop);
+  seed_now(dm.drop);
   __shared__ float red[4][2 * 4 * 64 * NCH];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float4 dg[NCH], db[NCH], gm[NCH];
@@ -944,6 +951,7 @@ __global__ __launch_bounds__(384, (NG == 3 ? GN16_OCC : 2)) void gn_gelu_bwd_reg
 __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ in, int64_t ld, int64_t outer,
                                                      int64_t inner, int nseg, int C, DropCtxN idc,
                                                      float* __restrict__ ws, int64_t chunk) {
+  seed_now(idc);
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
@@ -982,6 +990,7 @@ __global__ __launch_bounds__(256) void colsum_stage1_v4(const float* __restrict_
                                                         int64_t inner, int nseg, int C, DropCtxN idc,
                                                         float* __restrict__ ws, int64_t chunk,
                                                         __bf16* __restrict__ twin = nullptr, int64_t ld_twin = 0) {
+  seed_now(idc);
   __shared__ float4 red[256];
   const int Q = C >> 2;                       // quads per row (host: Q <= 256)
   const int RPB = 256 / Q;                    // row slots per pass

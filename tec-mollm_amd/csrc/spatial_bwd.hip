@@ -317,6 +317,7 @@ __global__ __launch_bounds__(BT, 2) void spatial_bwd_kernel(const BwdArgs args) 
   for (int c = 0; c < CH; ++c) att[c] = smem[m.scr + SCR_ATT + hh * CH + c];
   const uint32_t dth = d.alpha_drop.p > 0.f ? tecm_drop_thresh(d.alpha_drop.p) : 0u;
   const float dinv = d.alpha_drop.p > 0.f ? 1.0f / (1.0f - d.alpha_drop.p) : 1.0f;
+  const uint64_t dseed = tecm_seed_now(d.alpha_drop.seed, d.alpha_drop.seed_dev);
   const bool even_cin = (Cin & 1) == 0;
   const unsigned cin_magic = (unsigned)((0x100000000ull + Cin - 1) / Cin);
 
@@ -555,7 +556,7 @@ __global__ __launch_bounds__(BT, 2) void spatial_bwd_kernel(const BwdArgs args) 
         }
         const float e = fmaf(0.4f * LOG2E, t0 + u0, fmaf(0.6f * LOG2E, a[CH], base));
         da += db;
-        if (dth) da *= tecm_drop_mult(d.alpha_drop.seed, dbase + s, dth, dinv);
+        if (dth) da *= tecm_drop_mult(dseed, dbase + s, dth, dinv);
         *reinterpret_cast<float2*>(smem + m.ea + (pos * 2 + hh) * 2) = make_float2(e, da);
         const float mn = fmaxf(mx, e);
         const float corr = __builtin_amdgcn_exp2f(mx - mn), pw = __builtin_amdgcn_exp2f(e - mn);
@@ -581,7 +582,7 @@ __global__ __launch_bounds__(BT, 2) void spatial_bwd_kernel(const BwdArgs args) 
         load12(smem + m.xl + j * CP + hh * 12, a);
         const float alpha = __builtin_amdgcn_exp2f(ed.x - mm) * zinv;
         float mult = 1.0f;
-        if (dth) mult = tecm_drop_mult(d.alpha_drop.seed, dbase + s, dth, dinv);
+        if (dth) mult = tecm_drop_mult(dseed, dbase + s, dth, dinv);
         const float de = alpha * (ed.y - dot);
         *slot = make_float2(alpha * mult, de);
 #pragma unroll

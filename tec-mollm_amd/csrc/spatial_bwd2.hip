@@ -129,6 +129,7 @@ __global__ __launch_bounds__(T2, SPB2_OCC) void spatial_bwd2_kernel(const Bwd2Ar
   for (int c = 0; c < CH; ++c) att[c] = d.att[hh * CH + c];
   const uint32_t dth = d.alpha_drop.p > 0.f ? tecm_drop_thresh(d.alpha_drop.p) : 0u;
   const float dinv = d.alpha_drop.p > 0.f ? 1.0f / (1.0f - d.alpha_drop.p) : 1.0f;
+  const uint64_t dseed = tecm_seed_now(d.alpha_drop.seed, d.alpha_drop.seed_dev);
 
   // ---- sums that live across the block's graphs
   float SL[C], SR[CH], SG[CH], datt[CH];
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(T2, SPB2_OCC) void spatial_bwd2_kernel(const Bwd2Ar
           }
           const float e = fmaf(0.4f * LOG2E, t0 + u0, fmaf(0.6f * LOG2E, al[CH], base));
           da += db;
-          if (dth) da *= tecm_drop_mult(d.alpha_drop.seed, dbase + sl, dth, dinv);
+          if (dth) da *= tecm_drop_mult(dseed, dbase + sl, dth, dinv);
           if (valid) *reinterpret_cast<float2*>(R2 + (pos * 2 + hh) * 2) = make_float2(e, da);
           ev[u] = valid ? e : -INFINITY;
           dav[u] = valid ? da : 0.f;
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(T2, SPB2_OCC) void spatial_bwd2_kernel(const Bwd2Ar
           ld12(R1 + j * CP + hh * 12, al);
           const float alpha = __builtin_amdgcn_exp2f(ed.x - mx) * zinv;
           float mult = 1.0f;
-          if (dth) mult = tecm_drop_mult(d.alpha_drop.seed, dbase + sl, dth, dinv);
+          if (dth) mult = tecm_drop_mult(dseed, dbase + sl, dth, dinv);
           const float de = valid ? alpha * (ed.y - dot) : 0.f;
           if (valid) *slot = make_float2(alpha * mult, de);
 #pragma unroll

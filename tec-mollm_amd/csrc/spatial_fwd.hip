@@ -320,6 +320,7 @@ __global__ __launch_bounds__(THREADS, 2) void spatial_fwd_kernel(const TecmSpati
 
   const uint32_t dth = d.alpha_drop.p > 0.f ? tecm_drop_thresh(d.alpha_drop.p) : 0u;
   const float dinv = d.alpha_drop.p > 0.f ? 1.0f / (1.0f - d.alpha_drop.p) : 1.0f;
+  const uint64_t dseed_now = tecm_seed_now(d.alpha_drop.seed, d.alpha_drop.seed_dev);
   const bool even_cin = (Cin & 1) == 0;
   const unsigned cin_magic = (unsigned)((0x100000000ull + Cin - 1) / Cin);   // idx / Cin == umulhi(idx, magic) for idx * Cin < 2^32
 
@@ -475,11 +476,11 @@ __global__ __launch_bounds__(THREADS, 2) void spatial_fwd_kernel(const TecmSpati
         const float* temb = smem + tb_off + qi * 32;
         if (hh == 0)
           edge_phase<0>(xg, Cin, smem, xl_off, xr_off, hT_off, P, eptr, ecol, temb, tn, i - lo, it.use_edges,
-                        d.alpha_drop.seed, (uint64_t)((rowi * H + 0) * d.alpha_drop.ld), att4, bias, residual,
+                        dseed_now, (uint64_t)((rowi * H + 0) * d.alpha_drop.ld), att4, bias, residual,
                         tf_uniform, dth, dinv);
         else
           edge_phase<1>(xg, Cin, smem, xl_off, xr_off, hT_off, P, eptr, ecol, temb, tn, i - lo, it.use_edges,
-                        d.alpha_drop.seed, (uint64_t)((rowi * H + 1) * d.alpha_drop.ld), att4, bias, residual,
+                        dseed_now, (uint64_t)((rowi * H + 1) * d.alpha_drop.ld), att4, bias, residual,
                         tf_uniform, dth, dinv);
       }
     }

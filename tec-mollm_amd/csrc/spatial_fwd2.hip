@@ -53,6 +53,7 @@ __device__ __forceinline__ void edge_phase2(const TecmSpatial& d, const float* _
     hres[c] = ch < CIN ? xg[ch] : emb_row[ch - CIN] + temb[ch - CIN];
   }
   const int* __restrict__ col = d.colidx + e0;
+  const uint64_t dseed = tecm_seed_now(d.alpha_drop.seed, d.alpha_drop.seed_dev);
   const float base = (0.6f * LOG2E) * xr[11];
   float m = -INFINITY, z = 0.f;
   float acc[CH + 1];
@@ -88,7 +89,7 @@ __device__ __forceinline__ void edge_phase2(const TecmSpatial& d, const float* _
       const float p = __builtin_amdgcn_exp2f(ev[u] - mn);
       zs += p;
       pm[u] = p;
-      if (dth) pm[u] = p * tecm_drop_mult(d.alpha_drop.seed, dbase + s + u, dth, dinv);
+      if (dth) pm[u] = p * tecm_drop_mult(dseed, dbase + s + u, dth, dinv);
     }
     z = z * corr + zs;
     m = mn;

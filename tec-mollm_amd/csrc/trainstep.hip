@@ -250,6 +250,16 @@ extern "C" int tecm_metrics_accumulate(const TecmMetrics* m, void* stream) {
   return TECM_OK;
 }
 
+namespace {
+__global__ void seed_advance_kernel(uint64_t* word, uint64_t inc) { *word += inc; }
+}  // namespace
+extern "C" int tecm_seed_advance(uint64_t* word, uint64_t inc, void* stream) {
+  TECM_REQUIRE(word && tecm_aligned(word, 8), TECM_E_ARG, "tecm_seed_advance: need an 8-byte aligned device word");
+  hipLaunchKernelGGL(seed_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, word, inc);
+  TECM_CHECK_LAUNCH("tecm_seed_advance");
+  return TECM_OK;
+}
+
 extern "C" int tecm_window_batch(const TecmWindowBatch* w, void* stream) {
   TECM_REQUIRE(w, TECM_E_ARG, "tecm_window_batch: null descriptor");
   TECM_REQUIRE(w->X && w->starts && w->x_out, TECM_E_ARG, "tecm_window_batch: null pointer");

@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TECM_LIB", os.path.join(_HERE, "libtecmollm_hip.so"))   # override for experiments
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 c_f32p = C.c_void_p
 
@@ -23,7 +23,7 @@ class TecmWin(C.Structure):
 
 
 class TecmDrop(C.Structure):
-    _fields_ = [("p", C.c_float), ("_pad", C.c_int32), ("seed", C.c_uint64), ("ld", C.c_int64)]
+    _fields_ = [("p", C.c_float), ("_pad", C.c_int32), ("seed", C.c_uint64), ("ld", C.c_int64), ("seed_dev", C.c_void_p)]
 
 
 class TecmGemm(C.Structure):
@@ -205,6 +205,7 @@ EXPORTS = {
     "tecm_adamw_clip_step": (C.c_int, [C.POINTER(TecmAdamW), C.c_void_p]),
     "tecm_checksum_tail": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "tecm_checksum_verify": (C.c_int, [c_f32p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "tecm_seed_advance": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
     "tecm_metrics_accumulate": (C.c_int, [C.POINTER(TecmMetrics), C.c_void_p]),
     "tecm_window_batch": (C.c_int, [C.POINTER(TecmWindowBatch), C.c_void_p]),
 }

@@ -39,14 +39,18 @@ class DeviceErrorWord:
         return self.word.data_ptr()
 
     def post(self) -> None:
-        """Queue the read-back of the word behind everything launched so far on the current stream."""
+        """Queue the read-back of the word behind everything launched so far on the current stream.  While a stream is
+        being captured (TrainStep.step_graphed) nothing is queued: events recorded inside a capture cannot be queried from
+        outside it -- the step posts once after every replay instead."""
+        if torch.cuda.is_current_stream_capturing():
+            return
         self.host.copy_(self.word, non_blocking=True)
         if self.event is None:
             self.event = torch.cuda.Event()
         self.event.record()
 
     def poll(self, sync: bool = False) -> None:
-        if self.event is None:
+        if self.event is None or torch.cuda.is_current_stream_capturing():
             return
         if sync:
             self.event.synchronize()

@@ -33,11 +33,16 @@ def win(N: int, Lin: int, Lout: int, stride_t: int, taps: int, Cw: int, pad: int
 NO_WIN = TecmWin(0, 0, 0, 0, 0, 0, 0, 0)
 
 
+# The step's dropout word (TecmDrop::seed_dev): a device uint64 every mask-drawing kernel adds to its recorded seed.  None
+# outside a captured step (tecmollm/train.py: TrainStep.step_graphed sets it while it records and replays).
+SEED_WORD: Optional[torch.Tensor] = None
+
+
 def drop(p: float, seed: int, ld: int) -> TecmDrop:
-    return TecmDrop(float(p), 0, seed & _MASK64, int(ld))
+    return TecmDrop(float(p), 0, seed & _MASK64, int(ld), SEED_WORD.data_ptr() if SEED_WORD is not None else None)
 
 
-NO_DROP = TecmDrop(0.0, 0, 0, 0)
+NO_DROP = TecmDrop(0.0, 0, 0, 0, None)
 
 
 def _off(t: torch.Tensor, col_off: int = 0) -> int:

@@ -110,6 +110,8 @@ class TrainStep:
         self._coll_events: list = []
         self._csum_ws = None                           # 256 doubles of scratch for tecm_checksum_tail (allocated on first use)
         self._coll_host_s: list = []
+        self._graphs: dict = {}                        # step_graphed: (shapes, mode) -> recorded micro-batch
+        self._seed_word: Optional[torch.Tensor] = None
 
     def collective_ms(self) -> List[float]:
         """Duration of every timed all-reduce so far (ms): device events for GPU tensors, host clock for CPU ones."""
@@ -133,6 +135,14 @@ class TrainStep:
 
     def step(self, x, time_features, edge_index, edge_weight, y) -> torch.Tensor:
         """One micro-batch; the optimizer fires every `accumulation_steps` calls.  Returns the (device) loss."""
+        loss = self._micro_batch(x, time_features, edge_index, edge_weight, y)
+        self._micro += 1                               # micro-batches since the last optimizer step (train.py:92: (i+1) % acc
+        if self._micro >= self.accumulation_steps:     # counted per epoch there: `finish_accumulation` restarts the count)
+            self.finish_accumulation()
+        return loss
+
+    def _micro_batch(self, x, time_features, edge_index, edge_weight, y) -> torch.Tensor:
+        """Forward, loss, backward and the hand-over of the gradients into the flat buffer (everything `step_graphed` records)."""
         if self.native:
             self.optimizer.detach_grads()              # backward hands its gradient tensors over; one add for all of them
         out = self.model(x, time_features, edge_index, edge_weight)
@@ -149,10 +159,66 @@ class TrainStep:
             (loss / self.accumulation_steps).backward()
         if self.native:
             self.optimizer.absorb_grads()
-        self._micro += 1                               # micro-batches since the last optimizer step (train.py:92: (i+1) % acc
-        if self._micro >= self.accumulation_steps:     # counted per epoch there: `finish_accumulation` restarts the count)
-            self.finish_accumulation()
         return loss.detach()
+
+    # ------------------------------------------------------------------ recorded step (small batches)
+    def step_graphed(self, x, time_features, edge_index, edge_weight, y) -> torch.Tensor:
+        """`step` with the micro-batch's ~200 launches (forward, Huber loss, backward, gradient hand-over) recorded ONCE as a
+        hipGraph and replayed: at the reference's per-GPU batch of 2 (scripts/train_2gpu.sh:4-12) the step is short enough for
+        the host's launch rate to show.  The first call with a new (shapes, mode) runs eagerly (it is also the
+        warm-up that fills every host-side cache), the second records and replays, later ones copy the batch into the
+        recorded input tensors and replay.  What changes from replay to replay lives on the device: the dropout masks draw
+        from recorded seeds PLUS one device word (`TecmDrop::seed_dev`) that the graph's first node advances.  The data-
+        parallel exchange, clip + AdamW and the scheduler stay outside the graph (two launches with host scalars).
+        Returns the loss tensor of the recorded step -- the SAME tensor every call; read it before the next one."""
+        if not (self.native and x.is_cuda):
+            raise RuntimeError("step_graphed needs the native optimizer and CUDA tensors")
+        from . import devcheck, ops
+        from ._lib import check, lib, stream_ptr
+        tf_uniform = time_features.dim() == 4 and time_features.stride(2) == 0 and time_features.shape[2] > 1
+        key = (tuple(x.shape), tuple(time_features.shape), tf_uniform, tuple(y.shape), str(y.dtype), self.model.training,
+               torch.is_autocast_enabled("cuda"), str(torch.get_autocast_dtype("cuda")), self.accumulation_steps,
+               id(edge_index))
+        rec = self._graphs.get(key)
+        if rec is None:                                # first sight of this configuration: a plain step, and the warm-up
+            self._graphs[key] = False
+            return self.step(x, time_features, edge_index, edge_weight, y)
+        if rec is False:
+            if self._seed_word is None:
+                self._seed_word = torch.zeros(1, device=x.device, dtype=torch.int64)
+            sx = x.detach().clone()
+            sy = y.detach().clone()
+            if tf_uniform:
+                tf_base = time_features[:, :, :1, :].detach().clone()
+                stf = tf_base.expand_as(time_features)
+            else:
+                tf_base = stf = time_features.detach().clone()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            prev = ops.SEED_WORD
+            ops.SEED_WORD = self._seed_word
+            try:
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    # a fresh word for every replay: an odd 64-bit increment walks all 2^64 values
+                    check(lib().tecm_seed_advance(self._seed_word.data_ptr(), 0x9E3779B97F4A7C15, stream_ptr()),
+                          "tecm_seed_advance")
+                    loss = self._micro_batch(sx, stf, edge_index, edge_weight, sy)
+            finally:
+                ops.SEED_WORD = prev
+            rec = self._graphs[key] = (g, sx, tf_base, sy, loss, edge_index)
+        else:
+            g, sx, tf_base, sy, loss, _ = rec
+            sx.copy_(x, non_blocking=True)
+            sy.copy_(y, non_blocking=True)
+            tf_base.copy_(time_features[:, :, :1, :] if tf_uniform else time_features, non_blocking=True)
+        rec[0].replay()
+        errs = devcheck.error_word(x.device)           # the spatial kernel's index check: read back as an eager step does
+        errs.poll()
+        errs.post()
+        self._micro += 1
+        if self._micro >= self.accumulation_steps:
+            self.finish_accumulation()
+        return rec[4]
 
     # ------------------------------------------------------------------ data-parallel exchange
     def _param_checksum(self) -> torch.Tensor:

@@ -138,6 +138,72 @@ def test_train_step_native_equals_torch_optimizer_path(dev):
     assert outs[0][0][2] != outs[0][0][0]                   # parameters moved after the first boundary
 
 
+def test_recorded_step_equals_the_eager_step_with_dropout_off(dev):
+    """TrainStep.step_graphed (the micro-batch recorded once as a hipGraph and replayed; the optimizer stays outside) against
+    TrainStep.step: same losses and parameters over six micro-batches with accumulation and changing inputs."""
+    from oracle import ref_cpu as R
+    from tecmollm.train import TrainStep
+    cfg = R.default_config(L_in=48, L_out=12, num_nodes=12, llm_layers=1)
+    outs = []
+    for graphed in (False, True):
+        model = _model(cfg, 2, dev).eval()
+        x, tf, ei, y = _inputs(cfg, 2, (3, 4), 4, dev)
+        ts = TrainStep(model, lr=1e-3, accumulation_steps=2)
+        f = ts.step_graphed if graphed else ts.step
+        losses = []
+        for i in range(6):
+            xi = x + 0.01 * i                                # the recorded input tensors must be refilled every call
+            losses.append(float(f(xi, tf, ei, None, y)))
+        outs.append((losses, ts.optimizer.flat_param.detach().clone().cpu()))
+        if graphed:
+            assert len(ts._graphs) == 1 and all(v not in (None, False) for v in ts._graphs.values())
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-5)
+    torch.testing.assert_close(outs[0][1], outs[1][1], rtol=1e-4, atol=2e-6)
+    assert len(set(outs[1][0])) == 6
+
+
+def test_recorded_step_draws_fresh_masks_every_replay_and_the_same_ones_in_forward_and_backward(dev):
+    """Training mode: the recorded kernels add the step's device word to their seeds (TecmDrop::seed_dev).  With lr = 0 the
+    loss of a replay is a function of that word alone: it differs from replay to replay, and setting the word back
+    reproduces loss and gradients bit for bit (the spatial stage's float atomics aside) -- and an EAGER micro-batch run
+    with the same word and plan gives the same gradients, i.e. forward and backward of a replay read one value."""
+    from oracle import ref_cpu as R
+    from src.model import modules as M
+    from tecmollm import ops
+    from tecmollm.train import TrainStep
+    cfg = R.default_config(L_in=48, L_out=12, num_nodes=12, llm_layers=1)
+    model = _model(cfg, 2, dev).train()
+    x, tf, ei, y = _inputs(cfg, 2, (3, 4), 4, dev)
+    ts = TrainStep(model, lr=0.0, weight_decay=0.0, accumulation_steps=1 << 30)       # gradients stay in the flat buffer
+    ts.step_graphed(x, tf, ei, None, y)                      # eager warm-up
+    ts.flat_grad.zero_()
+    l1 = float(ts.step_graphed(x, tf, ei, None, y))          # records + first replay
+    plan_count = M._seed_counter[0]
+    w1 = int(ts._seed_word.item())
+    g1 = ts.flat_grad.clone()
+    ts.flat_grad.zero_()
+    l2 = float(ts.step_graphed(x, tf, ei, None, y))
+    g2 = ts.flat_grad.clone()
+    assert w1 != 0 and int(ts._seed_word.item()) != w1 and l2 != l1 and not torch.equal(g1, g2)
+    # back to the first word: the next replay advances it to w1 again
+    ts._seed_word.fill_(0)
+    ts.flat_grad.zero_()
+    l3 = float(ts.step_graphed(x, tf, ei, None, y))
+    assert int(ts._seed_word.item()) == w1 and l3 == l1
+    torch.testing.assert_close(ts.flat_grad, g1, rtol=1e-4, atol=1e-7)
+    # the eager micro-batch with the same plan (base seed) and the same word
+    ts.flat_grad.zero_()
+    M._seed_counter[0] = plan_count - 1
+    word = torch.tensor([w1], device=dev, dtype=torch.int64)
+    ops.SEED_WORD = word
+    try:
+        l4 = float(ts._micro_batch(x, tf, ei, None, y))
+    finally:
+        ops.SEED_WORD = None
+    assert l4 == l1
+    torch.testing.assert_close(ts.flat_grad, g1, rtol=1e-4, atol=1e-7)
+
+
 # ------------------------------------------------------------------------------------ metrics
 def _check(out, want, rtol=2e-5, atol=2e-6):
     for k in KEYS:

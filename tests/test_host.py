@@ -46,7 +46,7 @@ def test_binding_matches_header(built_lib):
     header = open(os.path.join(ROOT, "include", "tecmollm.h")).read()
     declared = set(re.findall(r"\b(tecm_[a-z0-9_]+)\s*\(", header))
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    assert ctypes.sizeof(_lib.TecmWin) == 32 and ctypes.sizeof(_lib.TecmDrop) == 24
+    assert ctypes.sizeof(_lib.TecmWin) == 32 and ctypes.sizeof(_lib.TecmDrop) == 32
     _lib.lib()                                              # loads, sets prototypes, checks the ABI version
 
 

@@ -134,6 +134,10 @@ int tecm_gemm_bf16x6(const TecmGemm* g, void* stream);
  * blocks on 256 CUs, slabs kept under a tenth of the operand bytes), or 0 when the shape is not served -- the caller
  * sizes split_k / the workspace with it; any split_k >= 2 is accepted.  Pure host function. */
 int32_t tecm_gemm_tn_splits(int64_t M, int64_t N, int64_t K);
+/* Rows per wave row (half the tile height: 128, 112 or 96) the eight-phase bf16 GEMM inside tecm_gemm_bf16 uses for an
+ * M x N result on this device: the height whose tile count wastes least of the last round of CUs (csrc/gemm_bf16_p8.hip).
+ * Exposed so that a caller's per-kernel accounting can name the instantiation a call runs on. */
+int tecm_p8_rows(int64_t M, int64_t N);
 
 /* ------------------------------------------------------------------ stage a-1..a-3 (fused)
  * SpatioTemporalEmbedding.forward (modules.py:230-266) + GATv2Conv (modules.py:329-336,:356)

@@ -15,12 +15,16 @@
 
 namespace tecm_gemm16 {
 
+// WR: rows per wave row -- 128 (the 256 x 256 tile) or 112 / 96 (short tiles of 224 / 192 rows, gemm_bf16_p8_loop.h): the
+// launcher picks the height whose tile count wastes least of the last round of CUs.
+template <int WR>
 __global__ __launch_bounds__(tecm_p8::NTH, 1) void gemm_bf16_p8_kernel(const TecmGemm g, int tiles_m, int tiles_n) {
   // (names qualified on purpose: tecm_gemm16 has its own BM / BN / BK, which would hide tecm_p8's behind a using-directive)
-  constexpr int BM = tecm_p8::BM, BN = tecm_p8::BN, MT = tecm_p8::MT, NT = tecm_p8::NT, LDS_BYTES = tecm_p8::LDS_BYTES;
-  constexpr int WTM = 128, WTN = 64;
+  constexpr int BM = 2 * WR, BN = tecm_p8::BN, MT = tecm_p8::MT, NT = tecm_p8::NT, LDS_BYTES = tecm_p8::LDS_BYTES;
+  constexpr int WTM = WR, WTN = 64;
+  constexpr int SLABS = (WR + 31) / 32;                  // 32-row slabs of a wave's rows; the last one is half used at WR = 112
   static_assert(LDS_BYTES >= 8 * 32 * (WTN + 4) * 4 && tecm_p8::BMAP == 1, "epilogue slabs fit in the operand ring");
-  static_assert(BM == 256 && BN == 256 && MT * 16 == WTM && NT * 16 == WTN, "wave tile 128 x 64 of a 256 x 256 block tile");
+  static_assert(tecm_p8::BM == 256 && BN == 256 && MT * 16 == 128 && NT * 16 == WTN, "wave tile <= 128 x 64, block tile <= 256 x 256");
   __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[LDS_BYTES];
 
   // block -> tile map: XCD-contiguous runs, GROUP_M m-tiles per L2 super-tile (as the other geometries)
@@ -47,7 +51,7 @@ __global__ __launch_bounds__(tecm_p8::NTH, 1) void gemm_bf16_p8_kernel(const Tec
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
   const tecm_p8::Operands o{reinterpret_cast<const __bf16*>(g.A), reinterpret_cast<const __bf16*>(g.B), g.lda, g.ldb, g.M, g.N, (int)g.K};
-  tecm_p8::kloop(o, m0, n0, smem_raw, acc);
+  tecm_p8::kloop<WR>(o, m0, n0, smem_raw, acc);
 #ifdef DMA_ABLATE_NOEPI                                  // diagnostics (tools/build_variant.py): K loop without the epilogue
   {
     float keep = 0.f;
@@ -87,17 +91,47 @@ __global__ __launch_bounds__(tecm_p8::NTH, 1) void gemm_bf16_p8_kernel(const Tec
       });
     });
   };
+  // a short tile's wave stops at its own WR rows: the rows behind them belong to the next wave row / tile (the epilogue
+  // masks rows by M only)
+  TecmGemm gw = g;
+  if constexpr (WR != 128) gw.M = min(g.M, m0 + (int64_t)(wm + 1) * WTM);
   const int fmode = tecm_gemm::epi_fast_mode(g);         // >= 0: checked on the host (tecm_gemm16_dma_try's can16)
   constexpr int LPR = WTN / 4, RPI = 64 / LPR;
   const int lcol = (lane % LPR) * 4, lrow = lane / LPR;
   const EpiCol ecol = epi_col(g, n0 + wn * WTN + lcol);
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (g.bias && ecol.ok) bias4 = *reinterpret_cast<const float4*>(g.bias + ecol.n);
-  tecm_gemm::epi_fast_dispatch<MT / 2, 32 / RPI, RPI, STG_LD, true>(fmode, g, odc, stg, lrow, lcol, m0 + wm * WTM, ecol, bias4,
-                                                                stage_slab);
+  tecm_gemm::epi_fast_dispatch<SLABS, 32 / RPI, RPI, STG_LD, true>(fmode, gw, odc, stg, lrow, lcol, m0 + wm * WTM, ecol, bias4,
+                                                               stage_slab);
 }
 
 }  // namespace tecm_gemm16
+
+// Rows per wave row (tile height / 2) the launcher uses for an M x N result.  The short tile is chosen where it was
+// MEASURED to win (M = 69 864, same box, 256-row -> 224-row tiles): results at most three tiles wide whose tile count it
+// brings closer to whole rounds of CUs -- N = 768 / K = 3072 352 -> 332 us, N = 768 / K = 768 131 -> 128, head d-input
+// (M = 23 288, N = 2304) 94 -> 92.  The rounds-of-CUs model alone over-promises (it says -12.5 % for all N <= 800 shapes):
+// blocks are re-issued as CUs free up and the last, partly filled round runs faster per tile -- the launch is bound by what
+// the CUs share, not by the slowest CU -- so wider results (N = 800 / 2304: +2 %; N = 3072: +9 %) and 192-row tiles
+// (+0 .. +13 %) stay on 256 rows; with a residual + dropout epilogue the two heights tie.
+// TECM_P8_ROWS = 128 | 112 | 96 pins it (A/B diagnostics).  Mirrored by tecmollm/ops.py (kernel names of the roofline).
+extern "C" int tecm_p8_rows(int64_t M, int64_t N) {
+  if (const char* e = std::getenv("TECM_P8_ROWS")) {     // read per call: the tests pin one height after another
+    const int v = atoi(e);
+    if (v == 128 || v == 112 || v == 96) return v;
+  }
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    return n;
+  }();
+  const int64_t tn = (N + tecm_p8::BN - 1) / tecm_p8::BN;
+  auto cost = [&](int wr) { return ((((M + 2 * wr - 1) / (2 * wr)) * tn + cus - 1) / cus) * wr; };
+  if (tn <= 3 && cost(112) < cost(128)) return 112;
+  if (M <= 32768 && cost(112) < cost(128)) return 112;      // few m-tiles (the head's d-input): the last round weighs more
+  return 128;
+}
 
 // 1 when this geometry served the call, 0 when the call is not eligible (the caller falls through to the ring kernels).
 // Eligibility beyond the ring kernels' (checked by the caller: both operands bf16, plain views, float4 epilogue, one
@@ -114,8 +148,13 @@ int tecm_gemm16_p8_try(const TecmGemm& g, hipStream_t st) {
   // the 128-column geometry; N = 576 / 384 / 128, the head and the 1x1 convs: 174 / 120 / 128 us against 147 / 88 / 102)
   const int nrem = (int)(g.N % tecm_p8::BN);
   if (!force && nrem >= 1 && nrem <= 128 && g.N < 768) return 0;
-  const int tiles_m = (int)((g.M + tecm_p8::BM - 1) / tecm_p8::BM), tiles_n = (int)((g.N + tecm_p8::BN - 1) / tecm_p8::BN);
-  hipLaunchKernelGGL(gemm_bf16_p8_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(tecm_p8::NTH), 0, st, g, tiles_m, tiles_n);
+  const int tiles_n = (int)((g.N + tecm_p8::BN - 1) / tecm_p8::BN);
+  const int wr = tecm_p8_rows(g.M, g.N);
+  const int tiles_m = (int)((g.M + 2 * wr - 1) / (2 * wr));
+  const dim3 grid((unsigned)(tiles_m * tiles_n)), block(tecm_p8::NTH);
+  if (wr == 128) hipLaunchKernelGGL(gemm_bf16_p8_kernel<128>, grid, block, 0, st, g, tiles_m, tiles_n);
+  else if (wr == 112) hipLaunchKernelGGL(gemm_bf16_p8_kernel<112>, grid, block, 0, st, g, tiles_m, tiles_n);
+  else hipLaunchKernelGGL(gemm_bf16_p8_kernel<96>, grid, block, 0, st, g, tiles_m, tiles_n);
   TECM_CHECK_LAUNCH("tecm_gemm_bf16/p8");
   return 1;
 }

@@ -71,7 +71,16 @@ __device__ __forceinline__ void bar() {
 //   BMAP 0: acc[i][j][e] = C[m0 + wr*128 + 16 i + (lane & 15)][n0 + wc*64 + 16 j + 4 (lane >> 4) + e]
 // -- lane (fr, fq) holds, for each of its 8 row tiles i, the 16 consecutive columns 16 fq .. 16 fq + 15 of row 16 i + fr:
 // the epilogue works row-wise straight from the registers (64 B fp32 / 32 B bf16 per lane and row), no LDS staging.
+//
+// WR = rows of C a wave row owns: 128, or 112 / 96 -- the SHORT tiles (block tile 2 WR x 256).  A short tile moves the same
+// half-tiles (its A1 rows 64 .. 127 of a wave row reach into the next wave row's / tile's rows; they are loaded and not
+// used) and runs 12 / 8 MFMAs instead of 16 in the two phases of the lower quadrants: accumulator row tiles WR/16 .. 7
+// stay zero and are never stored.  What it buys is the tile COUNT: 273 x 3 tiles of 256 rows (M = 69 864, N = 768) are 3.2
+// rounds of 256 CUs = four rounds of work for 3.2 rounds of result; 312 x 3 tiles of 224 rows are 3.66 rounds of 7/8 the work.
+template <int WR = 128>
 __device__ __forceinline__ void kloop(const Operands& o, int64_t m0, int64_t n0, unsigned char* smem, f32x4 (&acc)[MT][NT]) {
+  static_assert(WR == 128 || WR == 112 || WR == 96, "a wave row owns 8, 7 or 6 row tiles of 16");
+  constexpr int MTU = WR / 16;                          // row tiles in use
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave >> 2, wc = wave & 3;
@@ -95,7 +104,7 @@ __device__ __forceinline__ void kloop(const Operands& o, int64_t m0, int64_t n0,
       const int lr = 16 * wave + 8 * i + (lane >> 3);
       const int chunk = (lane & 7) ^ ((lr >> 1) & 7);
       if (isA) {
-        int64_t gm = m0 + (lr >> 6) * 128 + h * 64 + (lr & 63);
+        int64_t gm = m0 + (lr >> 6) * WR + h * 64 + (lr & 63);
         gm = gm < o.M ? gm : o.M - 1;                  // clamped rows feed accumulator rows that are never stored
         soff[k][i] = (uint32_t)((gm * o.lda + chunk * 8) * 2);
       } else {
@@ -135,11 +144,13 @@ __device__ __forceinline__ void kloop(const Operands& o, int64_t m0, int64_t n0,
     boff[ks] = (wc * 32 + fr) * 128 + pos;
   }
   bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
-  auto read_a = [&](int slot_bytes, int kind) {
+  auto read_a = [&](int slot_bytes, auto kindc) {
+    constexpr int kind = decltype(kindc)::value;         // 0: A0 (row tiles 0-3), 3: A1 (row tiles 4 .. MTU-1)
+    constexpr int NI = kind == 0 ? 4 : MTU - 4;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < NI; ++i)
         fa[i][ks] = *reinterpret_cast<const bf16x8*>(smem + slot_bytes + kind * HALF_BYTES + aoff[ks] + i * 2048);
   };
   auto read_b = [&](bf16x8 (&fb)[2][2], int slot_bytes, int kind) {
@@ -151,12 +162,13 @@ __device__ __forceinline__ void kloop(const Operands& o, int64_t m0, int64_t n0,
   };
   auto quadrant = [&](auto hac, auto hbc, const bf16x8 (&fb)[2][2], bool half_deep) {
     constexpr int HA = decltype(hac)::value, HB = decltype(hbc)::value;
+    constexpr int NI = HA == 0 ? 4 : MTU - 4;
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       if (ks == 1 && half_deep) break;                  // wave-uniform
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[4 * HA + i][2 * HB + j] =
@@ -181,7 +193,7 @@ __device__ __forceinline__ void kloop(const Operands& o, int64_t m0, int64_t n0,
     // phase 0: c[0][0]
     read_b(fb0, cur, 1);
     __builtin_amdgcn_sched_barrier(0);
-    read_a(cur, 0);
+    read_a(cur, K0{});
     if (g + 6 < S) issue(K2{}, oth, tl1);
     if (!last) wait_vm<8>(); else wait_vm<2>();
     bar();
@@ -195,7 +207,7 @@ __device__ __forceinline__ void kloop(const Operands& o, int64_t m0, int64_t n0,
     quadrant(K0{}, K1{}, fb1, hd);
     bar();
     // phase 2: c[1][1]
-    read_a(cur, 3);
+    read_a(cur, K3{});
     if (g + 8 < S) issue(K0{}, cur, tl2);
     bar();
     quadrant(K1{}, K1{}, fb1, hd);

@@ -195,6 +195,7 @@ EXPORTS = {
     "tecm_conv_dx_f32": (C.c_int, [C.POINTER(TecmConvDx), C.c_void_p]),
     "tecm_conv_fwd_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "tecm_gemm_tn_splits": (C.c_int32, [C.c_int64, C.c_int64, C.c_int64]),
+    "tecm_p8_rows": (C.c_int, [C.c_int64, C.c_int64]),
     "tecm_conv_dx_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "tecm_transpose_scale": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_float,
                                        C.c_void_p]),

@@ -219,7 +219,7 @@ def _kernel_name(g: TecmGemm, use16: bool = False) -> str:
             p8 = os.environ.get("TECM_BF16_P8", "")[:1]                        # mirrors tecm_gemm16_p8_try (gemm_bf16_p8.hip)
             if (can16 and not sel and p8 != "0" and g.K >= 128 and g.N >= 128 and (p8 == "1" or g.N >= 768 or not 1 <= g.N % 256 <= 128)
                     and (g.M * g.lda + 64) * 2 < 2 ** 32 and (g.N * g.ldb + 64) * 2 < 2 ** 32):
-                return "gemm_bf16_p8_kernel"
+                return f"gemm_bf16_p8_kernel<{lib().tecm_p8_rows(g.M, g.N)}>"
             narrow = n_small or (sel == "2" if (sel and not k32) else 1 <= g.N % 256 <= 128)   # the 256 x 128 geometry (N = 800)
             if narrow:
                 return "gemm_bf16_dma2_kernel"

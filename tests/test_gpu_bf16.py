@@ -290,15 +290,17 @@ def test_bf16_dma_ring_kernel_is_race_free_over_repeated_full_size_launches(dev,
         monkeypatch.delenv("TECM_BF16_P8")
 
 
+@pytest.mark.parametrize("rows", [128, 112, 96])
 @pytest.mark.parametrize("M,N,K", [(257, 768, 128), (1031, 2304, 800), (4099, 768, 3072), (513, 3072, 768), (300, 256, 160),
                                    (256, 800, 2304), (70000, 768, 768)])
-def test_bf16_p8_geometry_agrees_to_fp32_rounding(dev, M, N, K, monkeypatch):
+def test_bf16_p8_geometry_agrees_to_fp32_rounding(dev, M, N, K, rows, monkeypatch):
     """gemm_bf16_p8_kernel (round 5: 256 x 256 x 64 eight-phase K loop, half-tile LDS-DMA ring across raw barriers, wave
     groups half a phase apart; csrc/gemm_bf16_p8_loop.h) against the two-slot 32x32x16 kernel: another summation order,
     so fp32 outputs agree to 2e-6 of the largest value and bf16 outputs to one ulp.  Shapes: ragged M and N tiles, the
     shortest K (two K-tiles: the prologue IS the pipeline), K % 64 == 32 (the half-deep last tile of c_attn + LoRA, also
     with an odd tile count 160 = 2.5 tiles), N = 800 forced through it (TECM_BF16_P8 = 1), and 274 m-tiles (more blocks
-    than CUs); epilogues: GELU + bf16 C + pre-activation, residual + dropout, GELU'."""
+    than CUs); epilogues: GELU + bf16 C + pre-activation, residual + dropout, GELU'.  rows: the three tile heights (2 x 128
+    and the short tiles 2 x 112 / 2 x 96 whose last accumulator row tiles stay unused), pinned by TECM_P8_ROWS."""
     from tecmollm import ops
     A16, B16 = _rand(M, K, dev=dev, seed=1).bfloat16(), _rand(N, K, dev=dev, seed=2, scale=0.05).bfloat16()
     bias, res, pre_src = _rand(N, dev=dev, seed=4), _rand(M, N, dev=dev, seed=5), _rand(M, N, dev=dev, seed=6)
@@ -321,12 +323,13 @@ def test_bf16_p8_geometry_agrees_to_fp32_rounding(dev, M, N, K, monkeypatch):
     want = run("gemm_bf16_dma_kernel")
     monkeypatch.delenv("TECM_BF16_DMA")
     monkeypatch.setenv("TECM_BF16_P8", "1")
-    got = run("gemm_bf16_p8_kernel")
+    monkeypatch.setenv("TECM_P8_ROWS", str(rows))
+    got = run(f"gemm_bf16_p8_kernel<{rows}>")
     for g_, w_ in zip(got[1:], want[1:]):
         assert torch.isfinite(g_).all() and _rel(g_, w_) < 2e-6
     diff = (got[0].float() - want[0].float()).abs()
     assert bool((diff <= want[0].float().abs() * 2.0 ** -7 + 1e-6).all())
-    again = run("gemm_bf16_p8_kernel")                   # bit-reproducible
+    again = run(f"gemm_bf16_p8_kernel<{rows}>")          # bit-reproducible
     for g_, w_ in zip(got, again):
         assert torch.equal(g_, w_)
     # against an fp64 product of the same bf16 operands (an independent reference, not another kernel of this library)

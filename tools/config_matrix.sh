@@ -15,6 +15,8 @@ for l in sys.stdin:
 for p in bf16 fp32; do
   for b in 1 2 3 8; do run --precision $p --batch $b --steps 20 --warmup 5; done
 done
+# the same small batches with the micro-batch recorded as a hipGraph (TrainStep.step_graphed)
+for b in 1 2; do run --precision bf16 --batch $b --steps 20 --warmup 5 --graph; done
 run --precision bf16 --L_in 96 --L_out 24
 run --precision bf16 --L_in 336 --batch 2 --steps 5 --warmup 2
 run --precision bf16 --L_in 336 --batch 2 --llm_layers 6 --steps 5 --warmup 2

@@ -115,6 +115,8 @@ def main():
     L, N, C, Cin = 48, 2911, 22, 10
     alg = {"spatial_fwd_kernel": 4 * L * N * (Cin + C) * B, "spatial_bwd_kernel<1>": 4 * L * N * (C + Cin) * B,
            "spatial_bwd_kernel<2>": 4 * L * N * (C + Cin) * B}
+    for cin in (6, 10):                                  # round 5: the second formulations (template argument = C_in)
+        alg[f"spatial_fwd2_kernel<{cin}>"] = alg[f"spatial_bwd2_kernel<{cin}>"] = 4 * L * N * (Cin + C) * B
     md = [f"# Round {tag[1:]} -- L2-miss (HBM-side) traffic and rate per kernel, {prec}\n",
           "From the `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes (separate runs; KiB -> bytes, FETCH x2 on gfx950) of "
           f"`python3 bench.py --precision {prec} --steps 1 --warmup 1 --no-cpu-baseline --no-other-precisions "

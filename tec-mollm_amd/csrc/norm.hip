@@ -1047,27 +1047,32 @@ __global__ __launch_bounds__(256) void colsum_stage1_v4(const float* __restrict_
 
 // stage 2: 512 threads = 8 waves per 64 columns, 32 loads in flight per lane: 1024 partial rows are four rounds of
 // memory latency (the first version -- 4 waves, 16 in flight -- took sixteen: 23 us per launch, 68 launches a step).
-__global__ __launch_bounds__(512) void colsum_stage2(const float* __restrict__ ws, int RB, int nseg, int C,
-                                                     float* __restrict__ out, int64_t ldo, int accumulate,
-                                                     float scale) {
-  __shared__ float red[8][64];
+// WAVES = 16 (round 5): the narrow matrices (C <= 128: one or two column blocks for up to 1024 partial rows) take ONE round
+// of latency instead of four -- 17-23 us -> see DESIGN_HISTORY B.11; the summation order differs between the two forms
+// only in the association of the partial rows, fixed per (RB, WAVES): results stay run-to-run identical.
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void colsum_stage2(const float* __restrict__ ws, int RB, int nseg, int C,
+                                                            float* __restrict__ out, int64_t ldo, int accumulate,
+                                                            float scale) {
+  constexpr int UNR = WAVES == 16 ? 64 : 32;            // loads in flight per lane
+  __shared__ float red[WAVES][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane, s = blockIdx.y;
   float acc = 0.f;
   if (c < C) {
-    float a32[32];
+    float a32[UNR];
 #pragma unroll
-    for (int u = 0; u < 32; ++u) a32[u] = 0.f;
-    for (int rb = wave; rb < RB; rb += 256) {
+    for (int u = 0; u < UNR; ++u) a32[u] = 0.f;
+    for (int rb = wave; rb < RB; rb += WAVES * UNR) {
 #pragma unroll
-      for (int u = 0; u < 32; ++u) {                    // clamped row + select, not `if`: the bound is wave-uniform, a branch
-        const int r = rb + 8 * u;                       // per load would put a wait between every two of them
+      for (int u = 0; u < UNR; ++u) {                   // clamped row + select, not `if`: the bound is wave-uniform, a branch
+        const int r = rb + WAVES * u;                   // per load would put a wait between every two of them
         const float v = ws[((int64_t)s * RB + (r < RB ? r : RB - 1)) * C + c];
         a32[u] += r < RB ? v : 0.f;
       }
     }
 #pragma unroll
-    for (int u = 16; u > 0; u >>= 1)
+    for (int u = UNR / 2; u > 0; u >>= 1)
 #pragma unroll
       for (int v = 0; v < u; ++v) a32[v] += a32[v + u];
     acc = a32[0];
@@ -1075,11 +1080,20 @@ __global__ __launch_bounds__(512) void colsum_stage2(const float* __restrict__ w
   red[wave][lane] = acc;
   __syncthreads();
   if (wave == 0 && c < C) {
-    const float v = (((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) +
-                     ((red[4][lane] + red[5][lane]) + (red[6][lane] + red[7][lane]))) * scale;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < WAVES; w += 4) v += (red[w][lane] + red[w + 1][lane]) + (red[w + 2][lane] + red[w + 3][lane]);
+    v *= scale;
     float* o = out + (int64_t)s * ldo + c;
     *o = accumulate ? *o + v : v;
   }
+}
+void launch_colsum_stage2(const float* ws, int RB, int nseg, int C, float* out, int64_t ldo, int accumulate, float scale,
+                          int colblocks, hipStream_t st) {
+  if (colblocks * nseg <= 4 && RB > 256)
+    hipLaunchKernelGGL(colsum_stage2<16>, dim3(colblocks, nseg), dim3(1024), 0, st, ws, RB, nseg, C, out, ldo, accumulate, scale);
+  else
+    hipLaunchKernelGGL(colsum_stage2<8>, dim3(colblocks, nseg), dim3(512), 0, st, ws, RB, nseg, C, out, ldo, accumulate, scale);
 }
 
 int ln_blocks(int64_t M) {
@@ -1631,8 +1645,7 @@ static int colsum_impl(const float* in, int64_t ld, int64_t outer, int64_t inner
     hipLaunchKernelGGL(colsum_stage1_v4, dim3((unsigned)rb4, nseg), dim3(256), 0, st, in, ld, outer, inner, nseg, C,
                        idc, workspace, chunk4, static_cast<__bf16*>(twin), ld_twin);
     TECM_CHECK_LAUNCH("tecm_colsum/stage1_v4");
-    hipLaunchKernelGGL(colsum_stage2, dim3(colblocks, nseg), dim3(512), 0, st, workspace, (int)rb4, nseg, C, out, ldo,
-                       accumulate, scale);
+    launch_colsum_stage2(workspace, (int)rb4, nseg, C, out, ldo, accumulate, scale, colblocks, st);
     TECM_CHECK_LAUNCH("tecm_colsum/stage2");
     return TECM_OK;
   }
@@ -1640,8 +1653,7 @@ static int colsum_impl(const float* in, int64_t ld, int64_t outer, int64_t inner
   hipLaunchKernelGGL(colsum_stage1, dim3(colblocks, (unsigned)rb, nseg), dim3(256), 0, st, in, ld, outer, inner, nseg,
                      C, idc, workspace, chunk);
   TECM_CHECK_LAUNCH("tecm_colsum/stage1");
-  hipLaunchKernelGGL(colsum_stage2, dim3(colblocks, nseg), dim3(512), 0, st, workspace, (int)rb, nseg, C, out, ldo,
-                     accumulate, scale);
+  launch_colsum_stage2(workspace, (int)rb, nseg, C, out, ldo, accumulate, scale, colblocks, st);
   TECM_CHECK_LAUNCH("tecm_colsum/stage2");
   return TECM_OK;
 }

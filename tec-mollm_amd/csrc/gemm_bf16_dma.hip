@@ -1101,9 +1101,17 @@ int tecm_gemm16_dma_try(const TecmGemm& g, hipStream_t st) {
   if (!both || !(g.io_bf16 & TECM_P0_VEC4) || g.split_k > 1 || g.K % 32 != 0 || g.K < 32 || g.M < DBM || g.N < 32 ||
       ((k32 || n_small) && g.a_win.enabled) || (n_small && g.N > 32))    // N = 64 (first 1x1 conv): the register-staged
     return 0;                                                               //   kernel's 64-column tile is faster (114 vs 124 us)
+  // the straight-line epilogues (gemm_impl.h: epi_fast_mode >= 0): at most one input stream; or a row bias; or an fp32
+  // window scatter with nothing but bias / activation / dropout
+  const int n_streams = (g.residual ? 1 : 0) + (g.dact_src ? 1 : 0) + (g.accumulate ? 1 : 0);
+  const bool fast_epi = g.c_win.enabled ? (n_streams == 0 && !g.rowbias && !g.preact &&
+                                           !(g.io_bf16 & (TECM_IO_C_BF16 | TECM_IO_PRE_BF16)))
+                                        : (g.rowbias ? n_streams == 0 : n_streams <= 1);
   if (g.a_win.enabled) {
     // a pad-free window view of A whose taps are whole K-tiles (the patch projection's 'b (p l) d -> b p (l d)',
-    // modules.py:114): served by the first geometry, whose source pointers move one time step on at every tap boundary
+    // modules.py:114): the eight-phase geometry (round 5), else the first geometry -- both move their source pointers one
+    // time step on at every tap boundary
+    if (!sel && !k32 && !n_small && fast_epi && tecm_gemm16_p8_try(g, st)) return 1;
     const TecmWin& w = g.a_win;
     if (g.b_win.enabled || w.pad != 0 || w.Cw % DBK != 0 || (int64_t)(w.Lout - 1) * w.stride_t + w.taps > w.Lin ||
         g.M % ((int64_t)w.Lout * w.N) != 0)
@@ -1115,10 +1123,7 @@ int tecm_gemm16_dma_try(const TecmGemm& g, hipStream_t st) {
   }
   // round 5: the eight-phase geometry (gemm_bf16_p8.hip) wherever it is eligible (it declines n-tiles that are mostly
   // padding, N = 800, unless forced); TECM_BF16_P8 = 0 or any TECM_BF16_DMA selection keeps the older geometries
-  {
-    const int streams = (g.residual ? 1 : 0) + (g.dact_src ? 1 : 0) + (g.accumulate ? 1 : 0);
-    if (!sel && !g.c_win.enabled && !g.rowbias && streams <= 1 && tecm_gemm16_p8_try(g, st)) return 1;
-  }
+  if (!sel && fast_epi && tecm_gemm16_p8_try(g, st)) return 1;
   // the 128-column geometry where the 256-column tile would waste more than half of its last n-tile (N = 800);
   // TECM_BF16_DMA = 1 / 2 forces one of the two (A/B diagnostics, tools/dma_ab.sh)
   const int nrem = (int)(g.N % DBN);

@@ -50,7 +50,8 @@ __global__ __launch_bounds__(tecm_p8::NTH, 1) void gemm_bf16_p8_kernel(const Tec
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
-  const tecm_p8::Operands o{reinterpret_cast<const __bf16*>(g.A), reinterpret_cast<const __bf16*>(g.B), g.lda, g.ldb, g.M, g.N, (int)g.K};
+  const tecm_p8::Operands o{reinterpret_cast<const __bf16*>(g.A), reinterpret_cast<const __bf16*>(g.B), g.lda, g.ldb, g.M, g.N, (int)g.K,
+                            g.a_win.enabled ? g.a_win.N : 0, g.a_win.Lin, g.a_win.Lout, g.a_win.stride_t, g.a_win.Cw};
   tecm_p8::kloop<WR>(o, m0, n0, smem_raw, acc);
 #ifdef DMA_ABLATE_NOEPI                                  // diagnostics (tools/build_variant.py): K loop without the epilogue
   {
@@ -143,7 +144,16 @@ int tecm_gemm16_p8_try(const TecmGemm& g, hipStream_t st) {
   if (sel && sel[0] == '0') return 0;
   const bool force = sel && sel[0] == '1';
   if (g.K < 128 || g.K % 32 != 0 || g.M < tecm_p8::BM || g.N < 128) return 0;
-  if ((g.M * g.lda + 64) * 2 >= (int64_t(1) << 32) || (g.N * g.ldb + 64) * 2 >= (int64_t(1) << 32)) return 0;
+  int64_t a_rows = g.M;                                  // source rows of A the kernel may address
+  if (g.a_win.enabled) {
+    // a pad-free window view whose taps are whole K-tiles and stay inside the sequence (the patch projection, modules.py:114)
+    const TecmWin& w = g.a_win;
+    if (g.b_win.enabled || w.pad != 0 || w.Cw % tecm_p8::BK != 0 || (int64_t)(w.Lout - 1) * w.stride_t + w.taps > w.Lin ||
+        g.M % ((int64_t)w.Lout * w.N) != 0)
+      return 0;
+    a_rows = g.M / ((int64_t)w.Lout * w.N) * w.Lin * w.N;
+  }
+  if ((a_rows * g.lda + 64) * 2 >= (int64_t(1) << 32) || (g.N * g.ldb + 64) * 2 >= (int64_t(1) << 32)) return 0;
   // a last n-tile that is mostly padding is only worth it from N = 768 on (N = 800, d c_attn: 290 us here against 344 on
   // the 128-column geometry; N = 576 / 384 / 128, the head and the 1x1 convs: 174 / 120 / 128 us against 147 / 88 / 102)
   const int nrem = (int)(g.N % tecm_p8::BN);

@@ -56,6 +56,10 @@ constexpr int MT = 8, NT = 4;                         // accumulator tiles of 16
 struct Operands {
   const __bf16* A; const __bf16* B;                   // [M][lda], [N][ldb], bf16, 16-byte aligned rows
   int64_t lda, ldb, M, N; int K;                      // K % 32 == 0, K >= 128; byte offsets of both operands < 4 GiB
+  // A as a pad-free window view (TecmWin, include/tecmollm.h; the patch projection's 'b (p l) d -> b p (l d)', modules.py:114):
+  // row m = (bq, t_out, n) starts at source row (bq*Lin + t_out*stride_t)*wN + n, K index kk = (tap, c) lies `tap` time
+  // steps = tap*wN source rows further on.  Cw % 64 == 0: a K-tile never straddles a tap.  wN == 0: the plain view.
+  int32_t wN, wLin, wLout, wstride, wCw;
 };                                                    // (K % 64 == 32, c_attn with its 32 LoRA columns: the last K-tile is
                                                       //  half deep -- its DMAs re-read the valid half, its MFMAs stop at k = 32)
 
@@ -106,6 +110,11 @@ __device__ __forceinline__ void kloop(const Operands& o, int64_t m0, int64_t n0,
       if (isA) {
         int64_t gm = m0 + (lr >> 6) * WR + h * 64 + (lr & 63);
         gm = gm < o.M ? gm : o.M - 1;                  // clamped rows feed accumulator rows that are never stored
+        if (o.wN > 0) {                                // window view: the source row of tap 0 (32-bit arithmetic, M < 2^31)
+          const uint32_t q = (uint32_t)gm / (uint32_t)o.wN, n = (uint32_t)gm - q * (uint32_t)o.wN;
+          const uint32_t bq = q / (uint32_t)o.wLout, t_out = q - bq * (uint32_t)o.wLout;
+          gm = ((int64_t)bq * o.wLin + (int64_t)t_out * o.wstride) * o.wN + n;
+        }
         soff[k][i] = (uint32_t)((gm * o.lda + chunk * 8) * 2);
       } else {
         // LDS row lr of B_h = wave column lr >> 5, MFMA tile jl = (lr >> 4) & 1 of the half, fragment row r16 = lr & 15;
@@ -120,6 +129,10 @@ __device__ __forceinline__ void kloop(const Operands& o, int64_t m0, int64_t n0,
   const char* Ab = reinterpret_cast<const char*>(o.A);
   const char* Bb = reinterpret_cast<const char*>(o.B);
   int kA0 = 0, kB0 = 0, kB1 = 0, kA1 = 0;              // bytes along K already issued, per kind (wave-uniform)
+  // window view of A: after the last K-tile of a tap the source moves on by one time step (wN source rows) less the tap
+  const int a_tpt = o.wN > 0 ? o.wCw / BK : 0x40000000;  // K-tiles per tap
+  const int a_jump = o.wN > 0 ? (int)(((int64_t)o.wN * o.lda - o.wCw) * 2) : 0;
+  int iA0 = 0, iA1 = 0;                                // K-tiles issued inside the current tap, per A kind
   auto issue = [&](auto kc, int slot_bytes, bool tail_tile = false) {
     constexpr int k = decltype(kc)::value;
     const uint32_t tm = tail_tile ? 0xffffffffu : 0u;
@@ -130,6 +143,12 @@ __device__ __forceinline__ void kloop(const Operands& o, int64_t m0, int64_t n0,
     __builtin_amdgcn_global_load_lds((glb_void*)(base + (soff[k][0] - (tadj[0] & tm))), (lds_void*)dst, 16, 0, 0);
     __builtin_amdgcn_global_load_lds((glb_void*)(base + (soff[k][1] - (tadj[1] & tm))), (lds_void*)(dst + 1024), 16, 0, 0);
     kk += BK * 2;
+    if constexpr (isA) {
+      int& it = k == 0 ? iA0 : iA1;
+      const bool wrap = ++it == a_tpt;
+      kk += wrap ? a_jump : 0;
+      it = wrap ? 0 : it;
+    }
   };
   using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
   using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;

@@ -523,6 +523,16 @@ __device__ __forceinline__ void epi_vec4(const TecmGemm& g, const DropCtx& odc, 
 template <int NIT, int RPI, int MODE>
 __device__ __forceinline__ void epi_fast_load(const TecmGemm& g, int lrow, int64_t mrow0, const EpiCol& ecol,
                                               float4 (&in)[NIT]) {
+  if constexpr (MODE == 5) {                             // row bias: row ((m / rb_div) % rb_mod) of a small table (wpe)
+    if (!ecol.ok) return;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      int64_t m = mrow0 + it * RPI + lrow;
+      m = m < g.M ? m : g.M - 1;
+      const uint32_t rr = ((uint32_t)m / (uint32_t)g.rb_div) % (uint32_t)g.rb_mod;
+      in[it] = *reinterpret_cast<const float4*>(g.rowbias + (int64_t)rr * g.rb_ld + ecol.n);
+    }
+  }
   if constexpr (MODE >= 1 && MODE <= 3) {
     if (!ecol.ok) return;
     const float* src = MODE == 1 ? g.residual : (MODE == 2 ? g.dact_src : g.C);
@@ -565,6 +575,9 @@ __device__ __forceinline__ void epi_fast_rows(const TecmGemm& g, const DropCtx& 
       continue;
     }
     float o[4] = {v.x * g.alpha + bias4.x, v.y * g.alpha + bias4.y, v.z * g.alpha + bias4.z, v.w * g.alpha + bias4.w};
+    if constexpr (MODE == 5) {                         // + row bias, where epi_vec4 adds it: before pre-activation / act / dropout
+      o[0] += in[it].x; o[1] += in[it].y; o[2] += in[it].z; o[3] += in[it].w;
+    }
     if (g.preact && p16) {                             // bf16 pre-activation (see epi_vec4)
       tecm_bf16x4 hv;
       hv[0] = (__bf16)o[0]; hv[1] = (__bf16)o[1]; hv[2] = (__bf16)o[2]; hv[3] = (__bf16)o[3];
@@ -597,16 +610,24 @@ __device__ __forceinline__ void epi_fast_rows(const TecmGemm& g, const DropCtx& 
         for (int e = 0; e < 4; ++e) o[e] = gelu_tanh(o[e]);
       }
     }
+    int64_t off = m * g.ldc + n, didx = m * odc.ld + n;
+    bool st_ok = row_ok;
+    if constexpr (MODE == 6) {                         // window scatter (epi_vec4's address arithmetic): column n = (tap, c)
+      const WinRow w = win_row(g.c_win, m < g.M ? m : g.M - 1, g.M);
+      const int32_t t_in = w.t0 + ecol.tap;
+      const int64_t row = w.srow + (int64_t)ecol.tap * g.c_win.N;
+      st_ok = row_ok && t_in >= 0 && t_in < g.c_win.Lin;
+      off = row * g.ldc + ecol.c;
+      didx = row * odc.ld + ecol.c;
+    }
     if (odc.thresh) {
-      const int64_t didx = m * odc.ld + n;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] *= tecm_drop_mult(odc.seed, (uint64_t)(didx + e), odc.thresh, odc.inv);
     }
     if constexpr (MODE == 1 || MODE == 3) {            // + residual, or + the previous contents of C (accumulate)
       o[0] += in[it].x; o[1] += in[it].y; o[2] += in[it].z; o[3] += in[it].w;
     }
-    if (row_ok) {
-      const int64_t off = m * g.ldc + n;
+    if (st_ok) {
       if constexpr (NT) {
         if (c16) {
           tecm_bf16x4 hv;
@@ -643,12 +664,17 @@ __device__ __forceinline__ void epi_fast_block(const TecmGemm& g, const DropCtx&
   });
 }
 // which epilogues the straight-line form serves (everything else: the generic loop)
-// MODE: 0 no input stream, 1 residual, 2 GELU' source, 3 accumulate into C, 4 split-K slab store; -1: generic loop
+// MODE: 0 no input stream, 1 residual, 2 GELU' source, 3 accumulate into C, 4 split-K slab store, 5 row bias (the patch
+// projection's + wpe), 6 window scatter of C (the patch projection's input gradient); -1: generic loop
+// (Round 5: 5 and 6 were generic-loop cases -- the patch projection forward took 184 us against 87 for the same contraction
+//  with a plain epilogue, its d-input 144 against 83: a store round trip per row group, see "fast epilogue rows" above.)
 __device__ __forceinline__ int epi_fast_mode(const TecmGemm& g) {
   if (!(g.io_bf16 & TECM_P0_VEC4)) return -1;
   if (gridDim.z > 1) return 4;
-  if (g.c_win.enabled || g.rowbias) return -1;
   const int streams = (g.residual ? 1 : 0) + (g.dact_src ? 1 : 0) + (g.accumulate ? 1 : 0);
+  if (g.c_win.enabled)                                 // 6: fp32 window scatter with bias / act / dropout, nothing else
+    return (streams == 0 && !g.rowbias && !g.preact && !(g.io_bf16 & (TECM_IO_C_BF16 | TECM_IO_PRE_BF16))) ? 6 : -1;
+  if (g.rowbias) return streams == 0 ? 5 : -1;        // 5: row bias in place of the input stream
   if (streams > 1) return -1;
   return g.residual ? 1 : (g.dact_src ? 2 : (g.accumulate ? 3 : 0));
 }
@@ -661,6 +687,8 @@ __device__ __forceinline__ void epi_fast_dispatch(int mode, const TecmGemm& g, c
   else if (mode == 1) epi_fast_block<SLABS, NIT, RPI, STG_LD, 1, NT>(g, odc, stg, lrow, lcol, mrow0, ecol, bias4, stage);
   else if (mode == 2) epi_fast_block<SLABS, NIT, RPI, STG_LD, 2, NT>(g, odc, stg, lrow, lcol, mrow0, ecol, bias4, stage);
   else if (mode == 3) epi_fast_block<SLABS, NIT, RPI, STG_LD, 3, NT>(g, odc, stg, lrow, lcol, mrow0, ecol, bias4, stage);
+  else if (mode == 5) epi_fast_block<SLABS, NIT, RPI, STG_LD, 5, NT>(g, odc, stg, lrow, lcol, mrow0, ecol, bias4, stage);
+  else if (mode == 6) epi_fast_block<SLABS, NIT, RPI, STG_LD, 6, NT>(g, odc, stg, lrow, lcol, mrow0, ecol, bias4, stage);
   else epi_fast_block<SLABS, NIT, RPI, STG_LD, 4, NT>(g, odc, stg, lrow, lcol, mrow0, ecol, bias4, stage);
 }
 

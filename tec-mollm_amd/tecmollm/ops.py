@@ -204,21 +204,34 @@ def _kernel_name(g: TecmGemm, use16: bool = False) -> str:
         if (g.io_bf16 & (IO_A_BF16 | IO_B_BF16)) and not (g.a_layout == A_MK and g.b_layout == B_NK and win16 == "false"):
             win16 = "true"                             # the bf16-resident window / transposed instances are built WIN = true
         both16 = (g.io_bf16 & IO_A_BF16) and (g.io_bf16 & IO_B_BF16)
+        # the straight-line epilogues (gemm_impl.h epi_fast_mode >= 0; mirrors tecm_gemm16_dma_try's fast_epi)
+        streams = (1 if g.residual else 0) + (1 if g.dact_src else 0) + (1 if g.accumulate else 0)
+        if g.c_win.enabled:
+            fast_epi = streams == 0 and not g.rowbias and not g.preact and not (g.io_bf16 & (IO_C_BF16 | IO_PRE_BF16))
+        else:
+            fast_epi = streams == 0 if g.rowbias else streams <= 1
+        p8 = os.environ.get("TECM_BF16_P8", "")[:1]                            # mirrors tecm_gemm16_p8_try (gemm_bf16_p8.hip)
+
+        def p8_takes(a_rows: int) -> bool:
+            return (fast_epi and not os.environ.get("TECM_BF16_DMA", "") and p8 != "0" and g.K >= 128 and g.K % 32 == 0
+                    and g.M >= 256 and g.N >= 128 and (p8 == "1" or g.N >= 768 or not 1 <= g.N % 256 <= 128)
+                    and (a_rows * g.lda + 64) * 2 < 2 ** 32 and (g.N * g.ldb + 64) * 2 < 2 ** 32)
         if (both16 and g.a_layout == A_MK and g.b_layout == B_NK and g.a_win.enabled and not g.b_win.enabled and drp16 == "false"
                 and g.a_win.pad == 0 and g.a_win.Cw % 64 == 0 and g.split_k <= 1 and g.M >= 256 and g.N >= 128
                 and os.environ.get("TECM_BF16_DMA", "")[:1] != "0"):
-            return "gemm_bf16_dma_kernel"                  # the window route of tecm_gemm16_dma_try
+            w = g.a_win                                    # the window route of tecm_gemm16_dma_try
+            if ((w.Lout - 1) * w.stride_t + w.taps <= w.Lin and g.M % (w.Lout * w.N) == 0
+                    and p8_takes(g.M // (w.Lout * w.N) * w.Lin * w.N)):
+                return f"gemm_bf16_p8_kernel<{lib().tecm_p8_rows(g.M, g.N)}>"
+            return "gemm_bf16_dma_kernel"
         # mirrors tecm_gemm16_dma_try (csrc/gemm_bf16_dma.hip); the float4-epilogue condition holds for every bf16 call
         sel = os.environ.get("TECM_BF16_DMA", "")[:1]
         if (both16 and g.a_layout == A_MK and g.b_layout == B_NK and not g.a_win.enabled and not g.b_win.enabled
                 and g.split_k <= 1 and g.N % 4 == 0 and g.K % 32 == 0 and g.K >= 32 and g.M >= 256
                 and (g.N >= 128 or g.N == 32) and sel != "0"):
             k32, n_small = g.K < 64, g.N < 128
-            can16 = not g.c_win.enabled and not g.rowbias and \
-                (1 if g.residual else 0) + (1 if g.dact_src else 0) + (1 if g.accumulate else 0) <= 1
-            p8 = os.environ.get("TECM_BF16_P8", "")[:1]                        # mirrors tecm_gemm16_p8_try (gemm_bf16_p8.hip)
-            if (can16 and not sel and p8 != "0" and g.K >= 128 and g.N >= 128 and (p8 == "1" or g.N >= 768 or not 1 <= g.N % 256 <= 128)
-                    and (g.M * g.lda + 64) * 2 < 2 ** 32 and (g.N * g.ldb + 64) * 2 < 2 ** 32):
+            can16 = not g.c_win.enabled and not g.rowbias and streams <= 1
+            if p8_takes(g.M):
                 return f"gemm_bf16_p8_kernel<{lib().tecm_p8_rows(g.M, g.N)}>"
             narrow = n_small or (sel == "2" if (sel and not k32) else 1 <= g.N % 256 <= 128)   # the 256 x 128 geometry (N = 800)
             if narrow:

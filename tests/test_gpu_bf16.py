@@ -625,12 +625,17 @@ def test_bf16_weight_gradient_natural_orientation_kernel(dev, Mo, No, rows, bwin
         assert torch.equal(C2, outs[("1", want)])
 
 
-@pytest.mark.parametrize("Bq,Lin,N,taps,Cw,Nout", [(2, 12, 211, 4, 128, 768), (1, 8, 300, 2, 64, 256)])
-def test_bf16_dma_kernel_walks_a_window_view_of_a(dev, Bq, Lin, N, taps, Cw, Nout):
-    """The patch projection 'b (p l) d -> b p (l d)' + Linear (modules.py:114-116) with bf16 operands: the first LDS-DMA
-    geometry moves its A source pointers one time step on at every tap boundary.  Against fp64 on the bf16 values and the
-    register-staged kernel fed an fp32 copy of the same (already rounded) weight, generic epilogue (row bias + dropout)."""
+@pytest.mark.parametrize("p8", ["0", ""])
+@pytest.mark.parametrize("Bq,Lin,N,taps,Cw,Nout", [(2, 12, 211, 4, 128, 768), (1, 8, 300, 2, 64, 256), (3, 12, 2911, 4, 128, 768)])
+def test_bf16_dma_kernel_walks_a_window_view_of_a(dev, Bq, Lin, N, taps, Cw, Nout, p8, monkeypatch):
+    """The patch projection 'b (p l) d -> b p (l d)' + Linear (modules.py:114-116) with bf16 operands: the LDS-DMA kernels
+    move their A source pointers one time step on at every tap boundary -- the eight-phase geometry (round 5) and, with
+    TECM_BF16_P8 = 0, the first geometry.  Against fp64 on the bf16 values and the register-staged kernel fed an fp32 copy
+    of the same (already rounded) weight; epilogue: bias + row bias (wpe) + dropout, the straight-line form 5 of gemm_impl.h.
+    The third case has 103 m-tiles of 256 rows: tiles that straddle the (b, p) boundaries of the view."""
     from tecmollm import ops
+    if p8:
+        monkeypatch.setenv("TECM_BF16_P8", p8)
     Lout = Lin // taps
     M, K = Bq * Lout * N, taps * Cw
     src = _rand(Bq, Lin, N, Cw, dev=dev, seed=21).bfloat16()
@@ -647,7 +652,8 @@ def test_bf16_dma_kernel_walks_a_window_view_of_a(dev, Bq, Lin, N, taps, Cw, Nou
         ops.gemm(M, Nout, K, src, Cw, Wop, K, C, Nout, a_win=w, bias=bias, rowbias=(wpe, Nout, N, Lout), out_drop=spec, bf16=True)
         names = list(ops.summarize_gemm_timing(rec))
         ops.disable_gemm_timing()
-        assert ("gemm_bf16_dma_kernel" in names[0]) == (Wop.dtype == torch.bfloat16), names
+        want = ("gemm_bf16_dma_kernel" if p8 == "0" else "gemm_bf16_p8_kernel") if Wop.dtype == torch.bfloat16 else "gemm_bf16_kernel"
+        assert want in names[0], names
         outs.append(C)
     A = src.view(Bq, Lout, taps, N, Cw).permute(0, 1, 3, 2, 4).reshape(M, K).double()
     ref = A @ W16.double().t() + bias.double() + wpe.double().repeat_interleave(N, 0).repeat(Bq, 1)
@@ -655,6 +661,34 @@ def test_bf16_dma_kernel_walks_a_window_view_of_a(dev, Bq, Lin, N, taps, Cw, Nou
     mult = torch.from_numpy(rng.keep_mult(4242, np.arange(M * Nout, dtype=np.uint64).reshape(M, Nout), 0.1)).to(dev).double()
     assert _rel(outs[0], ref * mult) < TOL and _rel(outs[1], ref * mult) < TOL
     assert _rel(outs[0], outs[1]) < 1e-6
+
+
+@pytest.mark.parametrize("p8", ["0", ""])
+@pytest.mark.parametrize("Bq,Lin,N,taps,Cw,Kc", [(2, 12, 211, 4, 128, 768), (1, 8, 300, 2, 64, 256), (3, 12, 2911, 4, 128, 768)])
+def test_bf16_window_scatter_of_the_result_takes_the_straight_line_epilogue(dev, Bq, Lin, N, taps, Cw, Kc, p8, monkeypatch):
+    """The patch projection's input gradient (autograd of modules.py:114-116): d conv[b, p*l + tap, n, :] = (d h . W)[(b, p, n),
+    tap*Cw ..] -- a plain bf16 contraction whose fp32 result is scattered through a window view of C (form 6 of
+    gemm_impl.h's straight-line epilogue; rounds 1-4 ran it through the rolled generic loop).  Against fp64 on the bf16
+    values, on the eight-phase geometry and (TECM_BF16_P8 = 0) the older ones; every element of the target is written once."""
+    from tecmollm import ops
+    if p8:
+        monkeypatch.setenv("TECM_BF16_P8", p8)
+    Lout = Lin // taps
+    M, Ncols = Bq * Lout * N, taps * Cw
+    dh = _rand(M, Kc, dev=dev, seed=31).bfloat16()
+    Wt = _rand(Ncols, Kc, dev=dev, seed=32, scale=0.05).bfloat16()            # W^T as [row = (tap, c)][k]
+    bias = _rand(Ncols, dev=dev, seed=33)
+    out = torch.full((Bq, Lin, N, Cw), float("nan"), device=dev)
+    w = ops.win(N, Lin, Lout, taps, taps, Cw, 0)
+    rec = ops.enable_gemm_timing(detail=True)
+    ops.gemm(M, Ncols, Kc, dh, Kc, Wt, Kc, out, Cw, c_win=w, bias=bias, bf16=True)
+    names = list(ops.summarize_gemm_timing(rec))
+    ops.disable_gemm_timing()
+    takes = p8 == "" and not (1 <= Ncols % 256 <= 128 and Ncols < 768)      # tecm_gemm16_p8_try declines mostly empty n-tiles
+    assert ("gemm_bf16_p8_kernel" in names[0]) == takes, names
+    ref = dh.double() @ Wt.double().t() + bias.double()                       # (M, taps*Cw), row (b, p, n)
+    ref = ref.view(Bq, Lout, N, taps, Cw).permute(0, 1, 3, 2, 4).reshape(Bq, Lin, N, Cw)
+    assert torch.isfinite(out).all() and _rel(out, ref) < TOL
 
 
 @pytest.mark.parametrize("Bn,Lc,N,cin,ld_in,Cout,stride", [(2, 48, 7, 22, 24, 64, 2), (1, 24, 9, 64, 64, 128, 2), (1, 8, 5, 22, 24, 64, 1)])

@@ -884,7 +884,7 @@ __device__ __forceinline__ void gemm_bf16_dma5_body(const TecmGemm& g, int tiles
   const int lcol = (lane % LPR) * 4, lrow = lane / LPR;
   const EpiCol ecol = epi_col(g, n0 + wn * WTN + lcol);
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (g.bias && ecol.ok) bias4 = *reinterpret_cast<const float4*>(g.bias + ecol.n);
+  if (g.bias) bias4 = *reinterpret_cast<const float4*>(g.bias + (ecol.ok ? ecol.n : 0));   // (lanes outside the matrix: column 0, never stored)
   tecm_gemm::epi_fast_dispatch<MT / 2, 32 / RPI, RPI, STG_LD, true>(fmode, g, odc, stg, lrow, lcol, m0 + wm * WTM, ecol, bias4,
                                                                 stage_slab);
   if constexpr (MT % 2 == 1) {                           // the ninth row tile: a half slab of 16 rows
@@ -1081,7 +1081,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma6_kernel(const TecmGemm g
   const int lcol = (lane % LPR) * 4, lrow = lane / LPR;
   const EpiCol ecol = epi_col(g, n0 + wn * WTN + lcol);
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (g.bias && ecol.ok) bias4 = *reinterpret_cast<const float4*>(g.bias + ecol.n);
+  if (g.bias) bias4 = *reinterpret_cast<const float4*>(g.bias + (ecol.ok ? ecol.n : 0));   // (lanes outside the matrix: column 0, never stored)
   tecm_gemm::epi_fast_dispatch<WTM / 32, 32 / RPI, RPI, STG_LD, true>(fmode, g, odc, stg, lrow, lcol, m0 + wm * WTM, ecol, bias4,
                                                                   stage_slab);
 }

@@ -735,7 +735,7 @@ __device__ __forceinline__ void block_epilogue16(const TecmGemm& g, f32x16 (&acc
     const int lcol = (lane % LPR) * 4, lrow = lane / LPR;
     const EpiCol ecol = epi_col(g, n0 + wn * WTN + lcol);
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (g.bias && ecol.ok) bias4 = *reinterpret_cast<const float4*>(g.bias + ecol.n);
+    if (g.bias) bias4 = *reinterpret_cast<const float4*>(g.bias + (ecol.ok ? ecol.n : 0));   // (lanes outside the matrix: column 0, never stored)
     if constexpr (HALF) {
       auto stage_half = [&](auto sc) {                   // half slab hs of 32-row slab i: accumulator registers 8hs .. 8hs+7
         constexpr int i = decltype(sc)::value / 2, hs = decltype(sc)::value % 2;
@@ -771,7 +771,7 @@ __device__ __forceinline__ void block_epilogue16(const TecmGemm& g, f32x16 (&acc
       const int lcol = (lane % LPR) * 4, lrow = lane / LPR;
       const EpiCol ecol = epi_col(g, n0 + wn * WTN + lcol);
       float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (g.bias && ecol.ok) bias4 = *reinterpret_cast<const float4*>(g.bias + ecol.n);
+      if (g.bias) bias4 = *reinterpret_cast<const float4*>(g.bias + (ecol.ok ? ecol.n : 0));   // (lanes outside the matrix: column 0, never stored)
 #pragma unroll 1
       for (int it = 0; it < 32 / RPI; ++it) {
         const int rl = it * RPI + lrow;

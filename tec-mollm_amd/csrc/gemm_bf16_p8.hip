@@ -10,8 +10,31 @@
 // The summation order is the fifth geometry's per MFMA but K is walked 64 at a time in quadrant order: results agree
 // with it to fp32 rounding (test_bf16_p8_geometry_agrees_to_fp32_rounding), and launches are bit-reproducible.
 #include <cstdlib>
+#ifdef P8_STAMPS
+#include <hip/hip_runtime.h>
+__shared__ unsigned long long p8_epi_ts[16];
+#define TECM_EPI_STAMP(i) do { if (threadIdx.x == 0) p8_epi_ts[(i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#endif
 #include "gemm_bf16_impl.h"
 #include "gemm_bf16_p8_loop.h"
+
+#ifdef P8_STAMPS                                         // diagnostics (tools/build_variant.py): per-block time stamps, 10 ns ticks
+__device__ unsigned long long p8_stamps[8 * 8192];       // [block][t_entry, t_kloop_done, t_stores_issued, t_stores_acked, hw_id, xcc_id, -, -]
+__device__ unsigned long long p8_epi_stamps[16 * 8192];  // [block][slab][before park, parked, rows done]
+extern "C" int tecm_p8_stamps_read(unsigned long long* dst, int n) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(p8_stamps), sizeof(unsigned long long) * n);
+}
+extern "C" int tecm_p8_epi_stamps_read(unsigned long long* dst, int n) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(p8_epi_stamps), sizeof(unsigned long long) * n);
+}
+#define P8_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) p8_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define P8_STAMP(i) do { } while (0)
+#endif
+
+#ifndef P8_SPECIAL                                       // false: every epilogue through the run-time feature tests (A/B)
+#define P8_SPECIAL true
+#endif
 
 namespace tecm_gemm16 {
 
@@ -43,6 +66,13 @@ __global__ __launch_bounds__(tecm_p8::NTH, 1) void gemm_bf16_p8_kernel(const Tec
   const int64_t m0 = (int64_t)tm * BM;
   const int64_t n0 = (int64_t)tn * BN;
 
+  P8_STAMP(0);
+#ifdef P8_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x < 8192) {
+    p8_stamps[blockIdx.x * 8 + 4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
+    p8_stamps[blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // XCC_ID
+  }
+#endif
   tecm_p8::f32x4 acc[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -66,6 +96,7 @@ __global__ __launch_bounds__(tecm_p8::NTH, 1) void gemm_bf16_p8_kernel(const Tec
     return;
   }
 #endif
+  P8_STAMP(1);
   __syncthreads();                                      // every wave has left the K loop: the ring becomes staging
   // ---- epilogue: gemm_impl.h's straight-line form over this wave's private staging rows.  Accumulator map (BMAP 1,
   // gemm_bf16_p8_loop.h): lane (fr, fq) holds 16 consecutive columns 16 fq .. of row 16 i + fr, so a slab of 32 rows is
@@ -101,9 +132,16 @@ __global__ __launch_bounds__(tecm_p8::NTH, 1) void gemm_bf16_p8_kernel(const Tec
   const int lcol = (lane % LPR) * 4, lrow = lane / LPR;
   const EpiCol ecol = epi_col(g, n0 + wn * WTN + lcol);
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (g.bias && ecol.ok) bias4 = *reinterpret_cast<const float4*>(g.bias + ecol.n);
-  tecm_gemm::epi_fast_dispatch<SLABS, 32 / RPI, RPI, STG_LD, true>(fmode, gw, odc, stg, lrow, lcol, m0 + wm * WTM, ecol, bias4,
-                                                               stage_slab);
+  if (g.bias) bias4 = *reinterpret_cast<const float4*>(g.bias + (ecol.ok ? ecol.n : 0));   // (lanes outside the matrix: column 0, never stored)
+  tecm_gemm::epi_fast_dispatch<SLABS, 32 / RPI, RPI, STG_LD, true, P8_SPECIAL>(fmode, gw, odc, stg, lrow, lcol, m0 + wm * WTM, ecol, bias4,
+                                                                     stage_slab);
+#ifdef P8_STAMPS
+  P8_STAMP(2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  P8_STAMP(3);
+  if (threadIdx.x == 0 && blockIdx.x < 8192)
+    for (int i = 0; i < 12; ++i) p8_epi_stamps[blockIdx.x * 16 + i] = p8_epi_ts[i];
+#endif
 }
 
 }  // namespace tecm_gemm16

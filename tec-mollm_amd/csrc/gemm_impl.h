@@ -520,29 +520,35 @@ __device__ __forceinline__ void epi_vec4(const TecmGemm& g, const DropCtx& odc, 
 // fully unrolled, the one optional input stream (MODE 1: residual, MODE 2: GELU' source) loaded for ALL groups up
 // front, then LDS read -> arithmetic -> stores back to back with counted waits only.  Element arithmetic is
 // epi_vec4's, expression for expression.
+#ifndef TECM_EPI_STAMP                                   // diagnostics hook (gemm_bf16_p8.hip -DP8_STAMPS); nothing otherwise
+#define TECM_EPI_STAMP(i) do { } while (0)
+#endif
 template <int NIT, int RPI, int MODE>
 __device__ __forceinline__ void epi_fast_load(const TecmGemm& g, int lrow, int64_t mrow0, const EpiCol& ecol,
                                               float4 (&in)[NIT]) {
+  const int32_t ncol = ecol.ok ? ecol.n : 0;             // lanes outside the matrix load column 0 (valid, never stored)
   if constexpr (MODE == 5) {                             // row bias: row ((m / rb_div) % rb_mod) of a small table (wpe)
-    if (!ecol.ok) return;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       int64_t m = mrow0 + it * RPI + lrow;
       m = m < g.M ? m : g.M - 1;
       const uint32_t rr = ((uint32_t)m / (uint32_t)g.rb_div) % (uint32_t)g.rb_mod;
-      in[it] = *reinterpret_cast<const float4*>(g.rowbias + (int64_t)rr * g.rb_ld + ecol.n);
+      in[it] = *reinterpret_cast<const float4*>(g.rowbias + (int64_t)rr * g.rb_ld + ncol);
     }
   }
   if constexpr (MODE >= 1 && MODE <= 3) {
-    if (!ecol.ok) return;
     const float* src = MODE == 1 ? g.residual : (MODE == 2 ? g.dact_src : g.C);
     const int64_t ld = MODE == 1 ? g.ldr : (MODE == 2 ? g.ldd : g.ldc);
+    // one 64-bit multiply per slab: row group `it` lies it * RPI rows = it * step elements further on (integer multiplies
+    // are quarter rate; three of them per address and row group were most of this epilogue's issue time); rows past M read
+    // the last row instead (a valid address, the value is never stored)
+    const int32_t mb = (int32_t)mrow0 + lrow;            // M < 2^31 (host)
+    const int64_t off0 = (int64_t)mb * ld + ncol, step = (int64_t)RPI * ld, off_last = (g.M - 1) * ld + ncol;
     if (MODE == 2 && (g.io_bf16 & TECM_IO_PRE_BF16)) {   // bf16 GELU' source: the RAW 8 bytes travel in in[].x/.y and are
 #pragma unroll                                            // widened where they are used (converting here would be a wait)
       for (int it = 0; it < NIT; ++it) {
-        int64_t m = mrow0 + it * RPI + lrow;
-        m = m < g.M ? m : g.M - 1;
-        const float2 raw = *reinterpret_cast<const float2*>(reinterpret_cast<const __bf16*>(src) + m * ld + ecol.n);
+        const int64_t off = mb + it * RPI < (int32_t)g.M ? off0 + it * step : off_last;
+        const float2 raw = *reinterpret_cast<const float2*>(reinterpret_cast<const __bf16*>(src) + off);
         in[it].x = raw.x;
         in[it].y = raw.y;
       }
@@ -550,26 +556,53 @@ __device__ __forceinline__ void epi_fast_load(const TecmGemm& g, int lrow, int64
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      int64_t m = mrow0 + it * RPI + lrow;
-      m = m < g.M ? m : g.M - 1;                       // clamped: a valid address, the value is not used
-      in[it] = *reinterpret_cast<const float4*>(src + m * ld + ecol.n);
+      const int64_t off = mb + it * RPI < (int32_t)g.M ? off0 + it * step : off_last;
+      in[it] = *reinterpret_cast<const float4*>(src + off);
     }
   }
 }
-template <int NIT, int RPI, int STG_LD, int MODE, bool NT>
+// FEAT: -1 = the features of the call are tested at run time (wave-uniform branches inside every row group: eight or so
+// scalar branches per group, each a fetch redirect -- by the time stamps of DESIGN_HISTORY B.11 most of a plain row group's
+// 150 ns); >= 0 = a compile-time feature mask, for the handful of combinations the training step runs (epi_fast_dispatch):
+enum { EPI_F_PRE = 1, EPI_F_P16 = 2, EPI_F_ACT = 4, EPI_F_DROP = 8, EPI_F_C16 = 16 };
+template <int FEAT, int BIT>
+__device__ __forceinline__ bool epi_feat(bool dynamic) {
+  if constexpr (FEAT < 0) return dynamic;
+  else return (FEAT & BIT) != 0;
+}
+template <int NIT, int RPI, int STG_LD, int MODE, bool NT, int FEAT = -1>
 __device__ __forceinline__ void epi_fast_rows(const TecmGemm& g, const DropCtx& odc, const float* stg, int lrow, int lcol,
                                               int64_t mrow0, const EpiCol& ecol, const float4& bias4,
                                               const float4 (&in)[NIT]) {
-  if (!ecol.ok) return;
+  // (Round 5, from per-block time stamps and the ISA of the eight-phase kernel -- DESIGN_HISTORY B.11: a lane outside the
+  //  matrix used to `return` here.  That divergent skip of a whole slab made every later slab's first use of bias4 wait
+  //  with vmcnt(0) -- the path that skipped still "had the bias load pending" -- i.e. for ALL stores of the previous slab;
+  //  and with one LDS read per row group inside the feature branches every group waited for its own read.  Now the
+  //  column test only masks the stores, and a slab's staged rows are read four groups at a time before any of them is used.)
   const int32_t n = ecol.n;
-  const bool c16 = (g.io_bf16 & TECM_IO_C_BF16) != 0;
-  const bool p16 = (g.io_bf16 & TECM_IO_PRE_BF16) != 0;
+  const bool c16 = epi_feat<FEAT, EPI_F_C16>((g.io_bf16 & TECM_IO_C_BF16) != 0);
+  const bool p16 = epi_feat<FEAT, EPI_F_P16>((g.io_bf16 & TECM_IO_PRE_BF16) != 0);
+  const bool has_pre = epi_feat<FEAT, EPI_F_PRE>(g.preact != nullptr);
+  const bool has_act = epi_feat<FEAT, EPI_F_ACT>(g.act != 0);
+  const bool has_drop = epi_feat<FEAT, EPI_F_DROP>(odc.thresh != 0);
+  constexpr int GRP = NIT < 4 ? NIT : 4;              // (8 at a time spilled 15 registers in the eight-phase kernel)
+  static_assert(NIT % GRP == 0, "row groups are read from the staging rows in whole batches");
+  // addresses: one 64-bit multiply per tensor and slab, then it * (RPI * ld) per row group (see epi_fast_load)
+  const int32_t mb = (int32_t)mrow0 + lrow;              // M < 2^31 (host)
+  const int64_t offC0 = (int64_t)mb * g.ldc + n, stepC = (int64_t)RPI * g.ldc;
+  const int64_t offP0 = (int64_t)mb * g.ldp + n, stepP = (int64_t)RPI * g.ldp;
+  const int64_t idxD0 = (int64_t)mb * odc.ld + n, stepD = (int64_t)RPI * odc.ld;
+  float4 vv[GRP];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
-    const int rl = it * RPI + lrow;
-    const int64_t m = mrow0 + rl;
-    const float4 v = *reinterpret_cast<const float4*>(&stg[rl * STG_LD + lcol]);
-    const bool row_ok = m < g.M;
+    if (it % GRP == 0) {
+#pragma unroll
+      for (int j = 0; j < GRP; ++j)
+        vv[j] = *reinterpret_cast<const float4*>(&stg[((it + j) * RPI + lrow) * STG_LD + lcol]);
+    }
+    const int64_t m = mb + it * RPI;
+    const float4 v = vv[it % GRP];
+    const bool row_ok = mb + it * RPI < (int32_t)g.M && ecol.ok;
     if constexpr (MODE == 4) {                         // split-K slab: the raw partial sums
       if (row_ok) *reinterpret_cast<float4*>(g.workspace + ((int64_t)blockIdx.z * g.M + m) * g.N + n) = v;
       continue;
@@ -578,21 +611,21 @@ __device__ __forceinline__ void epi_fast_rows(const TecmGemm& g, const DropCtx& 
     if constexpr (MODE == 5) {                         // + row bias, where epi_vec4 adds it: before pre-activation / act / dropout
       o[0] += in[it].x; o[1] += in[it].y; o[2] += in[it].z; o[3] += in[it].w;
     }
-    if (g.preact && p16) {                             // bf16 pre-activation (see epi_vec4)
+    if (has_pre && p16) {                              // bf16 pre-activation (see epi_vec4)
       tecm_bf16x4 hv;
       hv[0] = (__bf16)o[0]; hv[1] = (__bf16)o[1]; hv[2] = (__bf16)o[2]; hv[3] = (__bf16)o[3];
       if (row_ok) {
-        tecm_bf16x4* dst = reinterpret_cast<tecm_bf16x4*>(reinterpret_cast<__bf16*>(g.preact) + m * g.ldp + n);
+        tecm_bf16x4* dst = reinterpret_cast<tecm_bf16x4*>(reinterpret_cast<__bf16*>(g.preact) + (offP0 + it * stepP));
         if constexpr (NT) __builtin_nontemporal_store(hv, dst);
         else *dst = hv;
       }
       o[0] = (float)hv[0]; o[1] = (float)hv[1]; o[2] = (float)hv[2]; o[3] = (float)hv[3];
-    } else if (g.preact && row_ok) {
+    } else if (has_pre && row_ok) {
       if constexpr (NT) {                              // streamed past L2: the operand panels stay (bf16 LDS-DMA kernel)
         f32x4 nv = {o[0], o[1], o[2], o[3]};
-        __builtin_nontemporal_store(nv, reinterpret_cast<f32x4*>(g.preact + m * g.ldp + n));
+        __builtin_nontemporal_store(nv, reinterpret_cast<f32x4*>(g.preact + (offP0 + it * stepP)));
       } else {
-        *reinterpret_cast<float4*>(g.preact + m * g.ldp + n) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4*>(g.preact + (offP0 + it * stepP)) = make_float4(o[0], o[1], o[2], o[3]);
       }
     }
     if constexpr (MODE == 2) {
@@ -605,12 +638,12 @@ __device__ __forceinline__ void epi_fast_rows(const TecmGemm& g, const DropCtx& 
       o[0] *= dgelu_tanh(t0); o[1] *= dgelu_tanh(t1);
       o[2] *= dgelu_tanh(t2); o[3] *= dgelu_tanh(t3);
     } else {
-      if (g.act) {
+      if (has_act) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = gelu_tanh(o[e]);
       }
     }
-    int64_t off = m * g.ldc + n, didx = m * odc.ld + n;
+    int64_t off = offC0 + it * stepC, didx = idxD0 + it * stepD;
     bool st_ok = row_ok;
     if constexpr (MODE == 6) {                         // window scatter (epi_vec4's address arithmetic): column n = (tap, c)
       const WinRow w = win_row(g.c_win, m < g.M ? m : g.M - 1, g.M);
@@ -620,7 +653,7 @@ __device__ __forceinline__ void epi_fast_rows(const TecmGemm& g, const DropCtx& 
       off = row * g.ldc + ecol.c;
       didx = row * odc.ld + ecol.c;
     }
-    if (odc.thresh) {
+    if (has_drop) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] *= tecm_drop_mult(odc.seed, (uint64_t)(didx + e), odc.thresh, odc.inv);
     }
@@ -650,17 +683,20 @@ __device__ __forceinline__ void epi_fast_rows(const TecmGemm& g, const DropCtx& 
 // One wave's staged block of SLABS x (NIT * RPI) rows: the input stream of slab s+1 is requested BEFORE the stores
 // of slab s are issued, so that waiting for it does not mean waiting for those stores (vmcnt retires in order).
 // stage(s) parks slab s of the accumulators in the wave's PRIVATE staging rows (no barrier: nobody else reads them).
-template <int SLABS, int NIT, int RPI, int STG_LD, int MODE, bool NT, typename StageFn>
+template <int SLABS, int NIT, int RPI, int STG_LD, int MODE, bool NT, int FEAT = -1, typename StageFn>
 __device__ __forceinline__ void epi_fast_block(const TecmGemm& g, const DropCtx& odc, const float* stg, int lrow, int lcol,
                                                int64_t mrow0, const EpiCol& ecol, const float4& bias4, StageFn&& stage) {
   float4 in[2][NIT];
   epi_fast_load<NIT, RPI, MODE>(g, lrow, mrow0, ecol, in[0]);
   static_for<SLABS>([&](auto sc) {
     constexpr int sl = decltype(sc)::value;
+    TECM_EPI_STAMP(3 * sl);
     stage(sc);
+    TECM_EPI_STAMP(3 * sl + 1);
     if constexpr (sl + 1 < SLABS)
       epi_fast_load<NIT, RPI, MODE>(g, lrow, mrow0 + (int64_t)(sl + 1) * NIT * RPI, ecol, in[(sl + 1) & 1]);
-    epi_fast_rows<NIT, RPI, STG_LD, MODE, NT>(g, odc, stg, lrow, lcol, mrow0 + (int64_t)sl * NIT * RPI, ecol, bias4, in[sl & 1]);
+    epi_fast_rows<NIT, RPI, STG_LD, MODE, NT, FEAT>(g, odc, stg, lrow, lcol, mrow0 + (int64_t)sl * NIT * RPI, ecol, bias4, in[sl & 1]);
+    TECM_EPI_STAMP(3 * sl + 2);
   });
 }
 // which epilogues the straight-line form serves (everything else: the generic loop)
@@ -679,10 +715,24 @@ __device__ __forceinline__ int epi_fast_mode(const TecmGemm& g) {
   return g.residual ? 1 : (g.dact_src ? 2 : (g.accumulate ? 3 : 0));
 }
 // dispatch on the (wave-uniform) mode
-template <int SLABS, int NIT, int RPI, int STG_LD, bool NT = false, typename StageFn>
+// SPECIAL (the eight-phase bf16 kernel): the four feature combinations of the bf16 training step run branch-free
+template <int SLABS, int NIT, int RPI, int STG_LD, bool NT = false, bool SPECIAL = false, typename StageFn>
 __device__ __forceinline__ void epi_fast_dispatch(int mode, const TecmGemm& g, const DropCtx& odc, const float* stg, int lrow,
                                                   int lcol, int64_t mrow0, const EpiCol& ecol, const float4& bias4,
                                                   StageFn&& stage) {
+  if constexpr (SPECIAL) {
+    const int feat = (g.preact ? EPI_F_PRE : 0) | ((g.io_bf16 & TECM_IO_PRE_BF16) ? EPI_F_P16 : 0) | (g.act ? EPI_F_ACT : 0) |
+                     (odc.thresh ? EPI_F_DROP : 0) | ((g.io_bf16 & TECM_IO_C_BF16) ? EPI_F_C16 : 0);
+    if (mode == 0 && feat == EPI_F_C16)                                  // bf16 result (+ bias): c_attn, the d-input GEMMs
+      return epi_fast_block<SLABS, NIT, RPI, STG_LD, 0, NT, EPI_F_C16>(g, odc, stg, lrow, lcol, mrow0, ecol, bias4, stage);
+    if (mode == 0 && feat == (EPI_F_PRE | EPI_F_P16 | EPI_F_ACT | EPI_F_C16))                    // mlp.c_fc
+      return epi_fast_block<SLABS, NIT, RPI, STG_LD, 0, NT, EPI_F_PRE | EPI_F_P16 | EPI_F_ACT | EPI_F_C16>(g, odc, stg, lrow, lcol, mrow0,
+                                                                                                    ecol, bias4, stage);
+    if (mode == 1 && feat == EPI_F_DROP)                                 // attn.c_proj / mlp.c_proj: dropout + residual, fp32
+      return epi_fast_block<SLABS, NIT, RPI, STG_LD, 1, NT, EPI_F_DROP>(g, odc, stg, lrow, lcol, mrow0, ecol, bias4, stage);
+    if (mode == 2 && (feat & ~EPI_F_ACT) == (EPI_F_P16 | EPI_F_C16))     // d mlp.c_proj x GELU' (mode 2 ignores `act`)
+      return epi_fast_block<SLABS, NIT, RPI, STG_LD, 2, NT, EPI_F_P16 | EPI_F_C16>(g, odc, stg, lrow, lcol, mrow0, ecol, bias4, stage);
+  }
   if (mode == 0) epi_fast_block<SLABS, NIT, RPI, STG_LD, 0, NT>(g, odc, stg, lrow, lcol, mrow0, ecol, bias4, stage);
   else if (mode == 1) epi_fast_block<SLABS, NIT, RPI, STG_LD, 1, NT>(g, odc, stg, lrow, lcol, mrow0, ecol, bias4, stage);
   else if (mode == 2) epi_fast_block<SLABS, NIT, RPI, STG_LD, 2, NT>(g, odc, stg, lrow, lcol, mrow0, ecol, bias4, stage);
@@ -724,7 +774,7 @@ __device__ __forceinline__ void block_epilogue(const TecmGemm& g, f32x16 (&acc)[
     const int lcol = (lane % LPR) * 4, lrow = lane / LPR;
     const EpiCol ecol = epi_col(g, n0 + wn * WTN + lcol);
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (g.bias && ecol.ok) bias4 = *reinterpret_cast<const float4*>(g.bias + ecol.n);
+    if (g.bias) bias4 = *reinterpret_cast<const float4*>(g.bias + (ecol.ok ? ecol.n : 0));   // (lanes outside the matrix: column 0, never stored)
     const int fmode = epi_fast_mode(g);
     if (fmode >= 0) {
       // staging rows are private to the wave: no barrier (a __syncthreads here would also drain every store)

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(NTH, 2) void gemm_x3_kernel(const TecmGemm g, int t
       const int lcol = (lane % LPR) * 4, lrow = lane / LPR;
       const EpiCol ecol = epi_col(g, n0 + wn * WTN + lcol);
       float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (g.bias && ecol.ok) bias4 = *reinterpret_cast<const float4*>(g.bias + ecol.n);
+      if (g.bias) bias4 = *reinterpret_cast<const float4*>(g.bias + (ecol.ok ? ecol.n : 0));   // (lanes outside the matrix: column 0, never stored)
 #pragma unroll 1
       for (int it = 0; it < 32 / RPI; ++it) {
         const int rl = it * RPI + lrow;

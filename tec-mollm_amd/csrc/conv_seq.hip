@@ -471,8 +471,20 @@ struct FArgs {
   unsigned long long assign;   // 4 waves x 3 unit ids of 4 bits (15 = none): no kernel-argument arrays -- indexing
 };                             //   one dynamically makes the compiler copy the whole struct to scratch
 
+#ifdef CFW_STAMPS          // diagnostics (tools/build_variant.py): 10 ns time stamps of wave 0 -- entry, image staged, per unit K loop / stores
+__device__ unsigned long long cfw_stamps[16 * 8192];
+}  // namespace tecm_convseq
+extern "C" int tecm_cfw_stamps_read(unsigned long long* dst, int n) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(tecm_convseq::cfw_stamps), sizeof(unsigned long long) * n);
+}
+namespace tecm_convseq {
+#define CFW_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) cfw_stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CFW_STAMP(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(NTH, 3) void conv_fwd_seq_kernel(const FArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  CFW_STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
@@ -500,6 +512,7 @@ __global__ __launch_bounds__(NTH, 3) void conv_fwd_seq_kernel(const FArgs a) {
     }
   }
   __syncthreads();
+  CFW_STAMP(1);
 
   const int ntt = tc >> 3;
   const int cpt = a.ld_in / 8;                             // chunks per tap
@@ -567,6 +580,7 @@ __global__ __launch_bounds__(NTH, 3) void conv_fwd_seq_kernel(const FArgs a) {
       case 5: kloop(std::integral_constant<int, 5>{}); break;
       default: kloop(std::integral_constant<int, MAXT>{}); break;
     }
+    CFW_STAMP(2 + 2 * ui);                                 // wave 0: this unit's K loop done
     if (CFW_ABLATE & 4) {                                  // keep the accumulators alive without storing them
       float keep = 0.f;
 #pragma unroll
@@ -614,6 +628,7 @@ __global__ __launch_bounds__(NTH, 3) void conv_fwd_seq_kernel(const FArgs a) {
           }
         }
       }
+      CFW_STAMP(3 + 2 * ui);                               // wave 0: this unit's stores issued
       if (a.stats) {
         // one pass of shifted sums -- shift = the wave's first value, so that sum((v - s)^2) - sum(v - s)^2 / n does not
         // cancel when |mean| >> std -- and eight wave reductions per unit
@@ -654,6 +669,7 @@ __global__ __launch_bounds__(NTH, 3) void conv_fwd_seq_kernel(const FArgs a) {
       }
     }
   }
+  CFW_STAMP(8);
   if (a.stats) {
     __syncthreads();
     if (tid < 3 * NB) {

@@ -34,7 +34,7 @@ def timeit(fn, n):
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 
-which = sys.argv[1] if len(sys.argv) > 1 else ("all" if __name__ == "__main__" else "none")
+which = sys.argv[1] if len(sys.argv) > 1 else "all"
 if which in ("all", "equiv"):
     # equivalence with dropout off: 4 steps eager vs 4 steps graphed from the same init
     outs = []

@@ -27,6 +27,7 @@
 // Block end: node-embedding halves of dW_l / dW_r (one more outer-product pass over the register sums), node-table rows by
 // atomics, everything else into this block's row of `partials` in the first formulation's layout
 // [dWl (C*C) | dbl (C) | dWr (C*C) | dbr (C) | datt (C) | dbias (C, unused)] -- the caller's column sum is unchanged.
+#include <cstdlib>
 #include "spatial2_common.h"
 
 using namespace tecm_spatial;
@@ -578,6 +579,10 @@ extern "C" int tecm_spatial_bwd2_blocks(const TecmSpatial* dp) {
   if ((size_t)m.total * sizeof(float) > 80 * 1024) return 0;   // two blocks per CU; a tile with more edges: first formulation
   const int G = d.B * d.L;
   int nch = (SPB2_OCC * 256) / d.num_tiles;                   // one round of SPB2_OCC blocks per CU
+  if (const char* e = std::getenv("TECM_SPB2_NCH")) {         // diagnostics: chunks of graphs per tile
+    const int v = atoi(e);
+    if (v > 0) nch = v;
+  }
   if (nch < 1) nch = 1;
   if (nch > G) nch = G;
   const int gc = (G + nch - 1) / nch;

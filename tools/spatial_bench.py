@@ -8,7 +8,7 @@ from src.model.tec_mollm import TEC_MoLLM
 from tecmollm import functions as F_, graph as graph_
 from src.model.modules import make_plan
 from tecmollm.synthetic import grid_graph, synthetic_batch
-B, L, cin = 8, 48, 10
+B, L, cin = int(os.environ.get("BATCH", "8")), 48, 10
 cfg = {"num_nodes": 2911, "d_emb": 22 - cin, "spatial_in_channels_base": cin, "spatial_out_channels": 11,
        "spatial_heads": 2, "temporal_channel_list": [64, 128], "temporal_strides": [2, 2], "patch_len": 4, "d_llm": 768,
        "llm_layers": 1, "prediction_horizon": 12, "temporal_seq_len": L, "num_years": 13, "gat_graphs": "per_timestep",

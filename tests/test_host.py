@@ -66,6 +66,25 @@ def test_conv_sequence_kernels_report_what_they_serve_including_the_lds_budget(b
     assert not ops.conv_fwd_seq_ok(48, 256, 64) and not ops.conv_dx_seq_ok(20, 64, 24) and not ops.conv_dx_seq_ok(48, 64, 128)
 
 
+def test_eight_phase_gemm_tile_height_is_chosen_by_tile_count(built_lib, monkeypatch):
+    """tecm_p8_rows is pure host arithmetic (no launch; without a GPU it assumes 256 CUs): 224-row tiles only for results at
+    most three tiles wide or at most 32 768 rows tall whose tile count then fills the last round of CUs better, 256 rows
+    otherwise; TECM_P8_ROWS pins a height (csrc/gemm_bf16_p8.hip)."""
+    from tecmollm import _lib
+    h = _lib.lib()
+    monkeypatch.delenv("TECM_P8_ROWS", raising=False)
+    assert h.tecm_p8_rows(69864, 768) == 112           # 819 tiles = 3.2 rounds -> 936 tiles of 7/8 the work
+    assert h.tecm_p8_rows(69864, 3072) == 128          # 12.8 rounds: nothing to win
+    assert h.tecm_p8_rows(69864, 2304) == 128          # wider than three tiles: measured slower on short tiles
+    assert h.tecm_p8_rows(23288, 2304) == 112          # few m-tiles (the head's d-input)
+    assert h.tecm_p8_rows(65536, 768) == 128           # 768 tiles = exactly three rounds
+    for rows in (128, 112, 96):
+        monkeypatch.setenv("TECM_P8_ROWS", str(rows))
+        assert h.tecm_p8_rows(69864, 3072) == rows
+    monkeypatch.setenv("TECM_P8_ROWS", "100")
+    assert h.tecm_p8_rows(69864, 3072) == 128          # not a height the kernel is built for: ignored
+
+
 def test_product_path_refuses_cpu_tensors(built_lib):
     """No CPU fallback: the model raises instead of silently computing somewhere else."""
     from tests.parity import build_model
